@@ -1,0 +1,138 @@
+"""ctypes binding of libcovahip.so (the C-ABI declared in include/covahip.h).
+
+The product path has no CPU fallback: if the shared library (built by
+`__graft_entry__.build()` / `make -C cova_amd/csrc`) is missing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcovahip.so")
+
+OK = 0
+MEM_HOST, MEM_DEVICE = 0, 1
+AU_DELTA_UNIT, AU_DISCONT, AU_DROPPABLE = 1, 2, 4
+
+
+class CovahipError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        msg = f"{where}: {lib().covahip_strerror(status).decode()} (status {status})"
+        if detail:
+            msg += f" [{detail}]"
+        super().__init__(msg)
+
+
+class Box(C.Structure):
+    _fields_ = [("left", C.c_int32), ("top", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("area_px", C.c_int32)]
+
+
+BOX_DTYPE = np.dtype([("left", "<i4"), ("top", "<i4"), ("width", "<i4"), ("height", "<i4"), ("area_px", "<i4")])
+
+BBOX_DTYPE = np.dtype([
+    ("left", "<f4"), ("top", "<f4"), ("width", "<f4"), ("height", "<f4"), ("area", "<f4"),
+    ("_pad0", "<u4"),
+    ("track_id", "<u8"), ("timestamp", "<u8"), ("class_id", "<u4"), ("confidence", "<f4"),
+    ("has_track_id", "u1"), ("has_timestamp", "u1"), ("has_class_id", "u1"), ("has_confidence", "u1"),
+    ("_pad1", "<u4"),
+])
+assert BBOX_DTYPE.itemsize == 56
+
+AU_OUT_DTYPE = np.dtype([("id", "<u8"), ("pts", "<u8"), ("flags", "<u4"), ("list", "<u4")])
+
+KERNEL_TIME_DTYPE = np.dtype([("name", "S48"), ("total_ms", "<f8"), ("launches", "<i8")])
+
+
+class GopFilterCfg(C.Structure):
+    _fields_ = [("sort_iou", C.c_float), ("sort_maxage", C.c_uint32), ("sort_minhits", C.c_uint32),
+                ("alpha", C.c_uint32), ("beta", C.c_uint32), ("infer_i", C.c_uint8)]
+
+
+# name -> (restype, argtypes); every symbol include/covahip.h declares
+_P = C.c_void_p
+_SZ = C.c_size_t
+PROTOTYPES = {
+    "covahip_strerror": (C.c_char_p, [C.c_int]),
+    "covahip_version": (C.c_char_p, []),
+    "covahip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "covahip_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "covahip_ctx_destroy": (None, [_P]),
+    "covahip_ctx_sync": (C.c_int, [_P]),
+    "covahip_last_hip_error": (C.c_char_p, [_P]),
+    "covahip_device_info": (C.c_int, [_P, C.c_char_p, _SZ, C.POINTER(C.c_int), C.POINTER(_SZ)]),
+    "covahip_malloc": (C.c_int, [_P, _SZ, C.POINTER(_P)]),
+    "covahip_free": (C.c_int, [_P, _P]),
+    "covahip_memcpy_h2d": (C.c_int, [_P, _P, _P, _SZ]),
+    "covahip_memcpy_d2h": (C.c_int, [_P, _P, _P, _SZ]),
+    "covahip_memset": (C.c_int, [_P, _P, C.c_int, _SZ]),
+    "covahip_timer_start": (C.c_int, [_P, C.c_int]),
+    "covahip_timer_stop": (C.c_int, [_P, C.c_int]),
+    "covahip_timer_elapsed_ms": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
+    "covahip_profile_enable": (C.c_int, [_P, C.c_int]),
+    "covahip_profile_reset": (C.c_int, [_P]),
+    "covahip_profile_read": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
+    "covahip_blobnet_load": (C.c_int, [_P, _P, _SZ, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "covahip_blobnet_forward": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int]),
+    "covahip_blobnet_macs_per_frame": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "covahip_blobnet_set_impl": (C.c_int, [_P, C.c_int]),
+    "covahip_bboxcc": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int]),
+    "covahip_filter_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int]),
+    "covahip_boxes_to_bbox": (None, [_P, C.c_int, _P]),
+    "covahip_bbox_serialize_vec": (_SZ, [_P, _SZ, _P, _SZ, C.POINTER(C.c_int)]),
+    "covahip_bbox_deserialize_vec": (C.c_int, [_P, _SZ, _P, _SZ, C.POINTER(_SZ)]),
+    "covahip_frame_serialize": (_SZ, [C.c_uint64, C.c_uint64, _P, _SZ, _P, _SZ, C.POINTER(C.c_int)]),
+    "covahip_bbox_iou": (C.c_float, [_P, _P]),
+    "covahip_stack_new": (C.c_int, [_SZ, C.c_uint, C.c_uint, C.POINTER(_P)]),
+    "covahip_stack_free": (None, [_P]),
+    "covahip_stack_push": (C.c_int, [_P, _P, _SZ, _P, _SZ, C.POINTER(C.c_int)]),
+    "covahip_stack_out_dims": (None, [C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "covahip_sort_new": (C.c_int, [C.c_uint64, C.c_uint64, C.c_float, C.POINTER(_P)]),
+    "covahip_sort_free": (None, [_P]),
+    "covahip_sort_update": (C.c_int, [_P, _P, _SZ, C.c_uint64, _P, _SZ, C.POINTER(_SZ), _P, _SZ, C.POINTER(_SZ)]),
+    "covahip_sort_finalize": (C.c_int, [_P, _P, _SZ, C.POINTER(_SZ), _P, _SZ, C.POINTER(_SZ)]),
+    "covahip_sort_mark_seen": (C.c_int, [_P, C.c_uint64]),
+    "covahip_sort_num_trackers": (C.c_int, [_P, C.POINTER(_SZ)]),
+    "covahip_sort_tracker_info": (C.c_int, [_P, _SZ, C.POINTER(C.c_uint64), C.POINTER(C.c_int),
+                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _P]),
+    "covahip_linear_assignment": (_SZ, [_P, _SZ, _SZ, _P, _SZ]),
+    "covahip_gopfilter_default_cfg": (None, [C.POINTER(GopFilterCfg)]),
+    "covahip_gopfilter_new": (C.c_int, [C.POINTER(GopFilterCfg), C.POINTER(_P)]),
+    "covahip_gopfilter_free": (None, [_P]),
+    "covahip_gopfilter_push_enc": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32]),
+    "covahip_gopfilter_push_boxes": (C.c_int, [_P, _P, _SZ, C.c_uint64, _P, _SZ, C.POINTER(_SZ)]),
+    "covahip_gopfilter_eos": (C.c_int, [_P, _P, _SZ, C.POINTER(_SZ)]),
+    "covahip_gopfilter_counters": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                             C.POINTER(C.c_uint64)]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads libcovahip.so; raises (no fallback) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C cova_amd/csrc` -- cova_amd has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status: int, where: str, ctx=None) -> None:
+    if status != OK:
+        detail = ""
+        if ctx is not None and status == 3:
+            detail = lib().covahip_last_hip_error(ctx).decode()
+        raise CovahipError(status, where, detail)

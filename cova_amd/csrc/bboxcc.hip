@@ -1,0 +1,314 @@
+// bboxcc on gfx950: 8-connected component labelling + per-component statistics + area
+// filter + OpenCV-order compaction, one workgroup per mask frame.
+//
+// Replaces regionprops() of cova-rs/gst-plugins/src/bboxcc/process.rs:5-49 (OpenCV
+// connectedComponentsWithStats, connectivity 8, CC_STAT_* columns, AREA >= threshold).
+//
+// Algorithm (block-based union-find, all state in LDS):
+//   * The frame is cut into 2x2-pixel blocks.  All foreground pixels of one block are
+//     mutually 8-adjacent, so a block carries ONE label; block id = by*BW + bx is the
+//     raster index of the block.
+//   * Rows are bit-packed (one byte = 8 pixels) while they stream in from HBM with
+//     8-byte-per-lane coalesced loads; each work item then derives, for the 4 blocks
+//     under one packed byte, the foreground nibble and the four "prior neighbour"
+//     connections (left, up-left, up, up-right) with shifts/ands on 3x3 bytes.
+//   * Blocks are merged with a lock-free min-root union-find (atomicMin on LDS), then
+//     flattened.  The root of a component is therefore its SMALLEST block id, i.e. the
+//     first block of the component in block-raster order -- exactly the block at which
+//     OpenCV's block-based scan (Grana BBDT / Spaghetti) creates the component's first
+//     provisional label; flattenL renumbers roots in that order, so ascending root id
+//     == OpenCV label order.
+//   * Area / min-max extents are accumulated per root with LDS atomics, and surviving
+//     roots are compacted in ascending id order with a workgroup prefix sum.
+#include <cstdint>
+
+#include "internal.h"
+
+namespace {
+
+constexpr int CC_THREADS = 256;
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t uf_find(const volatile uint32_t *lab, uint32_t i) {
+    uint32_t p = lab[i];
+    while (p != i) {
+        i = p;
+        p = lab[i];
+    }
+    return i;
+}
+
+// min-root union; safe under concurrent unions from other lanes/waves.
+__device__ __forceinline__ void uf_union(uint32_t *lab, uint32_t a, uint32_t b) {
+    while (true) {
+        a = uf_find(lab, a);
+        b = uf_find(lab, b);
+        if (a == b) return;
+        if (a < b) {
+            uint32_t t = a;
+            a = b;
+            b = t;
+        }
+        // a > b: hang a under b unless somebody re-parented a meanwhile
+        uint32_t old = atomicMin(&lab[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+struct CcGeom {
+    int H, W, BH, BW, NB;
+    int RS;     // packed-row stride in bytes (1 pad byte left, >=1 right)
+    int NXB;    // packed bytes per row = ceil(W/8)
+};
+
+__global__ __launch_bounds__(CC_THREADS) void bboxcc_kernel(const uint8_t *__restrict__ masks, CcGeom g,
+                                                             int area_thresh, covahip_box *__restrict__ boxes,
+                                                             int32_t *__restrict__ counts, int max_boxes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.x;
+    const int H = g.H, W = g.W, BW = g.BW, NB = g.NB, RS = g.RS, NXB = g.NXB;
+
+    // LDS carve-up (all offsets multiples of 16)
+    const int rb_bytes = ((H + 3) * RS + 15) & ~15;
+    uint8_t *rb = smem;                                   // packed rows, row y at (y+1)*RS + 1
+    uint32_t *lab = (uint32_t *)(smem + rb_bytes);        // [NB]
+    uint32_t *s_area = lab + NB;
+    uint32_t *s_minx = s_area + NB;
+    uint32_t *s_maxx = s_minx + NB;
+    uint32_t *s_miny = s_maxx + NB;
+    uint32_t *s_maxy = s_miny + NB;
+    __shared__ uint32_t wave_tot[CC_THREADS / 64];
+
+    // ---- phase 0: clear packed rows (pads must be zero)
+    for (int i = tid; i < rb_bytes / 4; i += CC_THREADS) ((uint32_t *)rb)[i] = 0;
+    __syncthreads();
+
+    // ---- phase 1: stream the mask in, 8 pixels per work item, and bit-pack it
+    const uint8_t *m = masks + (size_t)frame * H * W;
+    const bool fast = (W % 8 == 0) && ((((uintptr_t)masks) & 7) == 0);
+    const int n_chunks = H * NXB;
+    for (int q = tid; q < n_chunks; q += CC_THREADS) {
+        const int y = q / NXB, xc = q - y * NXB;
+        uint32_t bits = 0;
+        if (fast) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(m + (size_t)y * W + xc * 8);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                bits |= (((v.x >> (8 * k)) & 0xFF) ? 1u : 0u) << k;
+                bits |= (((v.y >> (8 * k)) & 0xFF) ? 1u : 0u) << (4 + k);
+            }
+        } else {
+            for (int k = 0; k < 8; k++) {
+                const int x = xc * 8 + k;
+                if (x < W && m[(size_t)y * W + x]) bits |= 1u << k;
+            }
+        }
+        rb[(y + 1) * RS + 1 + xc] = (uint8_t)bits;
+    }
+    __syncthreads();
+
+    // ---- phase 2: per packed byte of a block row -> 4 blocks: nibble + connections
+    // A work item keeps its blocks' info in registers across the union phase.
+    const int n_units = g.BH * NXB;
+    constexpr int MAX_UNITS = 4;  // units per thread this kernel is sized for (host checks)
+    uint32_t info[MAX_UNITS];     // per unit: 4 x 8 bits = fg nibble | conn nibble << 4
+#pragma unroll
+    for (int u = 0; u < MAX_UNITS; u++) {
+        const int q = tid + u * CC_THREADS;
+        info[u] = 0;
+        if (q < n_units) {
+            const int by = q / NXB, xc = q - by * NXB;
+            const int r = 2 * by;
+            // 24-bit windows: bit 8+k = pixel 8*xc+k; bits 7 / 16 = neighbours across bytes
+            const uint8_t *p0 = rb + (r + 0) * RS + xc;  // row r-1 (stored at index r), byte xc-1
+            const uint8_t *p1 = p0 + RS;                 // row r
+            const uint8_t *p2 = p1 + RS;                 // row r+1
+            const uint32_t up = p0[0] | (p0[1] << 8) | (p0[2] << 16);
+            const uint32_t ra = p1[0] | (p1[1] << 8) | (p1[2] << 16);
+            const uint32_t rc = p2[0] | (p2[1] << 8) | (p2[2] << 16);
+            uint32_t packed = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int bx = xc * 4 + j;
+                const int s = 8 + 2 * j;  // bit of pixel column c = 2*bx
+                const uint32_t a = (ra >> s) & 1, b = (ra >> (s + 1)) & 1;
+                const uint32_t c = (rc >> s) & 1, d = (rc >> (s + 1)) & 1;
+                const uint32_t fg = a | (b << 1) | (c << 2) | (d << 3);
+                const uint32_t u_l = (up >> (s - 1)) & 1, u_0 = (up >> s) & 1, u_1 = (up >> (s + 1)) & 1,
+                               u_r = (up >> (s + 2)) & 1;
+                const uint32_t l_a = (ra >> (s - 1)) & 1, l_c = (rc >> (s - 1)) & 1;
+                const uint32_t cL = (a | c) & (l_a | l_c);
+                const uint32_t cUL = a & u_l;
+                const uint32_t cU = (a | b) & (u_0 | u_1);
+                const uint32_t cUR = b & u_r;
+                const uint32_t conn = cL | (cUL << 1) | (cU << 2) | (cUR << 3);
+                const uint32_t blk = by * BW + bx;
+                if (bx < BW) {
+                    lab[blk] = fg ? blk : NONE;
+                    s_area[blk] = 0;
+                    s_minx[blk] = 0x7FFFFFFF;
+                    s_maxx[blk] = 0;
+                    s_miny[blk] = 0x7FFFFFFF;
+                    s_maxy[blk] = 0;
+                    packed |= (fg | (conn << 4)) << (8 * j);
+                }
+            }
+            info[u] = packed;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: unions with the four prior neighbours
+#pragma unroll
+    for (int u = 0; u < MAX_UNITS; u++) {
+        const int q = tid + u * CC_THREADS;
+        if (q < n_units && (info[u] & 0xF0F0F0F0u)) {
+            const int by = q / NXB, xc = q - by * NXB;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t conn = (info[u] >> (8 * j + 4)) & 0xF;
+                if (!conn) continue;
+                const uint32_t blk = by * BW + xc * 4 + j;
+                if (conn & 1) uf_union(lab, blk, blk - 1);
+                if (conn & 4) uf_union(lab, blk, blk - BW);
+                if (conn & 2) uf_union(lab, blk, blk - BW - 1);
+                if (conn & 8) uf_union(lab, blk, blk - BW + 1);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 4+5: flatten and accumulate statistics on the root
+#pragma unroll
+    for (int u = 0; u < MAX_UNITS; u++) {
+        const int q = tid + u * CC_THREADS;
+        if (q < n_units && (info[u] & 0x0F0F0F0Fu)) {
+            const int by = q / NXB, xc = q - by * NXB;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t fg = (info[u] >> (8 * j)) & 0xF;
+                if (!fg) continue;
+                const uint32_t bx = xc * 4 + j;
+                const uint32_t blk = by * BW + bx;
+                const uint32_t root = uf_find(lab, blk);
+                const uint32_t x0 = 2 * bx + ((fg & 5) ? 0 : 1), x1 = 2 * bx + ((fg & 10) ? 1 : 0);
+                const uint32_t y0 = 2 * by + ((fg & 3) ? 0 : 1), y1 = 2 * by + ((fg & 12) ? 1 : 0);
+                atomicAdd(&s_area[root], __popc(fg));
+                atomicMin(&s_minx[root], x0);
+                atomicMax(&s_maxx[root], x1);
+                atomicMin(&s_miny[root], y0);
+                atomicMax(&s_maxy[root], y1);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 6: ordered compaction of surviving roots (ascending block id)
+    const int per = (NB + CC_THREADS - 1) / CC_THREADS;
+    const int i0 = tid * per;
+    uint32_t cnt = 0;
+    for (int k = 0; k < per; k++) {
+        const int i = i0 + k;
+        if (i < NB && lab[i] == (uint32_t)i && (int)s_area[i] >= area_thresh) cnt++;
+    }
+    // wave inclusive scan
+    const int lane = tid & 63, wv = tid >> 6;
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < CC_THREADS / 64; k++) {
+        const uint32_t t = wave_tot[k];
+        if (k < wv) base += t;
+        total += t;
+    }
+    uint32_t pos = base + incl - cnt;
+    covahip_box *ob = boxes + (size_t)frame * max_boxes;
+    for (int k = 0; k < per; k++) {
+        const int i = i0 + k;
+        if (i < NB && lab[i] == (uint32_t)i && (int)s_area[i] >= area_thresh) {
+            if ((int)pos < max_boxes) {
+                covahip_box bx;
+                bx.left = (int32_t)s_minx[i];
+                bx.top = (int32_t)s_miny[i];
+                bx.width = (int32_t)(s_maxx[i] - s_minx[i] + 1);
+                bx.height = (int32_t)(s_maxy[i] - s_miny[i] + 1);
+                bx.area_px = (int32_t)s_area[i];
+                ob[pos] = bx;
+            }
+            pos++;
+        }
+    }
+    if (tid == 0) counts[frame] = (int32_t)total;
+}
+
+}  // namespace
+
+int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, int h, int w, int area_thresh,
+                          covahip_box *d_boxes, int32_t *d_counts, int max_boxes) {
+    if (batch == 0) return COVAHIP_OK;
+    CcGeom g;
+    g.H = h;
+    g.W = w;
+    g.BH = (h + 1) / 2;
+    g.BW = (w + 1) / 2;
+    g.NB = g.BH * g.BW;
+    g.NXB = (w + 7) / 8;
+    g.RS = g.NXB + 2;
+    const size_t rb_bytes = (((size_t)(h + 3) * g.RS) + 15) & ~(size_t)15;
+    const size_t lds = rb_bytes + (size_t)g.NB * 4 * 6;
+    const int n_units = g.BH * g.NXB;
+    // Shapes the kernel and its grid assume (checked on the host before any launch).
+    if (lds + 64 > 160 * 1024 || n_units > 4 * CC_THREADS) return COVAHIP_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            COVAHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bboxcc_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+            attr_set = true;
+        }
+    }
+    ProfScope ps(ctx, "bboxcc_kernel");
+    hipLaunchKernelGGL(bboxcc_kernel, dim3(batch), dim3(CC_THREADS), lds, ctx->stream, d_mask, g, area_thresh,
+                       d_boxes, d_counts, max_boxes);
+    COVAHIP_CHECK_HIP(ctx, hipGetLastError());
+    return COVAHIP_OK;
+}
+
+extern "C" int covahip_bboxcc(covahip_ctx *ctx, const uint8_t *mask, int batch, int h, int w, int area_thresh,
+                              covahip_box *boxes, int32_t *counts, int max_boxes, int mem_kind) {
+    if (!ctx || batch < 0 || h <= 0 || w <= 0 || max_boxes < 0) return COVAHIP_ERR_INVALID_ARG;
+    if (batch == 0) return COVAHIP_OK;
+    if (!mask || !counts || (!boxes && max_boxes > 0)) return COVAHIP_ERR_INVALID_ARG;
+    COVAHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    if (mem_kind == COVAHIP_MEM_DEVICE)
+        return covahip_bboxcc_launch(ctx, mask, batch, h, w, area_thresh, boxes, counts, max_boxes);
+    if (mem_kind != COVAHIP_MEM_HOST) return COVAHIP_ERR_INVALID_ARG;
+
+    const size_t mask_bytes = (size_t)batch * h * w;
+    const size_t box_bytes = (size_t)batch * max_boxes * sizeof(covahip_box);
+    const size_t cnt_bytes = (size_t)batch * sizeof(int32_t);
+    int rc = covahip_ensure_buffer(ctx, &ctx->stage_in, &ctx->stage_in_bytes, mask_bytes);
+    if (rc) return rc;
+    rc = covahip_ensure_buffer(ctx, &ctx->stage_out, &ctx->stage_out_bytes, box_bytes + cnt_bytes + 16);
+    if (rc) return rc;
+    uint8_t *d_mask = (uint8_t *)ctx->stage_in;
+    covahip_box *d_boxes = (covahip_box *)ctx->stage_out;
+    int32_t *d_counts = (int32_t *)((uint8_t *)ctx->stage_out + ((box_bytes + 15) & ~(size_t)15));
+    COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(d_mask, mask, mask_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = covahip_bboxcc_launch(ctx, d_mask, batch, h, w, area_thresh, d_boxes, d_counts, max_boxes);
+    if (rc) return rc;
+    if (box_bytes)
+        COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(boxes, d_boxes, box_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(counts, d_counts, cnt_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return COVAHIP_OK;
+}

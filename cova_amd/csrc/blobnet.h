@@ -1,0 +1,50 @@
+// BlobNet on gfx950: model state shared by the kernels' translation units.
+#pragma once
+#include <hip/hip_fp16.h>
+
+#include "internal.h"
+
+constexpr int BN_T = 4;       // timestep the network is built for (utils/train-blobnet.py:58)
+constexpr int BN_LEVELS = 4;
+
+struct BnLevelGeom {
+    int H, W;  // spatial size of the tensor at this level (level 0 = network input)
+};
+
+struct EncParams {        // device pointers into the fp32 weight blob
+    const float *k, *b, *gamma, *beta, *mean, *var, *w1, *w2;
+};
+struct DecParams {
+    const float *k, *b, *gamma, *beta, *mean, *var;
+};
+
+struct covahip_blobnet {
+    int H = 0, W = 0, max_batch = 0;
+    BnLevelGeom lv[BN_LEVELS + 1];
+    int enc_c[BN_LEVELS + 1] = {3, 16, 32, 64, 128};
+    int dec_ci[BN_LEVELS] = {128, 128, 64, 32};
+    int dec_co[BN_LEVELS] = {64, 32, 16, 16};
+    int dec_cy[BN_LEVELS], dec_cx[BN_LEVELS];  // crop offsets (top/left) per decoder block
+    float *d_weights = nullptr;  // raw fp32 blob payload
+    EncParams enc[BN_LEVELS];
+    DecParams dec[BN_LEVELS];
+    const float *final_k = nullptr, *final_b = nullptr;
+    // activations (fp16, channels-last)
+    __half *act[BN_LEVELS + 1] = {};  // act[i], i=1..3: [B][T][H_i][W_i][C_i]; act[4]: [B][H_4][W_4][128] (t=0)
+    __half *dact[BN_LEVELS] = {};     // dact[j], j=0..2: [B][Hd][Wd][Cout_j]
+    // prepared (MFMA path) weights
+    void *d_prepared = nullptr;
+    size_t prepared_bytes = 0;
+    struct Prepared *prep = nullptr;
+    int impl = 1;  // 0 = naive direct kernels, 1 = MFMA kernels
+    int64_t macs_per_frame = 0;
+};
+
+// blobnet_naive.hip
+int blobnet_forward_naive(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_stack, int batch, float *d_logits,
+                          uint8_t *d_mask);
+// blobnet_mfma.hip
+int blobnet_prepare_mfma(covahip_ctx *ctx, covahip_blobnet *m, const float *h_weights);
+void blobnet_release_mfma(covahip_ctx *ctx, covahip_blobnet *m);
+int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_stack, int batch, float *d_logits,
+                         uint8_t *d_mask);

@@ -1,0 +1,252 @@
+// BlobNet model state: weight blob validation, geometry (pad / crop rules), HBM
+// workspace, and the C-ABI entry points covahip_blobnet_* / covahip_filter_forward.
+//
+// Geometry follows utils/model/encoder.py:58-80 (level i -> ceil(H/2) x ceil(W/2), zero
+// row on top / zero column on the left when the pre-pool size is odd) and
+// utils/model/decoder.py:43-59 (convT output 2*in+2, crop ceil(p/2) top/left).
+#include <cstdlib>
+#include <cstring>
+
+#include "blobnet.h"
+
+namespace {
+
+constexpr uint32_t W_MAGIC = 0x57485643;  // "CVHW"
+constexpr size_t N_PARAMS = 320305;
+
+size_t bind_params(covahip_blobnet *m, const float *base) {
+    const float *p = base;
+    for (int i = 0; i < BN_LEVELS; i++) {
+        const int ci = m->enc_c[i], co = m->enc_c[i + 1];
+        EncParams &e = m->enc[i];
+        e.k = p; p += 9 * ci * co;
+        e.b = p; p += co;
+        e.gamma = p; p += co;
+        e.beta = p; p += co;
+        e.mean = p; p += co;
+        e.var = p; p += co;
+        e.w1 = p; p += 16;
+        e.w2 = p; p += 16;
+    }
+    for (int j = 0; j < BN_LEVELS; j++) {
+        const int ci = m->dec_ci[j], co = m->dec_co[j];
+        DecParams &d = m->dec[j];
+        d.k = p; p += 16 * ci * co;
+        d.b = p; p += co;
+        if (j < BN_LEVELS - 1) {
+            d.gamma = p; p += co;
+            d.beta = p; p += co;
+            d.mean = p; p += co;
+            d.var = p; p += co;
+        } else {
+            d.gamma = d.beta = d.mean = d.var = nullptr;
+        }
+    }
+    m->final_k = p; p += 16;
+    m->final_b = p; p += 1;
+    return (size_t)(p - base);
+}
+
+}  // namespace
+
+void covahip_blobnet_destroy(covahip_ctx *ctx) {
+    covahip_blobnet *m = ctx->blobnet;
+    if (!m) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    blobnet_release_mfma(ctx, m);
+    if (m->d_weights) hipFree(m->d_weights);
+    for (int i = 0; i <= BN_LEVELS; i++)
+        if (m->act[i]) hipFree(m->act[i]);
+    for (int j = 0; j < BN_LEVELS; j++)
+        if (m->dact[j]) hipFree(m->dact[j]);
+    delete m;
+    ctx->blobnet = nullptr;
+}
+
+int covahip_blobnet_geometry(covahip_ctx *ctx, int *h, int *w) {
+    if (!ctx->blobnet) return COVAHIP_ERR_NOT_LOADED;
+    *h = ctx->blobnet->H;
+    *w = ctx->blobnet->W;
+    return COVAHIP_OK;
+}
+
+int covahip_blobnet_forward_dev(covahip_ctx *ctx, const uint8_t *d_stack, int batch, float *d_logits,
+                                uint8_t *d_mask) {
+    covahip_blobnet *m = ctx->blobnet;
+    if (!m) return COVAHIP_ERR_NOT_LOADED;
+    if (batch > m->max_batch) return COVAHIP_ERR_INVALID_ARG;
+    if (batch == 0) return COVAHIP_OK;
+    if (m->impl == 0) return blobnet_forward_naive(ctx, m, d_stack, batch, d_logits, d_mask);
+    return blobnet_forward_mfma(ctx, m, d_stack, batch, d_logits, d_mask);
+}
+
+extern "C" {
+
+int covahip_blobnet_load(covahip_ctx *ctx, const void *weights, size_t weights_bytes, int h_mb, int w_mb, int t,
+                         int max_batch) {
+    if (!ctx || !weights || h_mb <= 0 || w_mb <= 0 || max_batch <= 0) return COVAHIP_ERR_INVALID_ARG;
+    if (t != BN_T) return COVAHIP_ERR_UNSUPPORTED;
+    if (h_mb < 16 || w_mb < 16 || h_mb > 1024 || w_mb > 1024) return COVAHIP_ERR_UNSUPPORTED;
+    if (weights_bytes < 64) return COVAHIP_ERR_BAD_WEIGHTS;
+    uint32_t hdr[16];
+    std::memcpy(hdr, weights, 64);
+    static const uint32_t want[] = {W_MAGIC, 1, 4, 3, 16, 32, 64, 128, 64, 32, 16, 16, (uint32_t)N_PARAMS};
+    for (int i = 0; i < 13; i++)
+        if (hdr[i] != want[i]) return COVAHIP_ERR_BAD_WEIGHTS;
+    if (weights_bytes != 64 + N_PARAMS * sizeof(float)) return COVAHIP_ERR_BAD_WEIGHTS;
+    const float *h_w = reinterpret_cast<const float *>(static_cast<const uint8_t *>(weights) + 64);
+
+    COVAHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    covahip_blobnet_destroy(ctx);
+    covahip_blobnet *m = new covahip_blobnet();
+    ctx->blobnet = m;
+    m->H = h_mb;
+    m->W = w_mb;
+    m->max_batch = max_batch;
+    m->lv[0] = {h_mb, w_mb};
+    for (int i = 0; i < BN_LEVELS; i++) m->lv[i + 1] = {(m->lv[i].H + 1) / 2, (m->lv[i].W + 1) / 2};
+    for (int j = 0; j < BN_LEVELS; j++) {
+        const BnLevelGeom in = m->lv[BN_LEVELS - j], out = m->lv[BN_LEVELS - 1 - j];
+        const int ph = 2 * in.H + 2 - out.H, pw = 2 * in.W + 2 - out.W;
+        if (ph < 0 || pw < 0) return COVAHIP_ERR_UNSUPPORTED;  // decoder.py zero-pad branch: never at these sizes
+        m->dec_cy[j] = ph / 2 + ph % 2;
+        m->dec_cx[j] = pw / 2 + pw % 2;
+    }
+    // algorithmic MACs per frame (conv + convT(full, uncropped as Keras computes it) + tmix + final)
+    int64_t macs = 0;
+    for (int i = 0; i < BN_LEVELS; i++) {
+        macs += (int64_t)BN_T * m->lv[i].H * m->lv[i].W * 9 * m->enc_c[i] * m->enc_c[i + 1];
+        macs += (int64_t)m->lv[i + 1].H * m->lv[i + 1].W * m->enc_c[i + 1] * 32;
+    }
+    for (int j = 0; j < BN_LEVELS; j++) {
+        const BnLevelGeom in = m->lv[BN_LEVELS - j];
+        macs += (int64_t)in.H * in.W * 16 * m->dec_ci[j] * m->dec_co[j];
+    }
+    macs += (int64_t)h_mb * w_mb * 16;
+    m->macs_per_frame = macs;
+
+    COVAHIP_CHECK_HIP(ctx, hipMalloc((void **)&m->d_weights, N_PARAMS * sizeof(float)));
+    COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(m->d_weights, h_w, N_PARAMS * sizeof(float), hipMemcpyHostToDevice,
+                                          ctx->stream));
+    if (bind_params(m, m->d_weights) != N_PARAMS) return COVAHIP_ERR_BAD_WEIGHTS;
+
+    // HBM workspace: activations stay resident; pad rows/columns are zeroed once here and
+    // never written afterwards.
+    for (int i = 1; i <= BN_LEVELS; i++) {
+        const size_t tt = (i == BN_LEVELS) ? 1 : BN_T;
+        const size_t n = (size_t)max_batch * tt * m->lv[i].H * m->lv[i].W * m->enc_c[i];
+        COVAHIP_CHECK_HIP(ctx, hipMalloc((void **)&m->act[i], n * sizeof(__half)));
+        COVAHIP_CHECK_HIP(ctx, hipMemsetAsync(m->act[i], 0, n * sizeof(__half), ctx->stream));
+    }
+    for (int j = 0; j < BN_LEVELS - 1; j++) {
+        const BnLevelGeom out = m->lv[BN_LEVELS - 1 - j];
+        const size_t n = (size_t)max_batch * out.H * out.W * m->dec_co[j];
+        COVAHIP_CHECK_HIP(ctx, hipMalloc((void **)&m->dact[j], n * sizeof(__half)));
+    }
+    int rc = blobnet_prepare_mfma(ctx, m, h_w);
+    if (rc) return rc;
+    const char *env = std::getenv("COVAHIP_BLOBNET_IMPL");
+    m->impl = (env && std::strcmp(env, "naive") == 0) ? 0 : 1;
+    COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return COVAHIP_OK;
+}
+
+int covahip_blobnet_macs_per_frame(covahip_ctx *ctx, int64_t *macs) {
+    if (!ctx || !macs) return COVAHIP_ERR_INVALID_ARG;
+    if (!ctx->blobnet) return COVAHIP_ERR_NOT_LOADED;
+    *macs = ctx->blobnet->macs_per_frame;
+    return COVAHIP_OK;
+}
+
+int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl) {
+    if (!ctx || !ctx->blobnet) return COVAHIP_ERR_NOT_LOADED;
+    if (impl != 0 && impl != 1) return COVAHIP_ERR_INVALID_ARG;
+    ctx->blobnet->impl = impl;
+    return COVAHIP_OK;
+}
+
+int covahip_filter_forward(covahip_ctx *ctx, const uint8_t *rgba_stack, int batch, int area_thresh,
+                           covahip_box *boxes, int32_t *counts, int max_boxes, float *logits, uint8_t *mask,
+                           int mem_kind) {
+    if (!ctx || batch < 0 || max_boxes < 0) return COVAHIP_ERR_INVALID_ARG;
+    covahip_blobnet *m = ctx->blobnet;
+    if (!m) return COVAHIP_ERR_NOT_LOADED;
+    if (batch == 0) return COVAHIP_OK;
+    if (!rgba_stack || !counts || (!boxes && max_boxes > 0) || batch > m->max_batch) return COVAHIP_ERR_INVALID_ARG;
+    COVAHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t hw = (size_t)m->H * m->W;
+    const size_t in_bytes = (size_t)batch * BN_T * hw * 4;
+    const size_t mask_bytes = (size_t)batch * hw;
+    const size_t logit_bytes = mask_bytes * sizeof(float);
+    const size_t box_bytes = (size_t)batch * max_boxes * sizeof(covahip_box);
+    const size_t cnt_bytes = (size_t)batch * sizeof(int32_t);
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+
+    if (mem_kind == COVAHIP_MEM_DEVICE) {
+        uint8_t *d_mask = mask;
+        if (!d_mask) {
+            int rc = covahip_ensure_buffer(ctx, &ctx->cc_scratch, &ctx->cc_scratch_bytes, mask_bytes);
+            if (rc) return rc;
+            d_mask = (uint8_t *)ctx->cc_scratch;
+        }
+        int rc = covahip_blobnet_forward_dev(ctx, rgba_stack, batch, logits, d_mask);
+        if (rc) return rc;
+        return covahip_bboxcc_launch(ctx, d_mask, batch, m->H, m->W, area_thresh, boxes, counts, max_boxes);
+    }
+    if (mem_kind != COVAHIP_MEM_HOST) return COVAHIP_ERR_INVALID_ARG;
+    int rc = covahip_ensure_buffer(ctx, &ctx->stage_in, &ctx->stage_in_bytes, in_bytes);
+    if (rc) return rc;
+    const size_t out_need = al(mask_bytes) + al(logit_bytes) + al(box_bytes) + al(cnt_bytes);
+    rc = covahip_ensure_buffer(ctx, &ctx->stage_out, &ctx->stage_out_bytes, out_need);
+    if (rc) return rc;
+    uint8_t *base = (uint8_t *)ctx->stage_out;
+    uint8_t *d_mask = base;
+    float *d_logits = (float *)(base + al(mask_bytes));
+    covahip_box *d_boxes = (covahip_box *)(base + al(mask_bytes) + al(logit_bytes));
+    int32_t *d_counts = (int32_t *)(base + al(mask_bytes) + al(logit_bytes) + al(box_bytes));
+    COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(ctx->stage_in, rgba_stack, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = covahip_blobnet_forward_dev(ctx, (const uint8_t *)ctx->stage_in, batch, logits ? d_logits : nullptr, d_mask);
+    if (rc) return rc;
+    rc = covahip_bboxcc_launch(ctx, d_mask, batch, m->H, m->W, area_thresh, d_boxes, d_counts, max_boxes);
+    if (rc) return rc;
+    if (logits) COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(logits, d_logits, logit_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (mask) COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(mask, d_mask, mask_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (box_bytes) COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(boxes, d_boxes, box_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(counts, d_counts, cnt_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return COVAHIP_OK;
+}
+
+int covahip_blobnet_forward(covahip_ctx *ctx, const uint8_t *rgba_stack, int batch, float *logits, uint8_t *mask,
+                            int mem_kind) {
+    if (!ctx || batch < 0) return COVAHIP_ERR_INVALID_ARG;
+    covahip_blobnet *m = ctx->blobnet;
+    if (!m) return COVAHIP_ERR_NOT_LOADED;
+    if (batch == 0) return COVAHIP_OK;
+    if (!rgba_stack || batch > m->max_batch) return COVAHIP_ERR_INVALID_ARG;
+    COVAHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    if (mem_kind == COVAHIP_MEM_DEVICE) return covahip_blobnet_forward_dev(ctx, rgba_stack, batch, logits, mask);
+    if (mem_kind != COVAHIP_MEM_HOST) return COVAHIP_ERR_INVALID_ARG;
+    const size_t hw = (size_t)m->H * m->W;
+    const size_t in_bytes = (size_t)batch * BN_T * hw * 4;
+    const size_t mask_bytes = (size_t)batch * hw;
+    const size_t logit_bytes = mask_bytes * sizeof(float);
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    int rc = covahip_ensure_buffer(ctx, &ctx->stage_in, &ctx->stage_in_bytes, in_bytes);
+    if (rc) return rc;
+    rc = covahip_ensure_buffer(ctx, &ctx->stage_out, &ctx->stage_out_bytes, al(mask_bytes) + al(logit_bytes));
+    if (rc) return rc;
+    uint8_t *d_mask = (uint8_t *)ctx->stage_out;
+    float *d_logits = (float *)((uint8_t *)ctx->stage_out + al(mask_bytes));
+    COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(ctx->stage_in, rgba_stack, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = covahip_blobnet_forward_dev(ctx, (const uint8_t *)ctx->stage_in, batch, logits ? d_logits : nullptr,
+                                     mask ? d_mask : nullptr);
+    if (rc) return rc;
+    if (logits) COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(logits, d_logits, logit_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (mask) COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(mask, d_mask, mask_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return COVAHIP_OK;
+}
+
+}  // extern "C"

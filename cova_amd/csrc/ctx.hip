@@ -1,0 +1,249 @@
+// GPU context, device memory helpers, HIP-event timers and per-kernel profiling for
+// libcovahip.so (see include/covahip.h).
+#include <cstdio>
+#include <cstring>
+
+#include "internal.h"
+
+extern "C" {
+
+const char *covahip_strerror(int status) {
+    switch (status) {
+        case COVAHIP_OK: return "ok";
+        case COVAHIP_ERR_INVALID_ARG: return "invalid argument";
+        case COVAHIP_ERR_NO_DEVICE: return "no usable HIP device";
+        case COVAHIP_ERR_HIP: return "HIP runtime call failed";
+        case COVAHIP_ERR_NOT_LOADED: return "BlobNet weights not loaded";
+        case COVAHIP_ERR_UNSUPPORTED: return "unsupported geometry";
+        case COVAHIP_ERR_BAD_WEIGHTS: return "bad weight blob";
+        case COVAHIP_ERR_OVERFLOW: return "output buffer too small";
+        case COVAHIP_ERR_BAD_DATA: return "malformed input data";
+        default: return "unknown status";
+    }
+}
+
+const char *covahip_version(void) { return "covahip 0.1.0 (gfx950, HIP)"; }
+
+int covahip_device_count(int *count) {
+    if (!count) return COVAHIP_ERR_INVALID_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        *count = 0;
+        return COVAHIP_ERR_NO_DEVICE;
+    }
+    *count = n;
+    return COVAHIP_OK;
+}
+
+int covahip_ctx_create(int device_id, covahip_ctx **out) {
+    if (!out) return COVAHIP_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return COVAHIP_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= n) return COVAHIP_ERR_INVALID_ARG;
+    if (hipSetDevice(device_id) != hipSuccess) return COVAHIP_ERR_NO_DEVICE;
+    covahip_ctx *ctx = new covahip_ctx();
+    ctx->device = device_id;
+    if (hipGetDeviceProperties(&ctx->props, device_id) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return COVAHIP_ERR_NO_DEVICE;
+    }
+    for (int i = 0; i < 16; i++) {
+        hipEventCreate(&ctx->t_start[i]);
+        hipEventCreate(&ctx->t_stop[i]);
+    }
+    *out = ctx;
+    return COVAHIP_OK;
+}
+
+void covahip_ctx_destroy(covahip_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    covahip_blobnet_destroy(ctx);
+    for (int i = 0; i < 16; i++) {
+        hipEventDestroy(ctx->t_start[i]);
+        hipEventDestroy(ctx->t_stop[i]);
+    }
+    for (auto &p : ctx->prof_pending) {
+        hipEventDestroy(p.a);
+        hipEventDestroy(p.b);
+    }
+    for (auto &p : ctx->prof_pool) {
+        hipEventDestroy(p.first);
+        hipEventDestroy(p.second);
+    }
+    if (ctx->stage_in) hipFree(ctx->stage_in);
+    if (ctx->stage_out) hipFree(ctx->stage_out);
+    if (ctx->cc_scratch) hipFree(ctx->cc_scratch);
+    if (ctx->pinned) hipHostFree(ctx->pinned);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int covahip_ctx_sync(covahip_ctx *ctx) {
+    if (!ctx) return COVAHIP_ERR_INVALID_ARG;
+    COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return COVAHIP_OK;
+}
+
+const char *covahip_last_hip_error(covahip_ctx *ctx) { return ctx ? ctx->last_hip_error.c_str() : ""; }
+
+int covahip_device_info(covahip_ctx *ctx, char *name, size_t name_cap, int *num_cu, size_t *hbm_bytes) {
+    if (!ctx) return COVAHIP_ERR_INVALID_ARG;
+    if (name && name_cap) {
+        std::snprintf(name, name_cap, "%s (%s)", ctx->props.name, ctx->props.gcnArchName);
+    }
+    if (num_cu) *num_cu = ctx->props.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = ctx->props.totalGlobalMem;
+    return COVAHIP_OK;
+}
+
+int covahip_malloc(covahip_ctx *ctx, size_t bytes, void **dev_ptr) {
+    if (!ctx || !dev_ptr) return COVAHIP_ERR_INVALID_ARG;
+    COVAHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    COVAHIP_CHECK_HIP(ctx, hipMalloc(dev_ptr, bytes ? bytes : 1));
+    return COVAHIP_OK;
+}
+
+int covahip_free(covahip_ctx *ctx, void *dev_ptr) {
+    if (!ctx) return COVAHIP_ERR_INVALID_ARG;
+    if (!dev_ptr) return COVAHIP_OK;
+    COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    COVAHIP_CHECK_HIP(ctx, hipFree(dev_ptr));
+    return COVAHIP_OK;
+}
+
+int covahip_memcpy_h2d(covahip_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes) {
+    if (!ctx || (!dev_dst && bytes) || (!host_src && bytes)) return COVAHIP_ERR_INVALID_ARG;
+    COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return COVAHIP_OK;
+}
+
+int covahip_memcpy_d2h(covahip_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
+    if (!ctx || (!host_dst && bytes) || (!dev_src && bytes)) return COVAHIP_ERR_INVALID_ARG;
+    COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return COVAHIP_OK;
+}
+
+int covahip_memset(covahip_ctx *ctx, void *dev_ptr, int value, size_t bytes) {
+    if (!ctx || (!dev_ptr && bytes)) return COVAHIP_ERR_INVALID_ARG;
+    COVAHIP_CHECK_HIP(ctx, hipMemsetAsync(dev_ptr, value, bytes, ctx->stream));
+    return COVAHIP_OK;
+}
+
+int covahip_timer_start(covahip_ctx *ctx, int slot) {
+    if (!ctx || slot < 0 || slot >= 16) return COVAHIP_ERR_INVALID_ARG;
+    COVAHIP_CHECK_HIP(ctx, hipEventRecord(ctx->t_start[slot], ctx->stream));
+    return COVAHIP_OK;
+}
+
+int covahip_timer_stop(covahip_ctx *ctx, int slot) {
+    if (!ctx || slot < 0 || slot >= 16) return COVAHIP_ERR_INVALID_ARG;
+    COVAHIP_CHECK_HIP(ctx, hipEventRecord(ctx->t_stop[slot], ctx->stream));
+    return COVAHIP_OK;
+}
+
+int covahip_timer_elapsed_ms(covahip_ctx *ctx, int slot, float *ms) {
+    if (!ctx || !ms || slot < 0 || slot >= 16) return COVAHIP_ERR_INVALID_ARG;
+    COVAHIP_CHECK_HIP(ctx, hipEventSynchronize(ctx->t_stop[slot]));
+    COVAHIP_CHECK_HIP(ctx, hipEventElapsedTime(ms, ctx->t_start[slot], ctx->t_stop[slot]));
+    return COVAHIP_OK;
+}
+
+int covahip_profile_enable(covahip_ctx *ctx, int on) {
+    if (!ctx) return COVAHIP_ERR_INVALID_ARG;
+    ctx->profile = on != 0;
+    return COVAHIP_OK;
+}
+
+static void prof_drain(covahip_ctx *ctx) {
+    for (auto &p : ctx->prof_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            auto &acc = ctx->prof_acc[p.name];
+            acc.first += ms;
+            acc.second += 1;
+        }
+        ctx->prof_pool.emplace_back(p.a, p.b);
+    }
+    ctx->prof_pending.clear();
+}
+
+int covahip_profile_reset(covahip_ctx *ctx) {
+    if (!ctx) return COVAHIP_ERR_INVALID_ARG;
+    prof_drain(ctx);
+    ctx->prof_acc.clear();
+    return COVAHIP_OK;
+}
+
+int covahip_profile_read(covahip_ctx *ctx, covahip_kernel_time *out, int cap, int *n) {
+    if (!ctx || !n) return COVAHIP_ERR_INVALID_ARG;
+    prof_drain(ctx);
+    int i = 0;
+    for (auto &kv : ctx->prof_acc) {
+        if (out && i < cap) {
+            std::memset(out[i].name, 0, sizeof(out[i].name));
+            std::strncpy(out[i].name, kv.first.c_str(), sizeof(out[i].name) - 1);
+            out[i].total_ms = kv.second.first;
+            out[i].launches = kv.second.second;
+        }
+        i++;
+    }
+    *n = i;
+    return COVAHIP_OK;
+}
+
+}  // extern "C"
+
+ProfScope::ProfScope(covahip_ctx *c, const char *name) : ctx(c) {
+    if (!ctx->profile) return;
+    covahip_ctx::ProfEntry e;
+    e.name = name;
+    if (!ctx->prof_pool.empty()) {
+        e.a = ctx->prof_pool.back().first;
+        e.b = ctx->prof_pool.back().second;
+        ctx->prof_pool.pop_back();
+    } else {
+        hipEventCreate(&e.a);
+        hipEventCreate(&e.b);
+    }
+    hipEventRecord(e.a, ctx->stream);
+    ctx->prof_pending.push_back(e);
+    idx = (int)ctx->prof_pending.size() - 1;
+}
+
+ProfScope::~ProfScope() {
+    if (idx < 0) return;
+    hipEventRecord(ctx->prof_pending[idx].b, ctx->stream);
+    // keep the pending list bounded: drain when it grows large
+    if (ctx->prof_pending.size() > 4096) {
+        // inline drain (synchronises; only in profiling mode)
+        for (auto &p : ctx->prof_pending) {
+            float ms = 0.f;
+            if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+                auto &acc = ctx->prof_acc[p.name];
+                acc.first += ms;
+                acc.second += 1;
+            }
+            ctx->prof_pool.emplace_back(p.a, p.b);
+        }
+        ctx->prof_pending.clear();
+    }
+}
+
+int covahip_ensure_buffer(covahip_ctx *ctx, void **buf, size_t *cur, size_t need) {
+    if (*cur >= need && *buf) return COVAHIP_OK;
+    if (*buf) {
+        COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        COVAHIP_CHECK_HIP(ctx, hipFree(*buf));
+        *buf = nullptr;
+        *cur = 0;
+    }
+    COVAHIP_CHECK_HIP(ctx, hipMalloc(buf, need));
+    *cur = need;
+    return COVAHIP_OK;
+}

@@ -1,0 +1,928 @@
+// Host-side state of the CoVA filter elements behind the C-ABI (include/covahip.h):
+// Bbox / Frame bincode wire format, metapreprocess stacking ring, SORT tracker
+// (Kalman + Hungarian) and the cova GoP frame filter.  Plain C++17, no GPU.
+//
+// Reference (paths under /root/reference):
+//   cova-rs/bbox/src/bbox.rs:4-91, cova-rs/bbox/src/lib.rs:8-22
+//   cova-rs/gst-plugins/src/metapreprocess/imp.rs:204-332
+//   cova-rs/sort/src/lib.rs:14-214, state.rs:9-28, tracker/mod.rs:15-152,
+//   tracker/motion_model.rs:38-55, tracker/linear_observation_model.rs:33-47
+//   cova-rs/gst-plugins/src/cova/imp.rs:90-432, cova/tracker.rs:16-125
+// Third-party arithmetic restated from the published algorithms (sources absent):
+//   adskalman 0.13.0 (Kalman predict / Joseph-form update), linear_assignment 0.0.2
+//   (min-cost perfect matching), bincode 1.3.3 default config (LE, fixed-width ints,
+//   u64 length prefix, 1-byte Option tag).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <limits>
+#include <list>
+#include <new>
+#include <vector>
+
+#include "covahip.h"
+
+// ============================================================== bincode
+namespace {
+
+struct Writer {
+    uint8_t *out;
+    size_t cap;
+    size_t n = 0;
+    void put(const void *p, size_t len) {
+        if (out && n + len <= cap) std::memcpy(out + n, p, len);
+        n += len;
+    }
+    template <typename T>
+    void val(T v) { put(&v, sizeof(T)); }
+};
+
+void write_bbox(Writer &w, const covahip_bbox &b) {
+    w.val<float>(b.left);
+    w.val<float>(b.top);
+    w.val<float>(b.width);
+    w.val<float>(b.height);
+    w.val<float>(b.area);
+    w.val<uint8_t>(b.has_track_id ? 1 : 0);
+    if (b.has_track_id) w.val<uint64_t>(b.track_id);
+    w.val<uint8_t>(b.has_timestamp ? 1 : 0);
+    if (b.has_timestamp) w.val<uint64_t>(b.timestamp);
+    w.val<uint8_t>(b.has_class_id ? 1 : 0);
+    if (b.has_class_id) w.val<uint32_t>(b.class_id);
+    w.val<uint8_t>(b.has_confidence ? 1 : 0);
+    if (b.has_confidence) w.val<float>(b.confidence);
+}
+
+struct Reader {
+    const uint8_t *p;
+    size_t len;
+    size_t n = 0;
+    bool ok = true;
+    template <typename T>
+    T val() {
+        T v{};
+        if (n + sizeof(T) > len) { ok = false; return v; }
+        std::memcpy(&v, p + n, sizeof(T));
+        n += sizeof(T);
+        return v;
+    }
+};
+
+bool read_bbox(Reader &r, covahip_bbox &b) {
+    std::memset(&b, 0, sizeof(b));
+    b.left = r.val<float>();
+    b.top = r.val<float>();
+    b.width = r.val<float>();
+    b.height = r.val<float>();
+    b.area = r.val<float>();
+    uint8_t t = r.val<uint8_t>();
+    if (t > 1) return false;
+    b.has_track_id = t;
+    if (t) b.track_id = r.val<uint64_t>();
+    t = r.val<uint8_t>();
+    if (t > 1) return false;
+    b.has_timestamp = t;
+    if (t) b.timestamp = r.val<uint64_t>();
+    t = r.val<uint8_t>();
+    if (t > 1) return false;
+    b.has_class_id = t;
+    if (t) b.class_id = r.val<uint32_t>();
+    t = r.val<uint8_t>();
+    if (t > 1) return false;
+    b.has_confidence = t;
+    if (t) b.confidence = r.val<float>();
+    return r.ok;
+}
+
+covahip_bbox bbox_new(float l, float t, float w, float h) {  // Bbox::new, bbox.rs:17-29
+    covahip_bbox b;
+    std::memset(&b, 0, sizeof(b));
+    b.left = l;
+    b.top = t;
+    b.width = w;
+    b.height = h;
+    b.area = w * h;
+    return b;
+}
+
+float bbox_iou(const covahip_bbox &s, const covahip_bbox &t) {  // bbox.rs:39-56
+    const float s_x2 = s.left + s.width, s_y2 = s.top + s.height;
+    const float t_x2 = t.left + t.width, t_y2 = t.top + t.height;
+    const float x_left = std::fmax(s.left, t.left), y_top = std::fmax(s.top, t.top);
+    const float x_right = std::fmin(s_x2, t_x2), y_bottom = std::fmin(s_y2, t_y2);
+    if (x_right <= x_left || y_bottom <= y_top) return 0.f;
+    const float inter = (x_right - x_left) * (y_bottom - y_top);
+    const float uni = s.area + t.area - inter;
+    return inter / uni;
+}
+
+}  // namespace
+
+extern "C" {
+
+void covahip_boxes_to_bbox(const covahip_box *in, int n, covahip_bbox *out) {
+    for (int i = 0; i < n; i++)
+        out[i] = bbox_new((float)in[i].left, (float)in[i].top, (float)in[i].width, (float)in[i].height);
+}
+
+size_t covahip_bbox_serialize_vec(const covahip_bbox *boxes, size_t n, uint8_t *out, size_t cap, int *status) {
+    Writer w{out, cap};
+    w.val<uint64_t>((uint64_t)n);
+    for (size_t i = 0; i < n; i++) write_bbox(w, boxes[i]);
+    if (status) *status = (out && w.n <= cap) ? COVAHIP_OK : COVAHIP_ERR_OVERFLOW;
+    return w.n;
+}
+
+int covahip_bbox_deserialize_vec(const uint8_t *data, size_t len, covahip_bbox *out, size_t cap, size_t *n) {
+    if (!data || !n) return COVAHIP_ERR_INVALID_ARG;
+    Reader r{data, len};
+    const uint64_t cnt = r.val<uint64_t>();
+    if (!r.ok) return COVAHIP_ERR_BAD_DATA;
+    if (cnt > len) return COVAHIP_ERR_BAD_DATA;  // each box is >= 24 bytes
+    *n = (size_t)cnt;
+    for (uint64_t i = 0; i < cnt; i++) {
+        covahip_bbox b;
+        if (!read_bbox(r, b)) return COVAHIP_ERR_BAD_DATA;
+        if (out && i < cap) out[i] = b;
+    }
+    if (r.n != len) return COVAHIP_ERR_BAD_DATA;  // trailing bytes
+    return (cnt > cap && out) ? COVAHIP_ERR_OVERFLOW : COVAHIP_OK;
+}
+
+size_t covahip_frame_serialize(uint64_t range_start, uint64_t oldest, const covahip_bbox *boxes, size_t n,
+                               uint8_t *out, size_t cap, int *status) {
+    Writer w{out, cap};
+    w.val<uint64_t>(range_start);
+    w.val<uint64_t>(oldest);
+    w.val<uint64_t>((uint64_t)n);
+    for (size_t i = 0; i < n; i++) write_bbox(w, boxes[i]);
+    if (status) *status = (out && w.n <= cap) ? COVAHIP_OK : COVAHIP_ERR_OVERFLOW;
+    return w.n;
+}
+
+float covahip_bbox_iou(const covahip_bbox *a, const covahip_bbox *b) { return bbox_iou(*a, *b); }
+
+}  // extern "C"
+
+// ============================================================== metapreprocess ring
+struct covahip_stack {
+    size_t size_per_buf;
+    unsigned timestep, gamma;
+    size_t gamma_idx = 0;
+    std::deque<std::vector<uint8_t>> prev;  // front = newest (imp.rs:304,321)
+};
+
+extern "C" {
+
+int covahip_stack_new(size_t size_per_buf, unsigned timestep, unsigned gamma, covahip_stack **out) {
+    if (!out || timestep < 1 || gamma < 1 || size_per_buf == 0) return COVAHIP_ERR_INVALID_ARG;
+    covahip_stack *s = new (std::nothrow) covahip_stack();
+    if (!s) return COVAHIP_ERR_INVALID_ARG;
+    s->size_per_buf = size_per_buf;
+    s->timestep = timestep;
+    s->gamma = gamma;
+    *out = s;
+    return COVAHIP_OK;
+}
+
+void covahip_stack_free(covahip_stack *s) { delete s; }
+
+int covahip_stack_push(covahip_stack *s, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                       int *emitted) {
+    if (!s || !in || !emitted) return COVAHIP_ERR_INVALID_ARG;
+    if (in_len < s->size_per_buf) return COVAHIP_ERR_INVALID_ARG;
+    *emitted = 0;
+    const size_t spb = s->size_per_buf;
+    if (s->prev.size() < (size_t)s->timestep - 1) {  // imp.rs:302-305: warm-up, FLOW_DROPPED
+        s->prev.emplace_front(in, in + spb);
+        return COVAHIP_OK;
+    }
+    if (s->gamma_idx == 0) {  // imp.rs:306-324
+        if (!out || out_cap < spb * s->timestep) return COVAHIP_ERR_OVERFLOW;
+        std::memcpy(out, in, spb);
+        size_t idx = spb;
+        for (const auto &p : s->prev) {
+            std::memcpy(out + idx, p.data(), spb);
+            idx += spb;
+        }
+        *emitted = 1;
+        s->gamma_idx = s->gamma - 1;
+    } else {  // imp.rs:325-330
+        s->gamma_idx -= 1;
+    }
+    s->prev.emplace_front(in, in + spb);
+    s->prev.pop_back();
+    return COVAHIP_OK;
+}
+
+void covahip_stack_out_dims(int width, int height, unsigned timestep, int *out_w, int *out_h) {
+    if (out_w) *out_w = width / 16;
+    if (out_h) *out_h = height / 16 * (int)timestep;
+}
+
+}  // extern "C"
+
+// ============================================================== SORT
+namespace {
+
+typedef float P;  // PrecisionType = f32 (sort/src/lib.rs:3)
+
+struct Mat7 {
+    P m[7][7];
+};
+
+// x' = F x with F = I + (x0 += x4, x1 += x5, x2 += x6)  (motion_model.rs:38-45,
+// nalgebra from_vec is column-major, so the literal is F transposed on the page).
+void kalman_predict(const P x[7], const Mat7 &Pm, P xo[7], Mat7 &Po) {
+    static const P Q[7] = {1.f, 1.f, 1.f, 1.f, 0.01f, 0.01f, 0.0001f};  // motion_model.rs:48-55
+    P F[7][7];
+    for (int i = 0; i < 7; i++)
+        for (int j = 0; j < 7; j++) F[i][j] = (i == j) ? 1.f : 0.f;
+    F[0][4] = 1.f;
+    F[1][5] = 1.f;
+    F[2][6] = 1.f;
+    for (int i = 0; i < 7; i++) {
+        P a = 0.f;
+        for (int k = 0; k < 7; k++) a += F[i][k] * x[k];
+        xo[i] = a;
+    }
+    P FP[7][7];
+    for (int i = 0; i < 7; i++)
+        for (int j = 0; j < 7; j++) {
+            P a = 0.f;
+            for (int k = 0; k < 7; k++) a += F[i][k] * Pm.m[k][j];
+            FP[i][j] = a;
+        }
+    for (int i = 0; i < 7; i++)
+        for (int j = 0; j < 7; j++) {
+            P a = 0.f;
+            for (int k = 0; k < 7; k++) a += FP[i][k] * F[j][k];  // * F^T
+            Po.m[i][j] = a + (i == j ? Q[i] : 0.f);
+        }
+}
+
+// adskalman ObservationModel::update, CovarianceUpdateMethod::JosephForm, with
+// H = [I4 0] (linear_observation_model.rs:33-40), R = diag(1,1,10,10) (:43-47).
+// Returns false when S is not positive definite (adskalman returns Err).
+bool kalman_update(const P xp[7], const Mat7 &Pp, const P z[4], P xo[7], Mat7 &Po) {
+    static const P R[4] = {1.f, 1.f, 10.f, 10.f};
+    // S = H P H^T + R = P[0:4,0:4] + R
+    P S[4][4];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) S[i][j] = Pp.m[i][j] + (i == j ? R[i] : 0.f);
+    // Cholesky S = L L^T
+    P L[4][4] = {};
+    for (int j = 0; j < 4; j++) {
+        P d = S[j][j];
+        for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
+        if (!(d > 0.f)) return false;
+        L[j][j] = std::sqrt(d);
+        for (int i = j + 1; i < 4; i++) {
+            P a = S[i][j];
+            for (int k = 0; k < j; k++) a -= L[i][k] * L[j][k];
+            L[i][j] = a / L[j][j];
+        }
+    }
+    // S^-1 via L^-1
+    P Li[4][4] = {};
+    for (int i = 0; i < 4; i++) {
+        Li[i][i] = 1.f / L[i][i];
+        for (int j = 0; j < i; j++) {
+            P a = 0.f;
+            for (int k = j; k < i; k++) a -= L[i][k] * Li[k][j];
+            Li[i][j] = a / L[i][i];
+        }
+    }
+    P Si[4][4];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            P a = 0.f;
+            for (int k = 0; k < 4; k++) a += Li[k][i] * Li[k][j];
+            Si[i][j] = a;
+        }
+    // K = P H^T S^-1  (7x4): P H^T = first 4 columns of P
+    P K[7][4];
+    for (int i = 0; i < 7; i++)
+        for (int j = 0; j < 4; j++) {
+            P a = 0.f;
+            for (int k = 0; k < 4; k++) a += Pp.m[i][k] * Si[k][j];
+            K[i][j] = a;
+        }
+    P innov[4];
+    for (int i = 0; i < 4; i++) innov[i] = z[i] - xp[i];
+    for (int i = 0; i < 7; i++) {
+        P a = 0.f;
+        for (int k = 0; k < 4; k++) a += K[i][k] * innov[k];
+        xo[i] = xp[i] + a;
+    }
+    // (I - K H) P (I - K H)^T + K R K^T
+    P A[7][7];
+    for (int i = 0; i < 7; i++)
+        for (int j = 0; j < 7; j++) A[i][j] = (i == j ? 1.f : 0.f) - (j < 4 ? K[i][j] : 0.f);
+    P AP[7][7];
+    for (int i = 0; i < 7; i++)
+        for (int j = 0; j < 7; j++) {
+            P a = 0.f;
+            for (int k = 0; k < 7; k++) a += A[i][k] * Pp.m[k][j];
+            AP[i][j] = a;
+        }
+    for (int i = 0; i < 7; i++)
+        for (int j = 0; j < 7; j++) {
+            P a = 0.f;
+            for (int k = 0; k < 7; k++) a += AP[i][k] * A[j][k];
+            P b = 0.f;
+            for (int k = 0; k < 4; k++) b += K[i][k] * R[k] * K[j][k];
+            Po.m[i][j] = a + b;
+        }
+    return true;
+}
+
+void into_z(const covahip_bbox &b, P z[4]) {  // state.rs:10-16
+    z[0] = b.left + b.width / 2.f;
+    z[1] = b.top + b.height / 2.f;
+    z[2] = b.area;
+    z[3] = b.width / b.height;
+}
+
+covahip_bbox from_x(const P x[7]) {  // state.rs:18-28 -- `top` uses width (reference quirk)
+    const P r = x[3], s = x[2], y = x[1], xx = x[0];
+    const P width = std::sqrt(s * r);
+    const P height = s / width;
+    return bbox_new(xx - width / 2.f, y - width / 2.f, width, height);
+}
+
+struct Tracker {  // KalmanBoxTracker, tracker/mod.rs:15-69
+    uint64_t id = 0, start = 0, last_match = 0;
+    std::vector<uint64_t> seen_ts;
+    bool active = false;
+    std::vector<covahip_bbox> history;
+    uint64_t hits = 0, time_since_update = 0, hit_streaks = 0, age = 0;
+    P x[7];
+    Mat7 Pm;  // previous_estimate
+    bool has_prior = false;
+    P xp[7];
+    Mat7 Pp;  // prior
+
+    Tracker(uint64_t id_, const covahip_bbox &b, uint64_t start_) : id(id_), start(start_), last_match(start_) {
+        P z[4];
+        into_z(b, z);
+        for (int i = 0; i < 7; i++) x[i] = i < 4 ? z[i] : 0.f;
+        for (int i = 0; i < 7; i++)
+            for (int j = 0; j < 7; j++) Pm.m[i][j] = (i == j) ? (i < 4 ? 10.f : 10000.f) : 0.f;
+    }
+
+    const covahip_bbox &predict(uint64_t ts) {  // tracker/mod.rs:104-121
+        if (x[6] + x[2] <= 0.f) x[6] = 0.f;
+        kalman_predict(x, Pm, xp, Pp);
+        has_prior = true;
+        covahip_bbox b = from_x(xp);
+        b.has_track_id = 1;
+        b.track_id = id;
+        b.has_timestamp = 1;
+        b.timestamp = ts;
+        age += 1;
+        time_since_update += 1;
+        history.push_back(b);
+        return history.back();
+    }
+
+    bool update(const covahip_bbox *det) {  // tracker/mod.rs:71-102
+        if (det) {
+            hits += 1;
+            hit_streaks += 1;
+            if (hit_streaks >= 5) {  // reference "FIXME: arbitrary number"
+                time_since_update = 0;
+                last_match = det->timestamp;
+            }
+            P z[4];
+            into_z(*det, z);
+            if (!has_prior) return false;
+            P xn[7];
+            Mat7 Pn;
+            if (!kalman_update(xp, Pp, z, xn, Pn)) return false;
+            std::memcpy(x, xn, sizeof(x));
+            Pm = Pn;
+            covahip_bbox &last = history.back();
+            last.has_class_id = det->has_class_id;
+            last.class_id = det->class_id;
+            last.has_confidence = det->has_confidence;
+            last.confidence = det->confidence;
+        } else {
+            hit_streaks = 0;
+        }
+        return true;
+    }
+
+    bool should_live(uint64_t max_age) const { return time_since_update <= max_age; }
+    void check_activate(uint64_t min_hits) {
+        if (!active && hit_streaks >= min_hits) active = true;
+    }
+    bool is_seen() const {  // tracker/mod.rs:138-142
+        for (uint64_t ts : seen_ts)
+            if (start <= ts && last_match >= ts) return true;
+        return false;
+    }
+    void trim_dead_history() {  // tracker/mod.rs:144-151
+        const uint64_t drop_idx = (uint64_t)history.size() - time_since_update;
+        if (drop_idx < history.size()) history.resize((size_t)drop_idx);
+    }
+};
+
+// Min-cost perfect matching on an n x n matrix (shortest augmenting paths with
+// potentials, O(n^3)); a[i][j] row-major.  Returns col_of_row.
+std::vector<int> hungarian(const std::vector<double> &a, int n) {
+    const double INF = std::numeric_limits<double>::infinity();
+    std::vector<double> u(n + 1, 0.0), v(n + 1, 0.0);
+    std::vector<int> p(n + 1, 0), way(n + 1, 0);
+    for (int i = 1; i <= n; i++) {
+        p[0] = i;
+        int j0 = 0;
+        std::vector<double> minv(n + 1, INF);
+        std::vector<char> used(n + 1, 0);
+        do {
+            used[j0] = 1;
+            const int i0 = p[j0];
+            double delta = INF;
+            int j1 = 0;
+            for (int j = 1; j <= n; j++)
+                if (!used[j]) {
+                    const double cur = a[(size_t)(i0 - 1) * n + (j - 1)] - u[i0] - v[j];
+                    if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
+                    if (minv[j] < delta) { delta = minv[j]; j1 = j; }
+                }
+            for (int j = 0; j <= n; j++)
+                if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
+                else minv[j] -= delta;
+            j0 = j1;
+        } while (p[j0] != 0);
+        do {
+            const int j1 = way[j0];
+            p[j0] = p[j1];
+            j0 = j1;
+        } while (j0);
+    }
+    std::vector<int> col_of_row(n, -1);
+    for (int j = 1; j <= n; j++)
+        if (p[j] > 0) col_of_row[p[j] - 1] = j - 1;
+    return col_of_row;
+}
+
+// linear_assignment() of sort/src/lib.rs:25-56: zero-pad to square, solve, drop padded
+// edges and edges whose ORIGINAL cost equals 2.0.
+std::vector<std::pair<size_t, size_t>> linear_assignment(const std::vector<P> &cost_colmajor, size_t n_rows,
+                                                         size_t n_cols) {
+    std::vector<std::pair<size_t, size_t>> out;
+    if (n_rows == 0 || n_cols == 0) return out;
+    const size_t n = std::max(n_rows, n_cols);
+    std::vector<double> a(n * n, 0.0);
+    for (size_t i = 0; i < n_rows; i++)
+        for (size_t j = 0; j < n_cols; j++) {
+            const P c = cost_colmajor[j * n_rows + i];
+            // OrderedFloat sorts NaN above everything; use a large finite stand-in.
+            a[i * n + j] = std::isnan(c) ? 1e30 : (double)c;
+        }
+    const std::vector<int> col = hungarian(a, (int)n);
+    for (size_t i = 0; i < n_rows; i++) {
+        const int j = col[i];
+        if (j < 0 || (size_t)j >= n_cols) continue;
+        if (cost_colmajor[(size_t)j * n_rows + i] == 2.0f) continue;
+        out.emplace_back(i, (size_t)j);
+    }
+    return out;
+}
+
+struct Sort {  // sort/src/lib.rs:14-23
+    uint64_t max_age, min_hits;
+    P iou_threshold;
+    std::vector<Tracker> trackers;
+    uint64_t frame_count = 0, id_counter = 0;
+
+    std::vector<std::pair<size_t, size_t>> match_dets(const std::vector<covahip_bbox> &preds,
+                                                      const std::vector<covahip_bbox> &dets) const {
+        std::vector<std::pair<size_t, size_t>> res;
+        const size_t np = preds.size(), nd = dets.size();
+        if (np == 0 || nd == 0) return res;
+        std::vector<P> cost(np * nd);  // column-major: rows = predictions, cols = detections
+        for (size_t j = 0; j < nd; j++)
+            for (size_t i = 0; i < np; i++) {
+                const P w = trackers[i].active ? 1.f : 2.f;  // lib.rs:108-113
+                cost[j * np + i] = -bbox_iou(dets[j], preds[i]) + w;
+            }
+        for (auto &e : linear_assignment(cost, np, nd)) {
+            const P thr = trackers[e.first].active ? (1.f - iou_threshold) : (2.f - iou_threshold);
+            if (cost[e.second * np + e.first] <= thr) res.push_back(e);
+        }
+        return res;
+    }
+
+    // Sort::update, lib.rs:134-187.  Returns false if a Kalman update failed.
+    bool update(std::vector<covahip_bbox> dets, uint64_t pts, std::vector<Tracker> &dead) {
+        frame_count += 1;
+        const size_t n_dets = dets.size();
+        std::vector<covahip_bbox> preds;
+        preds.reserve(trackers.size());
+        for (auto &t : trackers) preds.push_back(t.predict(pts));
+        auto matches = match_dets(preds, dets);
+        std::vector<size_t> unmatched;
+        for (size_t j = 0; j < n_dets; j++) {
+            bool m = false;
+            for (auto &e : matches) m |= (e.second == j);
+            if (!m) unmatched.push_back(j);
+        }
+        for (size_t i = 0; i < trackers.size(); i++) {
+            const covahip_bbox *det = nullptr;
+            for (auto &e : matches)
+                if (e.first == i) {
+                    dets[e.second].has_timestamp = 1;
+                    dets[e.second].timestamp = pts;
+                    det = &dets[e.second];
+                    break;
+                }
+            if (!trackers[i].update(det)) return false;
+        }
+        for (auto &t : trackers) t.check_activate(min_hits);
+        std::vector<Tracker> keep;
+        keep.reserve(trackers.size());
+        for (auto &t : trackers) {
+            if (!t.should_live(max_age)) {
+                if (t.active) {
+                    t.trim_dead_history();
+                    dead.push_back(std::move(t));
+                }
+            } else {
+                keep.push_back(std::move(t));
+            }
+        }
+        trackers.swap(keep);
+        for (size_t j : unmatched) {
+            trackers.emplace_back(id_counter, dets[j], pts);
+            id_counter += 1;
+        }
+        return true;
+    }
+
+    std::vector<Tracker> finalize() {  // lib.rs:207-213
+        std::vector<Tracker> out, keep;
+        for (auto &t : trackers) {
+            if (t.active) {
+                if (t.history.size() > (size_t)min_hits) out.push_back(std::move(t));
+            } else {
+                keep.push_back(std::move(t));
+            }
+        }
+        trackers.swap(keep);
+        return out;
+    }
+
+    void mark_seen(uint64_t ts) {
+        for (auto &t : trackers) t.seen_ts.push_back(ts);
+    }
+};
+
+int emit_tracks(const std::vector<Tracker> &tracks, covahip_bbox *boxes, size_t cap, size_t *n_boxes,
+                uint32_t *track_lens, size_t cap_tracks, size_t *n_tracks) {
+    size_t nb = 0;
+    bool overflow = false;
+    for (size_t k = 0; k < tracks.size(); k++) {
+        if (track_lens) {
+            if (k < cap_tracks) track_lens[k] = (uint32_t)tracks[k].history.size();
+            else overflow = true;
+        }
+        for (const auto &b : tracks[k].history) {
+            if (boxes) {
+                if (nb < cap) boxes[nb] = b;
+                else overflow = true;
+            }
+            nb++;
+        }
+    }
+    if (n_boxes) *n_boxes = nb;
+    if (n_tracks) *n_tracks = tracks.size();
+    return overflow ? COVAHIP_ERR_OVERFLOW : COVAHIP_OK;
+}
+
+}  // namespace
+
+struct covahip_sort {
+    Sort s;
+};
+
+extern "C" {
+
+int covahip_sort_new(uint64_t max_age, uint64_t min_hits, float iou_threshold, covahip_sort **out) {
+    if (!out) return COVAHIP_ERR_INVALID_ARG;
+    covahip_sort *p = new (std::nothrow) covahip_sort();
+    if (!p) return COVAHIP_ERR_INVALID_ARG;
+    p->s.max_age = max_age;
+    p->s.min_hits = min_hits;
+    p->s.iou_threshold = iou_threshold;
+    *out = p;
+    return COVAHIP_OK;
+}
+
+void covahip_sort_free(covahip_sort *s) { delete s; }
+
+int covahip_sort_update(covahip_sort *s, const covahip_bbox *dets, size_t n_dets, uint64_t pts,
+                        covahip_bbox *dead_boxes, size_t cap, size_t *n_dead_boxes, uint32_t *track_lens,
+                        size_t cap_tracks, size_t *n_tracks) {
+    if (!s || (!dets && n_dets)) return COVAHIP_ERR_INVALID_ARG;
+    std::vector<covahip_bbox> d(dets, dets + n_dets);
+    std::vector<Tracker> dead;
+    if (!s->s.update(std::move(d), pts, dead)) return COVAHIP_ERR_BAD_DATA;
+    return emit_tracks(dead, dead_boxes, cap, n_dead_boxes, track_lens, cap_tracks, n_tracks);
+}
+
+int covahip_sort_finalize(covahip_sort *s, covahip_bbox *boxes, size_t cap, size_t *n_boxes,
+                          uint32_t *track_lens, size_t cap_tracks, size_t *n_tracks) {
+    if (!s) return COVAHIP_ERR_INVALID_ARG;
+    std::vector<Tracker> fin = s->s.finalize();
+    return emit_tracks(fin, boxes, cap, n_boxes, track_lens, cap_tracks, n_tracks);
+}
+
+int covahip_sort_mark_seen(covahip_sort *s, uint64_t ts) {
+    if (!s) return COVAHIP_ERR_INVALID_ARG;
+    s->s.mark_seen(ts);
+    return COVAHIP_OK;
+}
+
+int covahip_sort_num_trackers(const covahip_sort *s, size_t *n) {
+    if (!s || !n) return COVAHIP_ERR_INVALID_ARG;
+    *n = s->s.trackers.size();
+    return COVAHIP_OK;
+}
+
+int covahip_sort_tracker_info(const covahip_sort *s, size_t i, uint64_t *id, int *active,
+                              uint64_t *hit_streaks, uint64_t *time_since_update, covahip_bbox *state) {
+    if (!s || i >= s->s.trackers.size()) return COVAHIP_ERR_INVALID_ARG;
+    const Tracker &t = s->s.trackers[i];
+    if (id) *id = t.id;
+    if (active) *active = t.active ? 1 : 0;
+    if (hit_streaks) *hit_streaks = t.hit_streaks;
+    if (time_since_update) *time_since_update = t.time_since_update;
+    if (state) *state = from_x(t.x);  // get_state(): box of the current estimate
+    return COVAHIP_OK;
+}
+
+size_t covahip_linear_assignment(const float *cost_colmajor, size_t n_rows, size_t n_cols, uint32_t *pairs,
+                                 size_t cap_pairs) {
+    if (!cost_colmajor) return 0;
+    std::vector<P> c(cost_colmajor, cost_colmajor + n_rows * n_cols);
+    auto e = linear_assignment(c, n_rows, n_cols);
+    for (size_t k = 0; k < e.size() && k < cap_pairs; k++) {
+        pairs[2 * k] = (uint32_t)e[k].first;
+        pairs[2 * k + 1] = (uint32_t)e[k].second;
+    }
+    return e.size();
+}
+
+}  // extern "C"
+
+// ============================================================== cova GoP filter
+namespace {
+
+struct Au {
+    uint64_t id, pts;
+    uint32_t flags;
+};
+struct Gop {  // (min, max, in, out, finalized) -- cova/imp.rs:58-67
+    uint64_t min, max;
+    std::list<Au> in, out;
+    bool finalized;
+};
+
+constexpr uint64_t SECOND = 1000000000ull;
+
+}  // namespace
+
+struct covahip_gopfilter {
+    covahip_gopfilter_cfg cfg;
+    std::list<Gop> bufs;
+    Sort *sort = nullptr;
+    bool have_range_start = false;
+    uint64_t range_start = 0;
+    uint64_t dropped = 0, decoded_dependency = 0, decoded_inference = 0;
+    uint32_t next_list = 0;
+    ~covahip_gopfilter() { delete sort; }
+};
+
+namespace {
+
+struct OutSink {
+    covahip_au_out *out;
+    size_t cap;
+    size_t n = 0;
+    void push_list(covahip_gopfilter *g, std::list<Au> &lst) {
+        const uint32_t li = g->next_list++;
+        for (const Au &a : lst) {
+            if (out && n < cap) {
+                out[n].id = a.id;
+                out[n].pts = a.pts;
+                out[n].flags = a.flags;
+                out[n].list = li;
+            }
+            n++;
+        }
+        lst.clear();
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+void covahip_gopfilter_default_cfg(covahip_gopfilter_cfg *cfg) {
+    if (!cfg) return;
+    cfg->sort_iou = 0.1f;
+    cfg->sort_maxage = 30;
+    cfg->sort_minhits = 30;
+    cfg->alpha = 0;
+    cfg->beta = 0;
+    cfg->infer_i = 0;
+}
+
+int covahip_gopfilter_new(const covahip_gopfilter_cfg *cfg, covahip_gopfilter **out) {
+    if (!cfg || !out) return COVAHIP_ERR_INVALID_ARG;
+    covahip_gopfilter *g = new (std::nothrow) covahip_gopfilter();
+    if (!g) return COVAHIP_ERR_INVALID_ARG;
+    g->cfg = *cfg;
+    *out = g;
+    return COVAHIP_OK;
+}
+
+void covahip_gopfilter_free(covahip_gopfilter *g) { delete g; }
+
+int covahip_gopfilter_push_enc(covahip_gopfilter *g, uint64_t id, uint64_t pts, uint32_t flags) {
+    if (!g) return COVAHIP_ERR_INVALID_ARG;
+    if (!(flags & COVAHIP_AU_DELTA_UNIT)) {  // imp.rs:327-347: key frame opens a GoP
+        if (!g->bufs.empty()) g->bufs.back().finalized = true;
+        Gop gop;
+        gop.min = gop.max = pts;
+        gop.finalized = false;
+        gop.in.push_back(Au{id, pts, flags | COVAHIP_AU_DISCONT});
+        g->bufs.push_back(std::move(gop));
+    } else {  // imp.rs:348-358
+        if (g->bufs.empty()) return COVAHIP_ERR_BAD_DATA;  // reference: unwrap() panic
+        Gop &back = g->bufs.back();
+        if (pts < back.min) back.min = pts;
+        else if (pts > back.max) back.max = pts;
+        back.in.push_back(Au{id, pts, flags});
+    }
+    return COVAHIP_OK;
+}
+
+int covahip_gopfilter_push_boxes(covahip_gopfilter *g, const covahip_bbox *boxes, size_t n, uint64_t pts,
+                                 covahip_au_out *out, size_t cap, size_t *n_out) {
+    if (!g || (!boxes && n)) return COVAHIP_ERR_INVALID_ARG;
+    OutSink sink{out, cap};
+    if (!g->sort) {  // imp.rs:99-108 (tracker dims 45x80 are unused by Sort)
+        g->sort = new Sort();
+        g->sort->max_age = g->cfg.sort_maxage;
+        g->sort->min_hits = g->cfg.sort_minhits;
+        g->sort->iou_threshold = (P)(double)g->cfg.sort_iou;
+    }
+    // cova/tracker.rs:43-60
+    if (!g->have_range_start) {
+        g->have_range_start = true;
+        g->range_start = pts;
+    }
+    std::vector<Tracker> dead;
+    if (!g->sort->update(std::vector<covahip_bbox>(boxes, boxes + n), pts, dead)) return COVAHIP_ERR_BAD_DATA;
+    bool have_min = !dead.empty();
+    uint64_t min_track_pts = 0;
+    for (const Tracker &t : dead)
+        if (!t.is_seen()) min_track_pts = std::max(min_track_pts, t.start);
+
+    const uint64_t clk30 = SECOND / 30;
+    const uint64_t maxage_pts = clk30 * ((uint64_t)g->cfg.sort_maxage + 10);  // SAFETY_BUFFER = 10
+    const uint64_t max_track_pts = pts >= maxage_pts ? pts - maxage_pts : 0;
+
+    if (have_min) {  // imp.rs:135-253
+        size_t track_inferenced = 0;
+        uint64_t dd = 0, di = 0;
+        for (auto it = g->bufs.rbegin(); it != g->bufs.rend(); ++it) {
+            Gop &gop = *it;
+            if (!(min_track_pts <= gop.max && gop.min <= max_track_pts)) continue;
+            bool already = false;
+            for (const Au &a : gop.out)
+                if (min_track_pts < a.pts) {
+                    track_inferenced += 1;
+                    already = true;
+                    break;
+                }
+            if (already) continue;
+            while (!gop.in.empty()) {
+                Au buf = gop.in.front();
+                gop.in.pop_front();
+                if (track_inferenced > 0) break;  // NB: the popped AU is discarded (reference behaviour)
+                if (min_track_pts <= buf.pts) {
+                    g->sort->mark_seen(buf.pts);
+                    di += 1;
+                    gop.out.push_back(buf);
+                    track_inferenced += 1;
+                    break;
+                } else {
+                    buf.flags |= COVAHIP_AU_DROPPABLE;
+                    dd += 1;
+                    gop.out.push_back(buf);
+                }
+            }
+        }
+        if (track_inferenced < (size_t)g->cfg.beta) {  // imp.rs:200-246
+            for (auto it = g->bufs.rbegin(); it != g->bufs.rend(); ++it) {
+                Gop &gop = *it;
+                if (!(min_track_pts <= gop.max && gop.min <= max_track_pts)) continue;
+                if (gop.out.empty()) continue;
+                const size_t extra_decode = std::min(gop.in.size(), (size_t)g->cfg.alpha);
+                const size_t extra_infer = std::min(extra_decode, (size_t)g->cfg.beta - track_inferenced);
+                if (extra_decode == 0 || extra_infer == 0) continue;
+                const size_t step = extra_decode / extra_infer, rem = extra_decode % extra_infer;
+                for (size_t k = 0; k < rem; k++) {
+                    Au b = gop.in.front();
+                    gop.in.pop_front();
+                    b.flags |= COVAHIP_AU_DROPPABLE;
+                    dd += 1;
+                    gop.out.push_back(b);
+                }
+                for (size_t k = 0; k < extra_infer; k++) {
+                    const size_t ndep = step > 0 ? step - 1 : 0;
+                    for (size_t q = 0; q < ndep; q++) {
+                        Au b = gop.in.front();
+                        gop.in.pop_front();
+                        b.flags |= COVAHIP_AU_DROPPABLE;
+                        dd += 1;
+                        gop.out.push_back(b);
+                    }
+                    Au b = gop.in.front();
+                    gop.in.pop_front();
+                    g->sort->mark_seen(b.pts);
+                    di += 1;
+                    gop.out.push_back(b);
+                    track_inferenced += 1;
+                }
+            }
+        }
+        if (track_inferenced == 0) {  // reference: assert!(track_inferenced > 0) -> panic -> FlowError
+            if (n_out) *n_out = 0;
+            return COVAHIP_ERR_BAD_DATA;
+        }
+        g->decoded_inference += di;
+        g->decoded_dependency += dd;
+    }
+
+    // imp.rs:255-315: flush finalised GoPs older than 250 frames
+    uint64_t dropped = 0, di2 = 0;
+    const uint64_t gop_pts = clk30 * 250;
+    const uint64_t droppable_pts = pts >= gop_pts ? pts - gop_pts : 0;
+    for (auto it = g->bufs.begin(); it != g->bufs.end();) {
+        Gop &gop = *it;
+        if (!(gop.finalized && gop.max <= droppable_pts)) {
+            ++it;
+            continue;
+        }
+        if (g->cfg.infer_i && !gop.in.empty()) {
+            Au b = gop.in.front();
+            gop.in.pop_front();
+            if (!(b.flags & COVAHIP_AU_DELTA_UNIT)) {
+                di2 += 1;
+                gop.out.push_back(b);
+            } else {
+                dropped += 1;
+            }
+        }
+        if (!gop.out.empty()) sink.push_list(g, gop.out);
+        dropped += gop.in.size();
+        it = g->bufs.erase(it);
+    }
+    g->decoded_inference += di2;
+    g->dropped += dropped;
+    if (n_out) *n_out = sink.n;
+    return (out && sink.n > cap) ? COVAHIP_ERR_OVERFLOW : COVAHIP_OK;
+}
+
+int covahip_gopfilter_eos(covahip_gopfilter *g, covahip_au_out *out, size_t cap, size_t *n_out) {
+    if (!g) return COVAHIP_ERR_INVALID_ARG;
+    OutSink sink{out, cap};
+    uint64_t dropped = 0;
+    for (Gop &gop : g->bufs) {  // imp.rs:371-387
+        dropped += gop.in.size();
+        sink.push_list(g, gop.out);
+    }
+    g->bufs.clear();
+    g->dropped += dropped;
+    delete g->sort;  // tracker.take(); flush() only writes to the optional TCP socket
+    g->sort = nullptr;
+    if (n_out) *n_out = sink.n;
+    return (out && sink.n > cap) ? COVAHIP_ERR_OVERFLOW : COVAHIP_OK;
+}
+
+int covahip_gopfilter_counters(const covahip_gopfilter *g, uint64_t *dropped, uint64_t *decoded_dependency,
+                               uint64_t *decoded_inference) {
+    if (!g) return COVAHIP_ERR_INVALID_ARG;
+    if (dropped) *dropped = g->dropped;
+    if (decoded_dependency) *decoded_dependency = g->decoded_dependency;
+    if (decoded_inference) *decoded_inference = g->decoded_inference;
+    return COVAHIP_OK;
+}
+
+}  // extern "C"

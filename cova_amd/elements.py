@@ -1,0 +1,425 @@
+"""Host-side mirror of the CoVA GStreamer elements on the compressed-domain hot path.
+
+Same element names, property names/defaults and buffer semantics as the reference's
+Rust/C++ elements, but every piece of arithmetic or state goes through the C-ABI of
+libcovahip.so (include/covahip.h) -- this module only marshals buffers, exactly what a
+GStreamer element's transform()/chain() vfunc would do.
+
+  metapreprocess  cova-rs/gst-plugins/src/metapreprocess/imp.rs   -> MetaPreprocess
+  nvinfer(BlobNet) config/blobnet/*.txt, model/tasks.py            -> BlobNetInfer
+  maskcopy        gst-plugins/gst-maskcopy/gstmaskcopy.cpp         -> folded into BlobNetInfer
+                                                                      (mask is already GRAY8 {0,1})
+  bboxcc          cova-rs/gst-plugins/src/bboxcc/{imp,process}.rs  -> BboxCc
+  sorttracker     cova-rs/gst-plugins/src/sorttracker/imp.rs       -> SortTracker
+  cova            cova-rs/gst-plugins/src/cova/{imp,tracker}.rs    -> Cova
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from . import weights as W
+
+FLOW_OK = "ok"
+FLOW_DROPPED = "dropped"  # gst_base::BASE_TRANSFORM_FLOW_DROPPED
+
+
+def _ptr(a: np.ndarray) -> int:
+    return a.ctypes.data
+
+
+# ---------------------------------------------------------------------------------- ctx
+class Context:
+    """One GPU context (device + HIP stream + BlobNet workspace)."""
+
+    def __init__(self, device_id: int = 0):
+        self._lib = L.lib()
+        h = C.c_void_p()
+        L.check(self._lib.covahip_ctx_create(device_id, C.byref(h)), "covahip_ctx_create")
+        self.handle = h
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.covahip_ctx_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def sync(self):
+        L.check(self._lib.covahip_ctx_sync(self.handle), "covahip_ctx_sync", self.handle)
+
+    def info(self):
+        name = C.create_string_buffer(256)
+        cu = C.c_int()
+        mem = C.c_size_t()
+        L.check(self._lib.covahip_device_info(self.handle, name, 256, C.byref(cu), C.byref(mem)), "device_info")
+        return {"name": name.value.decode(), "num_cu": cu.value, "hbm_bytes": mem.value}
+
+    # device memory -------------------------------------------------------------
+    def malloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        L.check(self._lib.covahip_malloc(self.handle, nbytes, C.byref(p)), "covahip_malloc", self.handle)
+        return p.value
+
+    def free(self, dptr: int):
+        L.check(self._lib.covahip_free(self.handle, dptr), "covahip_free", self.handle)
+
+    def h2d(self, dptr: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        L.check(self._lib.covahip_memcpy_h2d(self.handle, dptr, _ptr(arr), arr.nbytes), "h2d", self.handle)
+
+    def d2h(self, arr: np.ndarray, dptr: int):
+        assert arr.flags["C_CONTIGUOUS"]
+        L.check(self._lib.covahip_memcpy_d2h(self.handle, _ptr(arr), dptr, arr.nbytes), "d2h", self.handle)
+
+    # timing --------------------------------------------------------------------
+    def timer_start(self, slot=0):
+        L.check(self._lib.covahip_timer_start(self.handle, slot), "timer_start", self.handle)
+
+    def timer_stop(self, slot=0):
+        L.check(self._lib.covahip_timer_stop(self.handle, slot), "timer_stop", self.handle)
+
+    def timer_ms(self, slot=0) -> float:
+        ms = C.c_float()
+        L.check(self._lib.covahip_timer_elapsed_ms(self.handle, slot, C.byref(ms)), "timer_elapsed", self.handle)
+        return ms.value
+
+    def profile(self, on: bool):
+        L.check(self._lib.covahip_profile_enable(self.handle, int(on)), "profile_enable")
+        L.check(self._lib.covahip_profile_reset(self.handle), "profile_reset")
+
+    def profile_read(self):
+        buf = np.zeros(64, dtype=L.KERNEL_TIME_DTYPE)
+        n = C.c_int()
+        L.check(self._lib.covahip_profile_read(self.handle, _ptr(buf), 64, C.byref(n)), "profile_read")
+        return {r["name"].decode(): (float(r["total_ms"]), int(r["launches"])) for r in buf[:n.value]}
+
+
+# ---------------------------------------------------------------------- metapreprocess
+class MetaPreprocess:
+    """`metapreprocess` (BaseTransform, NeverInPlace): properties `timestep`, `gamma`."""
+
+    def __init__(self, timestep: int = 1, gamma: int = 1):  # DEFAULT_TIMESTEP / DEFAULT_GAMMA = 1
+        self.timestep = timestep
+        self.gamma = gamma
+        self._h = None
+        self._lib = L.lib()
+
+    def transform_caps(self, width: int, height: int):
+        """sink caps I420 w x h  ->  src caps RGBA (w/16) x (h/16*timestep) (imp.rs:247-286)."""
+        ow, oh = C.c_int(), C.c_int()
+        self._lib.covahip_stack_out_dims(width, height, self.timestep, C.byref(ow), C.byref(oh))
+        return ow.value, oh.value
+
+    def set_caps(self, width: int, height: int):
+        ow, oh = self.transform_caps(width, height)
+        out_size = ow * oh * 4                       # RGBA VideoInfo size
+        self.size_per_buf = out_size // self.timestep  # imp.rs:233
+        self.out_size = out_size
+        self.stop()
+        h = C.c_void_p()
+        L.check(self._lib.covahip_stack_new(self.size_per_buf, self.timestep, self.gamma, C.byref(h)), "stack_new")
+        self._h = h
+        return ow, oh
+
+    def transform(self, inbuf: bytes | np.ndarray):
+        """Returns (FLOW_OK, out_bytes) or (FLOW_DROPPED, None)."""
+        a = np.frombuffer(inbuf, dtype=np.uint8) if not isinstance(inbuf, np.ndarray) else inbuf.reshape(-1)
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        out = np.empty(self.out_size, dtype=np.uint8)
+        em = C.c_int()
+        L.check(self._lib.covahip_stack_push(self._h, _ptr(a), a.size, _ptr(out), out.size, C.byref(em)), "stack_push")
+        return (FLOW_OK, out) if em.value else (FLOW_DROPPED, None)
+
+    def stop(self):
+        if self._h:
+            self._lib.covahip_stack_free(self._h)
+            self._h = None
+
+    __del__ = stop
+
+
+# ------------------------------------------------------------------- nvinfer(BlobNet)
+class BlobNetInfer:
+    """Stands where `nvinfer` (BlobNet TensorRT engine) + `maskcopy` stand in the reference
+    pipeline: batched RGBA stacks in, GRAY8 {0,1} masks (and optionally logits) out."""
+
+    def __init__(self, ctx: Context, weights_flat: np.ndarray, h_mb: int, w_mb: int, max_batch: int,
+                 timestep: int = 4):
+        self.ctx, self.h, self.w, self.t, self.max_batch = ctx, h_mb, w_mb, timestep, max_batch
+        self._lib = L.lib()
+        blob = W.to_bytes(weights_flat)
+        L.check(self._lib.covahip_blobnet_load(ctx.handle, blob, len(blob), h_mb, w_mb, timestep, max_batch),
+                "covahip_blobnet_load", ctx.handle)
+
+    def set_impl(self, impl: str):
+        L.check(self._lib.covahip_blobnet_set_impl(self.ctx.handle, {"naive": 0, "mfma": 1}[impl]), "set_impl")
+
+    @property
+    def macs_per_frame(self) -> int:
+        v = C.c_int64()
+        L.check(self._lib.covahip_blobnet_macs_per_frame(self.ctx.handle, C.byref(v)), "macs_per_frame")
+        return v.value
+
+    def infer(self, stack: np.ndarray, want_logits: bool = True):
+        """stack u8 [B][t*h][w][4] (host) -> (logits f32 [B][h][w] | None, mask u8 [B][h][w])."""
+        stack = np.ascontiguousarray(stack, dtype=np.uint8)
+        b = stack.shape[0]
+        assert stack.shape == (b, self.t * self.h, self.w, 4), stack.shape
+        logits = np.empty((b, self.h, self.w), dtype=np.float32) if want_logits else None
+        mask = np.empty((b, self.h, self.w), dtype=np.uint8)
+        L.check(self._lib.covahip_blobnet_forward(self.ctx.handle, _ptr(stack), b, _ptr(logits) if want_logits else None,
+                                                  _ptr(mask), L.MEM_HOST), "covahip_blobnet_forward", self.ctx.handle)
+        return logits, mask
+
+    def infer_device(self, d_stack: int, batch: int, d_logits: int | None, d_mask: int | None):
+        L.check(self._lib.covahip_blobnet_forward(self.ctx.handle, d_stack, batch, d_logits, d_mask, L.MEM_DEVICE),
+                "covahip_blobnet_forward", self.ctx.handle)
+
+    def filter(self, stack: np.ndarray, cc_threshold: int, max_boxes: int = 256, want_mask: bool = False):
+        """Fused BlobNet -> mask -> bboxcc on host buffers: returns (boxes [B][max_boxes], counts [B], mask|None)."""
+        stack = np.ascontiguousarray(stack, dtype=np.uint8)
+        b = stack.shape[0]
+        boxes = np.zeros((b, max_boxes), dtype=L.BOX_DTYPE)
+        counts = np.zeros(b, dtype=np.int32)
+        mask = np.empty((b, self.h, self.w), dtype=np.uint8) if want_mask else None
+        L.check(self._lib.covahip_filter_forward(self.ctx.handle, _ptr(stack), b, cc_threshold, _ptr(boxes), _ptr(counts),
+                                                 max_boxes, None, _ptr(mask) if want_mask else None, L.MEM_HOST),
+                "covahip_filter_forward", self.ctx.handle)
+        return boxes, counts, mask
+
+    def filter_device(self, d_stack: int, batch: int, cc_threshold: int, d_boxes: int, d_counts: int, max_boxes: int,
+                      d_mask: int | None = None):
+        L.check(self._lib.covahip_filter_forward(self.ctx.handle, d_stack, batch, cc_threshold, d_boxes, d_counts,
+                                                 max_boxes, None, d_mask, L.MEM_DEVICE),
+                "covahip_filter_forward", self.ctx.handle)
+
+
+# -------------------------------------------------------------------------------- bbox
+def boxes_to_bbox(boxes: np.ndarray) -> np.ndarray:
+    """covahip_box[] (CC stats) -> covahip_bbox[] via Bbox::new (process.rs:47)."""
+    boxes = np.ascontiguousarray(boxes, dtype=L.BOX_DTYPE)
+    out = np.zeros(boxes.shape[0], dtype=L.BBOX_DTYPE)
+    L.lib().covahip_boxes_to_bbox(_ptr(boxes), boxes.shape[0], _ptr(out))
+    return out
+
+
+def make_bbox(left, top, width, height) -> np.ndarray:
+    b = np.zeros(1, dtype=L.BBOX_DTYPE)
+    b["left"], b["top"], b["width"], b["height"] = left, top, width, height
+    b["area"] = np.float32(width) * np.float32(height)
+    return b
+
+
+def serialize_vec(bboxes: np.ndarray) -> bytes:
+    bboxes = np.ascontiguousarray(bboxes, dtype=L.BBOX_DTYPE)
+    n = bboxes.shape[0]
+    need = L.lib().covahip_bbox_serialize_vec(_ptr(bboxes), n, None, 0, None)
+    out = np.empty(need, dtype=np.uint8)
+    st = C.c_int()
+    L.lib().covahip_bbox_serialize_vec(_ptr(bboxes), n, _ptr(out), need, C.byref(st))
+    L.check(st.value, "covahip_bbox_serialize_vec")
+    return out.tobytes()
+
+
+def deserialize_vec(data: bytes) -> np.ndarray:
+    a = np.frombuffer(data, dtype=np.uint8)
+    n = C.c_size_t()
+    cap = max(len(data) // 24, 1)
+    out = np.zeros(cap, dtype=L.BBOX_DTYPE)
+    L.check(L.lib().covahip_bbox_deserialize_vec(_ptr(a) if a.size else None, a.size, _ptr(out), cap, C.byref(n)),
+            "covahip_bbox_deserialize_vec")
+    return out[:n.value].copy()
+
+
+def serialize_frame(range_start: int, oldest: int, bboxes: np.ndarray) -> bytes:
+    bboxes = np.ascontiguousarray(bboxes, dtype=L.BBOX_DTYPE)
+    n = bboxes.shape[0]
+    need = L.lib().covahip_frame_serialize(range_start, oldest, _ptr(bboxes), n, None, 0, None)
+    out = np.empty(need, dtype=np.uint8)
+    st = C.c_int()
+    L.lib().covahip_frame_serialize(range_start, oldest, _ptr(bboxes), n, _ptr(out), need, C.byref(st))
+    L.check(st.value, "covahip_frame_serialize")
+    return out.tobytes()
+
+
+def iou(a: np.ndarray, b: np.ndarray) -> float:
+    a = np.ascontiguousarray(a, dtype=L.BBOX_DTYPE)
+    b = np.ascontiguousarray(b, dtype=L.BBOX_DTYPE)
+    return float(L.lib().covahip_bbox_iou(_ptr(a), _ptr(b)))
+
+
+# ------------------------------------------------------------------------------ bboxcc
+class BboxCc:
+    """`bboxcc` (BaseTransform, AlwaysInPlace): property `cc-threshold` (default 30)."""
+
+    def __init__(self, ctx: Context, cc_threshold: int = 30, max_boxes: int = 1024):
+        self.ctx, self.cc_threshold, self.max_boxes = ctx, cc_threshold, max_boxes
+        self._lib = L.lib()
+
+    def regionprops(self, masks: np.ndarray):
+        """masks u8 [B][H][W] (host) -> (boxes [B][max_boxes], counts [B])."""
+        masks = np.ascontiguousarray(masks, dtype=np.uint8)
+        if masks.ndim == 2:
+            masks = masks[None]
+        b, h, w = masks.shape
+        boxes = np.zeros((b, self.max_boxes), dtype=L.BOX_DTYPE)
+        counts = np.zeros(b, dtype=np.int32)
+        L.check(self._lib.covahip_bboxcc(self.ctx.handle, _ptr(masks), b, h, w, self.cc_threshold, _ptr(boxes),
+                                         _ptr(counts), self.max_boxes, L.MEM_HOST), "covahip_bboxcc", self.ctx.handle)
+        return boxes, counts
+
+    def regionprops_device(self, d_masks: int, b: int, h: int, w: int, d_boxes: int, d_counts: int):
+        L.check(self._lib.covahip_bboxcc(self.ctx.handle, d_masks, b, h, w, self.cc_threshold, d_boxes, d_counts,
+                                         self.max_boxes, L.MEM_DEVICE), "covahip_bboxcc", self.ctx.handle)
+
+    def transform_ip(self, buf: bytes | np.ndarray, width: int, height: int) -> bytes:
+        """GRAY8 mask buffer -> bincode Vec<Bbox> bytes (imp.rs:232-272)."""
+        m = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf
+        m = m.reshape(height, -1)[:, :width]  # process.rs:14-15: reshape(1, height)
+        boxes, counts = self.regionprops(m)
+        n = int(counts[0])
+        if n > self.max_boxes:
+            raise L.CovahipError(7, "bboxcc.transform_ip", f"{n} boxes > max_boxes {self.max_boxes}")
+        return serialize_vec(boxes_to_bbox(boxes[0, :n]))
+
+
+# ------------------------------------------------------------------------- sorttracker
+class _SortHandle:
+    def __init__(self, max_age: int, min_hits: int, iou_threshold: float):
+        self._lib = L.lib()
+        h = C.c_void_p()
+        L.check(self._lib.covahip_sort_new(max_age, min_hits, iou_threshold, C.byref(h)), "sort_new")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.covahip_sort_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _collect(self, fn, *args):
+        cap, capt = 4096, 256
+        while True:
+            boxes = np.zeros(cap, dtype=L.BBOX_DTYPE)
+            lens = np.zeros(capt, dtype=np.uint32)
+            nb, nt = C.c_size_t(), C.c_size_t()
+            st = fn(*args, _ptr(boxes), cap, C.byref(nb), _ptr(lens), capt, C.byref(nt))
+            if st == 7:
+                raise L.CovahipError(st, "sort output capacity")  # state already advanced; sized generously
+            L.check(st, "sort")
+            return boxes[:nb.value].copy(), lens[:nt.value].copy()
+
+    def update(self, dets: np.ndarray, pts: int):
+        dets = np.ascontiguousarray(dets, dtype=L.BBOX_DTYPE)
+        return self._collect(lambda *a: self._lib.covahip_sort_update(self.h, _ptr(dets), dets.shape[0], pts, *a))
+
+    def finalize(self):
+        return self._collect(lambda *a: self._lib.covahip_sort_finalize(self.h, *a))
+
+    def mark_seen(self, ts: int):
+        L.check(self._lib.covahip_sort_mark_seen(self.h, ts), "sort_mark_seen")
+
+    def num_trackers(self) -> int:
+        n = C.c_size_t()
+        L.check(self._lib.covahip_sort_num_trackers(self.h, C.byref(n)), "sort_num_trackers")
+        return n.value
+
+    def tracker_info(self, i: int):
+        tid, act, hs, tsu = C.c_uint64(), C.c_int(), C.c_uint64(), C.c_uint64()
+        st = np.zeros(1, dtype=L.BBOX_DTYPE)
+        L.check(self._lib.covahip_sort_tracker_info(self.h, i, C.byref(tid), C.byref(act), C.byref(hs), C.byref(tsu),
+                                                    _ptr(st)), "sort_tracker_info")
+        return {"id": tid.value, "active": bool(act.value), "hit_streaks": hs.value,
+                "time_since_update": tsu.value, "state": st[0]}
+
+
+class SortTracker:
+    """`sorttracker` (BaseTransform, NeverInPlace): `iou-threshold` 0.1, `maxage` 30, `minhits` 30."""
+
+    def __init__(self, iou_threshold: float = 0.1, maxage: int = 30, minhits: int = 30):
+        self.iou_threshold, self.maxage, self.minhits = iou_threshold, maxage, minhits
+        self.sort = None
+
+    def set_caps(self, width: int = 0, height: int = 0):  # Sort created in set_caps (imp.rs:209-236)
+        self.sort = _SortHandle(self.maxage, self.minhits, self.iou_threshold)
+
+    def transform(self, inbuf: bytes, pts: int) -> bytes:
+        if self.sort is None:
+            self.set_caps()
+        dead, _ = self.sort.update(deserialize_vec(inbuf), pts)
+        return serialize_vec(dead)
+
+    def sink_event_eos(self) -> bytes:
+        fin, _ = self.sort.finalize()
+        return serialize_vec(fin)
+
+
+def linear_assignment(cost: np.ndarray):
+    """cost [n_rows][n_cols] f32 -> sorted list of (row, col) (sort/src/lib.rs:25-56)."""
+    cost = np.asarray(cost, dtype=np.float32)
+    nr, nc = cost.shape
+    colmajor = np.ascontiguousarray(cost.T).reshape(-1)
+    pairs = np.zeros(2 * max(nr, nc, 1), dtype=np.uint32)
+    n = L.lib().covahip_linear_assignment(_ptr(colmajor), nr, nc, _ptr(pairs), pairs.size // 2)
+    return sorted((int(pairs[2 * k]), int(pairs[2 * k + 1])) for k in range(n))
+
+
+# -------------------------------------------------------------------------------- cova
+class Cova:
+    """`cova` element: pads sink_mask (bbox), sink_enc (encoded AUs), src.  Properties as in
+    cova/imp.rs:22-29,590-634; read-only counters dropped / decoded-dependency / decoded-inference."""
+
+    def __init__(self, sort_iou: float = 0.1, sort_maxage: int = 30, sort_minhits: int = 30, port: int = 0,
+                 infer_i: bool = False, debug: bool = False, alpha: int = 0, beta: int = 0):
+        if port != 0:
+            raise NotImplementedError("TCP track export (analysis-aggregator link) is out of scope of the hot path")
+        self._lib = L.lib()
+        cfg = L.GopFilterCfg(sort_iou, sort_maxage, sort_minhits, alpha, beta, int(infer_i))
+        h = C.c_void_p()
+        L.check(self._lib.covahip_gopfilter_new(C.byref(cfg), C.byref(h)), "gopfilter_new")
+        self._h = h
+        self._eos = [False, False]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.covahip_gopfilter_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def sink_enc_chain(self, au_id: int, pts: int, delta_unit: bool):
+        L.check(self._lib.covahip_gopfilter_push_enc(self._h, au_id, pts, L.AU_DELTA_UNIT if delta_unit else 0),
+                "gopfilter_push_enc")
+
+    def _out(self, fn):
+        cap = 1 << 16
+        out = np.zeros(cap, dtype=L.AU_OUT_DTYPE)
+        n = C.c_size_t()
+        L.check(fn(_ptr(out), cap, C.byref(n)), "gopfilter")
+        return out[:n.value].copy()
+
+    def sink_mask_chain(self, bbox_bytes: bytes, pts: int) -> np.ndarray:
+        boxes = deserialize_vec(bbox_bytes)
+        return self._out(lambda o, c, n: self._lib.covahip_gopfilter_push_boxes(self._h, _ptr(boxes), boxes.shape[0],
+                                                                                pts, o, c, n))
+
+    def eos(self, pad: str):
+        """EOS on `sink_enc` / `sink_mask`; flushes once both have seen it (imp.rs:361-432)."""
+        self._eos[0 if pad == "sink_enc" else 1] = True
+        if all(self._eos):
+            return self._out(lambda o, c, n: self._lib.covahip_gopfilter_eos(self._h, o, c, n))
+        return None
+
+    def _counters(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        L.check(self._lib.covahip_gopfilter_counters(self._h, C.byref(a), C.byref(b), C.byref(c)), "counters")
+        return a.value, b.value, c.value
+
+    dropped = property(lambda s: s._counters()[0])
+    decoded_dependency = property(lambda s: s._counters()[1])
+    decoded_inference = property(lambda s: s._counters()[2])

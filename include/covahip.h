@@ -1,0 +1,249 @@
+/*
+ * covahip.h -- C-ABI of libcovahip.so, the MI355X (gfx950) compressed-domain filter
+ * stage for CoVA.
+ *
+ * This is the drop-in boundary: every entry point replaces one piece of arithmetic
+ * or host state that a CoVA GStreamer element performs today, and is what that
+ * element's FFI (Rust `extern "C"` / C++ direct call) would bind.  The shape follows
+ * the reference's own C-ABI precedent, cova-rs/nvdsbbox/nvdsbbox.h:7-14 (opaque
+ * handle, plain scalars, caller-owned byte buffers, integer status).
+ *
+ *   - no C++/HIP/torch types in any signature: plain pointers, sizes, ints
+ *   - every function returns a covahip_status (0 = OK) unless noted
+ *   - no exceptions or unwinding cross the boundary, no global state
+ *   - one covahip_ctx per GPU per thread of use; host objects (stack / sort /
+ *     gopfilter) are one per stream, like the element instances they back
+ *   - pointers tagged "dev" must be device memory of the ctx's GPU (from
+ *     covahip_malloc or any HIP allocation of the same process); "host" pointers
+ *     are ordinary memory.  mem_kind says which one a dual-use pointer is.
+ *
+ * Reference paths below are relative to /root/reference.
+ */
+#ifndef COVAHIP_H
+#define COVAHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+typedef enum covahip_status {
+    COVAHIP_OK = 0,
+    COVAHIP_ERR_INVALID_ARG = 1,
+    COVAHIP_ERR_NO_DEVICE = 2,      /* no HIP device / HIP runtime failure at init      */
+    COVAHIP_ERR_HIP = 3,            /* a HIP call failed; see covahip_last_hip_error    */
+    COVAHIP_ERR_NOT_LOADED = 4,     /* BlobNet weights not loaded                       */
+    COVAHIP_ERR_UNSUPPORTED = 5,    /* geometry outside what the kernels are built for  */
+    COVAHIP_ERR_BAD_WEIGHTS = 6,    /* weight blob header / size mismatch               */
+    COVAHIP_ERR_OVERFLOW = 7,       /* caller buffer too small                          */
+    COVAHIP_ERR_BAD_DATA = 8        /* malformed bincode input                          */
+} covahip_status;
+
+const char *covahip_strerror(int status);
+/* "covahip <version> gfx950 ..." -- static string */
+const char *covahip_version(void);
+
+enum { COVAHIP_MEM_HOST = 0, COVAHIP_MEM_DEVICE = 1 };
+
+/* ------------------------------------------------------------ GPU context */
+typedef struct covahip_ctx covahip_ctx;
+
+int covahip_device_count(int *count);
+/* Creates a context on GPU `device_id` with its own HIP stream.
+ * (The reference pins its engines with gpu-id, config/blobnet/amsterdam_b128.txt:6,
+ *  gst-plugins/gst-maskcopy/gstmaskcopy.cpp:247.) */
+int covahip_ctx_create(int device_id, covahip_ctx **out);
+void covahip_ctx_destroy(covahip_ctx *ctx);
+int covahip_ctx_sync(covahip_ctx *ctx);
+/* Text of the last failing HIP call on this ctx ("" if none). */
+const char *covahip_last_hip_error(covahip_ctx *ctx);
+/* Device properties the bench reports: name (<=255 chars), CU count, HBM bytes. */
+int covahip_device_info(covahip_ctx *ctx, char *name, size_t name_cap, int *num_cu, size_t *hbm_bytes);
+
+/* Device memory helpers so a host language needs no HIP binding of its own. */
+int covahip_malloc(covahip_ctx *ctx, size_t bytes, void **dev_ptr);
+int covahip_free(covahip_ctx *ctx, void *dev_ptr);
+int covahip_memcpy_h2d(covahip_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
+int covahip_memcpy_d2h(covahip_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
+int covahip_memset(covahip_ctx *ctx, void *dev_ptr, int value, size_t bytes);
+
+/* HIP-event timing on the ctx's stream (bench.py's timed region and per-kernel
+ * roofline numbers).  slot in [0, 16). */
+int covahip_timer_start(covahip_ctx *ctx, int slot);
+int covahip_timer_stop(covahip_ctx *ctx, int slot);
+/* Synchronises on the stop event and returns elapsed milliseconds. */
+int covahip_timer_elapsed_ms(covahip_ctx *ctx, int slot, float *ms);
+
+/* Per-kernel profiling: when enabled every kernel launch of blobnet/bboxcc calls is
+ * bracketed by HIP events on the ctx stream; covahip_profile_read then reports the
+ * accumulated time and launch count per kernel name. */
+int covahip_profile_enable(covahip_ctx *ctx, int on);
+int covahip_profile_reset(covahip_ctx *ctx);
+/* Fills up to cap entries; *n gets the number of distinct kernels seen. */
+typedef struct covahip_kernel_time {
+    char name[48];
+    double total_ms;
+    int64_t launches;
+} covahip_kernel_time;
+int covahip_profile_read(covahip_ctx *ctx, covahip_kernel_time *out, int cap, int *n);
+
+/* ------------------------------------------------------------------ BlobNet
+ * Replaces the nvinfer/TensorRT BlobNet engine and its pre/post-processing:
+ *   config/blobnet/amsterdam_b128.txt:1-28 (engine, net-scale-factor 1, RGB planar,
+ *   segmentation threshold 0.5), model/tasks.py:34-55 (fp16 engine, explicit batch),
+ *   utils/model/{blobnet,encoder,decoder,pointwise,preprocessing}.py (the graph), gst-plugins/gst-maskcopy/gstmaskcopy.cpp:226-230
+ *   (class_map + 1 -> GRAY8 {0,1} mask).
+ *
+ * weights: blob in the format of cova_amd/weights.py (64-byte header + fp32 payload).
+ * h_mb x w_mb: macroblock grid (e.g. 68x120 for 1080p, 45x80 for 720p); t must be 4.
+ * max_batch sizes the activation workspace held in HBM by the ctx.               */
+int covahip_blobnet_load(covahip_ctx *ctx, const void *weights, size_t weights_bytes, int h_mb, int w_mb,
+                         int t, int max_batch);
+/* rgba_stack: u8 [batch][t*h_mb][w_mb][4] -- metapreprocess output (row block k =
+ *   frame i-k; byte 0/1/2 = mb_type/mv_x/mv_y, byte 3 ignored).
+ * logits (may be NULL): f32 [batch][h_mb][w_mb] pre-sigmoid output.
+ * mask   (may be NULL): u8  [batch][h_mb][w_mb], 1 where sigmoid(logit) > 0.5.
+ * mem_kind applies to all three pointers.  Asynchronous for device pointers (use
+ * covahip_ctx_sync); synchronous for host pointers.                               */
+int covahip_blobnet_forward(covahip_ctx *ctx, const uint8_t *rgba_stack, int batch, float *logits,
+                            uint8_t *mask, int mem_kind);
+/* Algorithmic MACs per frame of the loaded geometry. */
+int covahip_blobnet_macs_per_frame(covahip_ctx *ctx, int64_t *macs);
+/* Debug switch: 1 = MFMA kernels (default), 0 = direct one-thread-per-output kernels
+ * (on-GPU bring-up path; also selectable with COVAHIP_BLOBNET_IMPL=naive). */
+int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl);
+
+/* ------------------------------------------------------------------- bboxcc
+ * Replaces regionprops() (cova-rs/gst-plugins/src/bboxcc/process.rs:5-49): 8-connected
+ * components with stats on an h x w u8 mask (non-zero = foreground), components in
+ * OpenCV label order, keep pixel-count >= area_thresh.                            */
+typedef struct covahip_box {
+    int32_t left, top, width, height; /* CC_STAT_LEFT/TOP/WIDTH/HEIGHT */
+    int32_t area_px;                  /* CC_STAT_AREA (pixel count)     */
+} covahip_box;
+
+/* mask: u8 [batch][h][w]; boxes: [batch][max_boxes]; counts: i32 [batch] = number of
+ * components that pass the filter (if > max_boxes only the first max_boxes are
+ * written).  mem_kind applies to mask, boxes and counts.                          */
+int covahip_bboxcc(covahip_ctx *ctx, const uint8_t *mask, int batch, int h, int w, int area_thresh,
+                   covahip_box *boxes, int32_t *counts, int max_boxes, int mem_kind);
+
+/* Fused hot path = nvinfer(BlobNet) -> maskcopy -> bboxcc for one batch: the mask
+ * stays on the GPU.  logits/mask may be NULL.                                     */
+int covahip_filter_forward(covahip_ctx *ctx, const uint8_t *rgba_stack, int batch, int area_thresh,
+                           covahip_box *boxes, int32_t *counts, int max_boxes, float *logits,
+                           uint8_t *mask, int mem_kind);
+
+/* --------------------------------------------------------- Bbox wire format
+ * bincode 1.3 (default config) bytes of Vec<Bbox> / Frame as the reference's elements
+ * exchange them (cova-rs/bbox/src/bbox.rs:4-14,84-90; cova-rs/bbox/src/lib.rs:8-22).  */
+typedef struct covahip_bbox {
+    float left, top, width, height, area; /* area = width*height (bbox.rs:23) */
+    uint64_t track_id;                    /* valid iff has_track_id           */
+    uint64_t timestamp;
+    uint32_t class_id;
+    float confidence;
+    uint8_t has_track_id, has_timestamp, has_class_id, has_confidence;
+} covahip_bbox;
+
+/* Bbox::new for each CC box (process.rs:47, bbox.rs:17-29). */
+void covahip_boxes_to_bbox(const covahip_box *in, int n, covahip_bbox *out);
+/* Returns the encoded size; writes only if it fits in cap (else COVAHIP_ERR_OVERFLOW
+ * is reported through *status, which may be NULL). */
+size_t covahip_bbox_serialize_vec(const covahip_bbox *boxes, size_t n, uint8_t *out, size_t cap, int *status);
+/* Decodes up to cap boxes; *n gets the vector length found in the stream. */
+int covahip_bbox_deserialize_vec(const uint8_t *data, size_t len, covahip_bbox *out, size_t cap, size_t *n);
+size_t covahip_frame_serialize(uint64_t range_start, uint64_t oldest, const covahip_bbox *boxes, size_t n,
+                               uint8_t *out, size_t cap, int *status);
+/* Bbox::iou (bbox.rs:39-56). */
+float covahip_bbox_iou(const covahip_bbox *a, const covahip_bbox *b);
+
+/* ------------------------------------------------- metapreprocess stacking
+ * Host state of the `metapreprocess` element (cova-rs/gst-plugins/src/metapreprocess/
+ * imp.rs:204-332): keeps the last timestep-1 inputs, emits one stacked frame every
+ * gamma-th input once warm.                                                       */
+typedef struct covahip_stack covahip_stack;
+/* size_per_buf = out_size / timestep (imp.rs:233) = (W/16)*(H/16)*4 bytes. */
+int covahip_stack_new(size_t size_per_buf, unsigned timestep, unsigned gamma, covahip_stack **out);
+void covahip_stack_free(covahip_stack *s);
+/* in: >= size_per_buf bytes of carrier frame; out: timestep*size_per_buf bytes.
+ * *emitted = 1 if `out` was written (GST_FLOW_OK), 0 if the element would return
+ * BASE_TRANSFORM_FLOW_DROPPED. */
+int covahip_stack_push(covahip_stack *s, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                       int *emitted);
+/* transform_caps arithmetic (imp.rs:262-268): out = (w/16, h/16*timestep). */
+void covahip_stack_out_dims(int width, int height, unsigned timestep, int *out_w, int *out_h);
+
+/* ----------------------------------------------------------------- SORT
+ * Host state of the `sorttracker` element and of cova's embedded tracker
+ * (cova-rs/sort/src/lib.rs:14-214, tracker/mod.rs:15-152, state.rs:9-28).            */
+typedef struct covahip_sort covahip_sort;
+int covahip_sort_new(uint64_t max_age, uint64_t min_hits, float iou_threshold, covahip_sort **out);
+void covahip_sort_free(covahip_sort *s);
+/* Sort::update(dets, pts).  Dead active tracks' histories are appended, flattened in
+ * track order, to dead_boxes (cap entries; *n_dead_boxes = total produced);
+ * track_lens (cap_tracks entries; *n_tracks = number of dead tracks) holds each
+ * track's history length.  Any output pointer may be NULL with cap 0.           */
+int covahip_sort_update(covahip_sort *s, const covahip_bbox *dets, size_t n_dets, uint64_t pts,
+                        covahip_bbox *dead_boxes, size_t cap, size_t *n_dead_boxes, uint32_t *track_lens,
+                        size_t cap_tracks, size_t *n_tracks);
+/* Sort::finalize (lib.rs:207-213): same output convention. */
+int covahip_sort_finalize(covahip_sort *s, covahip_bbox *boxes, size_t cap, size_t *n_boxes,
+                          uint32_t *track_lens, size_t cap_tracks, size_t *n_tracks);
+int covahip_sort_mark_seen(covahip_sort *s, uint64_t ts);          /* lib.rs:189-193 */
+int covahip_sort_num_trackers(const covahip_sort *s, size_t *n);
+/* Introspection for tests: tracker i's id / active flag / hit_streaks / state box. */
+int covahip_sort_tracker_info(const covahip_sort *s, size_t i, uint64_t *id, int *active,
+                              uint64_t *hit_streaks, uint64_t *time_since_update, covahip_bbox *state);
+/* linear_assignment() of lib.rs:25-56 on a column-major n_rows x n_cols f32 cost
+ * matrix; writes (row, col) pairs; returns their number. */
+size_t covahip_linear_assignment(const float *cost_colmajor, size_t n_rows, size_t n_cols, uint32_t *pairs,
+                                 size_t cap_pairs);
+
+/* ------------------------------------------------------------- cova filter
+ * Host state of the `cova` element (cova-rs/gst-plugins/src/cova/imp.rs:90-432,
+ * cova/tracker.rs:16-125): GoP buffering of encoded access units, embedded SORT,
+ * decode/drop decisions and the three read-only counters.                        */
+typedef struct covahip_gopfilter covahip_gopfilter;
+typedef struct covahip_gopfilter_cfg {
+    float sort_iou;        /* "sort-iou"     default 0.1  (imp.rs:22) */
+    uint32_t sort_maxage;  /* "sort-maxage"  default 30   */
+    uint32_t sort_minhits; /* "sort-minhits" default 30   */
+    uint32_t alpha;        /* "alpha"        struct default 0 (imp.rs:28) */
+    uint32_t beta;         /* "beta"         struct default 0 */
+    uint8_t infer_i;       /* "infer-i"      default false */
+} covahip_gopfilter_cfg;
+void covahip_gopfilter_default_cfg(covahip_gopfilter_cfg *cfg);
+int covahip_gopfilter_new(const covahip_gopfilter_cfg *cfg, covahip_gopfilter **out);
+void covahip_gopfilter_free(covahip_gopfilter *g);
+
+enum {
+    COVAHIP_AU_DELTA_UNIT = 1u << 0, /* in:  not a key frame (GST_BUFFER_FLAG_DELTA_UNIT) */
+    COVAHIP_AU_DISCONT = 1u << 1,    /* out: set on the copy of each GoP's key frame       */
+    COVAHIP_AU_DROPPABLE = 1u << 2   /* out: decode for dependency only                    */
+};
+typedef struct covahip_au_out {
+    uint64_t id;    /* caller's handle of the access unit (e.g. GstBuffer*) */
+    uint64_t pts;   /* ns */
+    uint32_t flags; /* COVAHIP_AU_* */
+    uint32_t list;  /* index of the BufferList this AU belongs to (push order) */
+} covahip_au_out;
+
+/* sink_enc chain (imp.rs:320-360). */
+int covahip_gopfilter_push_enc(covahip_gopfilter *g, uint64_t id, uint64_t pts, uint32_t flags);
+/* sink_mask chain (imp.rs:90-317): boxes of the frame at `pts`; forwarded AUs are
+ * appended to out (cap entries, *n_out = number produced).                        */
+int covahip_gopfilter_push_boxes(covahip_gopfilter *g, const covahip_bbox *boxes, size_t n, uint64_t pts,
+                                 covahip_au_out *out, size_t cap, size_t *n_out);
+/* Both-sinks-EOS flush (imp.rs:361-432). */
+int covahip_gopfilter_eos(covahip_gopfilter *g, covahip_au_out *out, size_t cap, size_t *n_out);
+int covahip_gopfilter_counters(const covahip_gopfilter *g, uint64_t *dropped, uint64_t *decoded_dependency,
+                               uint64_t *decoded_inference);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COVAHIP_H */

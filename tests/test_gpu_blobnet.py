@@ -1,0 +1,97 @@
+"""HIP BlobNet vs the fp32 CPU oracle (SURVEY.md §8c tolerances)."""
+import numpy as np
+import pytest
+
+from cova_amd import synth
+from cova_amd.elements import BlobNetInfer
+from oracle import ref
+
+pytestmark = pytest.mark.gpu
+
+# fp16 weights/activations with fp32 accumulation on the GPU vs an all-fp32 oracle:
+ATOL, RTOL = 2e-2, 1e-2
+
+
+def _check(logits, mask, ref_logits):
+    err = np.abs(logits - ref_logits)
+    tol = ATOL + RTOL * np.abs(ref_logits)
+    assert (err <= tol).all(), f"max err {err.max():.4g}, worst excess {(err - tol).max():.4g}"
+    # the mask is the sign of the build's own logits ...
+    np.testing.assert_array_equal(mask, (logits > 0).astype(np.uint8))
+    # ... and may differ from the oracle's mask only where the oracle logit is within tolerance of 0
+    diff = mask != (ref_logits > 0)
+    assert (np.abs(ref_logits[diff]) <= ATOL).all()
+    return float(err.max())
+
+
+@pytest.mark.parametrize("impl", ["naive", "mfma"])
+@pytest.mark.parametrize("hw", [(68, 120), (67, 120), (45, 80)])
+def test_logits_match_oracle(ctx, weights_flat, hw, impl):
+    h, w = hw
+    stack = synth.stacked_batch(3, h, w, seed=11, streams=3)
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=4)
+    net.set_impl(impl)
+    logits, mask = net.infer(stack)
+    ref_logits, _ = ref.blobnet_forward(weights_flat, stack, h, w)
+    _check(logits, mask, ref_logits)
+
+
+def test_alpha_channel_ignored_and_clip(ctx, weights_flat):
+    h, w = 45, 80
+    stack = synth.stacked_batch(2, h, w, seed=5)
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=2)
+    l0, _ = net.infer(stack)
+    s2 = stack.copy()
+    s2[..., 3] = 255 - s2[..., 3]
+    l1, _ = net.infer(s2)
+    np.testing.assert_array_equal(l0, l1)
+    s3 = stack.copy()
+    s3[..., :3] = np.where(s3[..., :3] >= 6, 200, s3[..., :3])   # everything >= 6 clips to 6
+    l2, _ = net.infer(s3)
+    np.testing.assert_array_equal(l0, l2)
+
+
+def test_negative_bn_gamma(ctx):
+    """BN runs after ReLU and before max-pool; a negative gamma must not commute with the max."""
+    from cova_amd import weights as W
+    wts = W.unflatten(W.random_init(77))
+    for i in range(4):
+        g = wts[f"enc{i}.bn.gamma"]
+        g[::2] *= -1.0
+    flat = W.flatten(wts)
+    h, w = 45, 80
+    stack = synth.stacked_batch(2, h, w, seed=21)
+    net = BlobNetInfer(ctx, flat, h, w, max_batch=2)
+    logits, mask = net.infer(stack)
+    ref_logits, _ = ref.blobnet_forward(flat, stack, h, w)
+    _check(logits, mask, ref_logits)
+
+
+def test_batch_independence_and_full_batch(ctx, weights_flat):
+    """b=256 at 68x120 (BASELINE config): frames are independent -> a frame's logits do not
+    depend on its batch position; spot-check a sample of frames against the oracle."""
+    h, w = 68, 120
+    stack = synth.stacked_batch(256, h, w, seed=42, streams=8)
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=256)
+    logits, mask = net.infer(stack)
+    idx = [0, 1, 100, 255]
+    l_small, _ = net.infer(stack[idx])
+    np.testing.assert_array_equal(logits[idx], l_small)
+    ref_logits, _ = ref.blobnet_forward(weights_flat, stack[idx], h, w)
+    _check(logits[idx], mask[idx], ref_logits)
+
+
+def test_fused_filter_matches_separate(ctx, weights_flat):
+    from cova_amd.elements import BboxCc
+    h, w = 68, 120
+    stack = synth.stacked_batch(8, h, w, seed=7, streams=2)
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=8)
+    boxes, counts, mask = net.filter(stack, cc_threshold=1, max_boxes=2048, want_mask=True)
+    rb, rc = ref.regionprops_batch(mask, 1, 2048)
+    np.testing.assert_array_equal(counts, rc)
+    for i in range(8):
+        n = int(counts[i])
+        for f, g in (("left", "left"), ("top", "top"), ("width", "width"), ("height", "height"), ("area_px", "area")):
+            np.testing.assert_array_equal(boxes[i, :n][f], rb[i, :n][g])
+    _, mask2 = net.infer(stack)
+    np.testing.assert_array_equal(mask, mask2)
