@@ -1,0 +1,94 @@
+"""cova GoP frame filter (C++ behind the C-ABI) vs the numpy restatement on scripted timelines."""
+import numpy as np
+import pytest
+
+from cova_amd import _lib as L
+from cova_amd import elements as E
+from oracle import sort_ref as R
+
+CLK = 1_000_000_000 // 30
+
+
+def _bb(rows):
+    out = np.zeros(len(rows), dtype=L.BBOX_DTYPE)
+    for i, r in enumerate(rows):
+        out[i] = E.make_bbox(*r)[0]
+    return out
+
+
+def _timeline(n_frames, gop_len, objects):
+    """objects: list of (first_frame, last_frame, x0, y0, vx, vy, w, h)."""
+    det = []
+    for i in range(n_frames):
+        d = []
+        for (a, b, x0, y0, vx, vy, w, h) in objects:
+            if a <= i <= b:
+                d.append((x0 + vx * (i - a), y0 + vy * (i - a), w, h))
+        det.append(d)
+    return det
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(infer_i=True), dict(alpha=8, beta=3), dict(sort_maxage=5, sort_minhits=3)])
+def test_counters_and_forwarded_aus_match_restatement(cfg):
+    n, gop = 900, 250
+    objects = [(10, 120, 5, 5, 0.4, 0.2, 6, 6), (200, 420, 60, 30, -0.3, 0.0, 8, 5), (300, 330, 20, 20, 0, 0, 4, 4),
+               (500, 800, 10, 40, 0.2, -0.1, 7, 7)]
+    dets = _timeline(n, gop, objects)
+    kw = dict(sort_maxage=10, sort_minhits=5, sort_iou=0.1)
+    kw.update(cfg)
+    c = E.Cova(**kw)
+    r = R.GopFilter(**kw)
+    forwarded = []
+    # encoded AUs run ahead of the mask branch (the enc queue is unbounded in the reference pipeline)
+    lead = 300
+    for i in range(n + lead):
+        if i < n:
+            c.sink_enc_chain(i, i * CLK, delta_unit=(i % gop != 0))
+            r.push_enc(i, i * CLK, 0 if i % gop == 0 else R.DELTA_UNIT)
+        j = i - lead
+        if 0 <= j < n:
+            out = c.sink_mask_chain(E.serialize_vec(_bb(dets[j])), j * CLK)
+            forwarded.extend(out)
+            r.push_boxes([R.Bbox(*d) for d in dets[j]], j * CLK)
+    assert c.eos("sink_enc") is None
+    out = c.eos("sink_mask")
+    forwarded.extend(out)
+    r.eos()
+    assert (c.dropped, c.decoded_dependency, c.decoded_inference) == (r.dropped, r.decoded_dependency,
+                                                                      r.decoded_inference)
+    exp = [b for lst in r.pushed for b in lst]
+    assert [(int(a["id"]), int(a["pts"]), int(a["flags"])) for a in forwarded] == [tuple(b) for b in exp]
+    # grouping into BufferLists is preserved
+    got_lists = {}
+    for a in forwarded:
+        got_lists.setdefault(int(a["list"]), []).append(int(a["id"]))
+    assert list(got_lists.values()) == [[b[0] for b in lst] for lst in r.pushed]
+    assert c.decoded_inference >= 1
+    # every AU is accounted for except those the reference silently discards
+    assert c.dropped + c.decoded_dependency + c.decoded_inference <= n
+
+
+def test_key_frame_gets_discont_and_dependencies_droppable():
+    c = E.Cova(sort_maxage=10, sort_minhits=5)
+    for i in range(600):
+        c.sink_enc_chain(i, i * CLK, delta_unit=(i % 250 != 0))
+    out_all = []
+    for j in range(300):
+        dets = [(10, 10, 5, 5)] if 20 <= j < 60 else []
+        out_all.extend(c.sink_mask_chain(E.serialize_vec(_bb(dets)), j * CLK))
+    c.eos("sink_enc")
+    out_all.extend(c.eos("sink_mask"))
+    ids = [int(a["id"]) for a in out_all]
+    assert ids and ids[0] == 0
+    assert int(out_all[0]["flags"]) & L.AU_DISCONT and int(out_all[0]["flags"]) & L.AU_DROPPABLE
+    last = out_all[-1]
+    assert not int(last["flags"]) & L.AU_DROPPABLE          # the frame kept for inference
+    assert all(int(a["flags"]) & L.AU_DROPPABLE for a in out_all[:-1])
+    assert c.decoded_inference == 1 and c.decoded_dependency == len(out_all) - 1 == 20
+    assert ids == list(range(21))                           # frames 0..19 for dependency, frame 20 inferred
+
+
+def test_delta_unit_before_any_key_frame_is_an_error():
+    c = E.Cova()
+    with pytest.raises(L.CovahipError):
+        c.sink_enc_chain(0, 0, delta_unit=True)
