@@ -1,8 +1,779 @@
-// placeholder until the MFMA kernels land (next commit)
+// BlobNet forward on gfx950 matrix cores (production path).
+//
+// Every convolution is an implicit GEMM on v_mfma_f32_{32x32x16,16x16x32}_f16 with
+//   M = output positions, N = output channels, K = taps x input channels,
+// fp16 operands, fp32 accumulation.  Design (see DESIGN.md for the numbers):
+//   * activations live in HBM as fp16 channels-last tensors, so one MFMA A-fragment
+//     (8 consecutive k = 8 consecutive input channels of one tap) is one 16-byte LDS read;
+//   * a workgroup stages an input band (with halo, zero padded, XOR-swizzled so the
+//     ds_read_b128 lane groups are bank-conflict free) into LDS once and every wave
+//     reads its A fragments from there;
+//   * the weight (B) fragments of a wave's N-tile stay in VGPRs for the whole kernel
+//     (workgroups are persistent and loop over (frame, band) items);
+//   * the M index is laid out as m = 4*window + position so that the four conv outputs
+//     of one 2x2 max-pool window land in the four consecutive accumulator registers of a
+//     lane: bias/ReLU/BN/max-pool, and -- with the four T slices kept in four
+//     accumulators -- the temporal 4->4->4 MLP + residual all run in-register, and only
+//     the pooled tensor (1/4 of the conv output) is written back;
+//   * a transposed convolution (4x4, stride 2) is ONE 2x2-tap convolution over the input
+//     grid whose N axis stacks the four output parities (N = 4*Cout), so the decoder
+//     reuses the same tiling; the last block and the final 1x1 conv have no
+//     non-linearity between them and are folded into a single 32->1 transposed conv that
+//     runs on the vector ALU together with the threshold.
+//
+// Reference semantics: utils/model/{preprocessing,encoder,pointwise,decoder,blobnet}.py
+// (see oracle/blobnet_ref.c for the line-by-line citations).
+#include <cmath>
+#include <cstring>
+#include <vector>
+
 #include "blobnet.h"
-int blobnet_prepare_mfma(covahip_ctx *, covahip_blobnet *, const float *) { return COVAHIP_OK; }
-void blobnet_release_mfma(covahip_ctx *, covahip_blobnet *) {}
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr float BN_EPS = 1e-3f;
+constexpr int WG = 256;  // 4 waves
+
+// ------------------------------------------------------------------ prepared weights
+struct EncPrep {
+    size_t wfrag;  // byte offset of the B fragments: [NT][KSTEPS][64 lanes] x half8
+    size_t epi;    // byte offset of fp32 epilogue constants: bias[C], scale[C], shift[C], w1[16], w2[16]
+};
+struct DecPrep {
+    size_t wfrag;  // [NTT][KSTEPS][64] x half8
+    size_t epi;    // bias[C], scale[C], shift[C]
+};
+
+}  // namespace
+
+struct Prepared {
+    EncPrep enc[BN_LEVELS];
+    DecPrep dec[BN_LEVELS - 1];
+    size_t final_w;  // fp32 [4][4][32] folded (convT 32->16) x (1x1 16->1) weights, then folded bias
+    size_t total;
+};
+
+namespace {
+
+inline _Float16 f2h(float v) { return (_Float16)v; }
+
+// ------------------------------------------------------------------ geometry structs
+struct Enc0Args {
+    const uint8_t *in;  // [B][T][H][W][4]
+    __half *out;        // [B][T][Ho][Wo][16]
+    const half8 *wfrag;
+    const float *epi;
+    int B, H, W, Hp, Wp, Ho, Wo, oy, ox;
+    int RB, nbands, TR, TC;
+};
+
+struct EncArgs {
+    const __half *in;  // [B][T][H][W][CIN]
+    __half *out;       // [B][To][Ho][Wo][COUT]
+    const half8 *wfrag;
+    const float *epi;
+    int B, H, W, Hp, Wp, Ho, Wo, oy, ox, To;
+    int RB, nbands, TR, TC;
+};
+
+struct DecArgs {
+    const __half *up;    // [B][Hi][Wi][C1] or null
+    const __half *skip;  // [B][Ts][Hi][Wi][C2], t = 0 used
+    __half *out;         // [B][Hd][Wd][COUT]
+    const half8 *wfrag;
+    const float *epi;
+    int B, Hi, Wi, Hd, Wd, cy, cx, Ts;
+    int FPI;  // frames per work item
+};
+
+struct FinalArgs {
+    const __half *up;    // [B][Hi][Wi][16]
+    const __half *skip;  // [B][T][Hi][Wi][16], t = 0
+    const float *wf;     // [4][4][32] + bias
+    float *logits;       // [B][Hd][Wd] or null
+    uint8_t *mask;       // [B][Hd][Wd] or null
+    int B, Hi, Wi, Hd, Wd, cy, cx;
+};
+
+// ------------------------------------------------------------------ enc level 0
+// u8 RGBA stack -> conv3x3 (3->16) on v_mfma_f32_16x16x32_f16.
+// K layout: one K-step = 2 kernel rows x (4 pixels x 4 channels); pixel 3 and channel 3
+// carry zero weights, the 1/6 of clip(x,0,6)/6 is folded into the weights, so the LDS tile
+// holds min(x,6) as exact small integers in fp16, 8 bytes per macroblock.
+__global__ __launch_bounds__(WG) void enc0_mfma(Enc0Args p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int TR = p.TR, TC = p.TC;
+    const int tsz = TR * TC * 8;  // bytes per T slice
+
+    const half8 b0 = p.wfrag[lane], b1 = p.wfrag[64 + lane];
+    const int co = lane & 15;
+    const float bias = p.epi[co], scale = p.epi[16 + co], shift = p.epi[32 + co];
+    float w1[16], w2[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        w1[i] = p.epi[48 + i];
+        w2[i] = p.epi[64 + i];
+    }
+
+    const int n_items = p.B * p.nbands;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int b = item / p.nbands, band = item - b * p.nbands;
+        const int y0 = band * p.RB;
+        const int rows = min(p.RB, 2 * p.Hp - y0);
+        __syncthreads();
+        // ---- stage: tile row r <-> input row y0-1+r, tile col c <-> input col c-1
+        const int npix = BN_T * (rows + 2) * TC;
+        for (int i = tid; i < npix; i += WG) {
+            const int t = i / ((rows + 2) * TC);
+            const int rem = i - t * (rows + 2) * TC;
+            const int r = rem / TC, c = rem - r * TC;
+            const int y = y0 - 1 + r, x = c - 1;
+            half4 v = {0, 0, 0, 0};
+            if (y >= 0 && y < p.H && x >= 0 && x < p.W) {
+                const uint32_t px = *reinterpret_cast<const uint32_t *>(
+                    p.in + ((((size_t)b * BN_T + t) * p.H + y) * p.W + x) * 4);
+                v[0] = (_Float16)(float)min(px & 0xFF, 6u);
+                v[1] = (_Float16)(float)min((px >> 8) & 0xFF, 6u);
+                v[2] = (_Float16)(float)min((px >> 16) & 0xFF, 6u);
+            }
+            *reinterpret_cast<half4 *>(smem + t * tsz + (r * TC + c) * 8) = v;
+        }
+        __syncthreads();
+        // ---- compute: M-tile = 4 pool windows (16 conv pixels), all 4 T
+        const int nwin = (rows / 2) * p.Wp;
+        const int ntiles = (nwin + 3) / 4;
+        const int m = lane & 15, g = lane >> 4;
+        for (int tile = wave; tile < ntiles; tile += WG / 64) {
+            const int win = min(tile * 4 + (m >> 2), nwin - 1);
+            const int wy = win / p.Wp, wx = win - wy * p.Wp;
+            const int yy = 2 * wy + ((m >> 1) & 1), xx = 2 * wx + (m & 1);
+            // K-step 0: kernel rows 0/1 (g>>1), pixel pair g&1; K-step 1: kernel row 2 (g>>1 == 0)
+            const int off0 = ((yy + (g >> 1)) * TC + xx + 2 * (g & 1)) * 8;
+            const int off1 = ((yy + 2) * TC + xx + 2 * (g & 1)) * 8;
+            f32x4 acc[BN_T];
+#pragma unroll
+            for (int t = 0; t < BN_T; t++) {
+                const uint8_t *base = smem + t * tsz;
+                half8 a0, a1;
+                const half4 l0 = *reinterpret_cast<const half4 *>(base + off0);
+                const half4 h0 = *reinterpret_cast<const half4 *>(base + off0 + 8);
+                const half4 l1 = *reinterpret_cast<const half4 *>(base + off1);
+                const half4 h1 = *reinterpret_cast<const half4 *>(base + off1 + 8);
+                a0 = __builtin_shufflevector(l0, h0, 0, 1, 2, 3, 4, 5, 6, 7);
+                a1 = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                f32x4 c = {bias, bias, bias, bias};
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, c, 0, 0, 0);
+                acc[t] = c;
+            }
+            // ---- epilogue: D rows 4*(lane>>4)+r = window (lane>>4), position r
+            float pooled[BN_T];
+#pragma unroll
+            for (int t = 0; t < BN_T; t++) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 4; r++) mx = fmaxf(mx, fmaxf(acc[t][r], 0.f) * scale + shift);
+                pooled[t] = mx;
+            }
+            float u[BN_T], v[BN_T];
+#pragma unroll
+            for (int j = 0; j < BN_T; j++) {
+                float a = 0.f;
+#pragma unroll
+                for (int t = 0; t < BN_T; t++) a += w1[t * BN_T + j] * pooled[t];
+                u[j] = fmaxf(a, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < BN_T; j++) {
+                float a = 0.f;
+#pragma unroll
+                for (int t = 0; t < BN_T; t++) a += w2[t * BN_T + j] * u[t];
+                v[j] = fmaxf(a, 0.f);
+            }
+            const int owin = tile * 4 + g;
+            if (owin < nwin) {
+                const int owy = owin / p.Wp, owx = owin - owy * p.Wp;
+                const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
+#pragma unroll
+                for (int t = 0; t < BN_T; t++) {
+                    const float o = fmaxf(v[t] + pooled[t], 0.f);
+                    p.out[((((size_t)b * BN_T + t) * p.Ho + gy) * p.Wo + gx) * 16 + co] = __float2half(o);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ enc levels 1..3
+// conv3x3 CIN -> COUT on v_mfma_f32_32x32x16_f16.  Wave roles: N-tile = wave % NT,
+// M-group = wave / NT.  One K-step = one tap x 16 input channels.
+template <int CIN>
+__device__ __forceinline__ int enc_swz(int xx, int yy) {
+    constexpr int CPP = CIN / 8;   // 16-byte chunks per pixel
+    constexpr int XS = 16 / CPP;
+    return ((xx / XS) % (CPP / 2)) | ((yy & 1) * (CPP / 2));
+}
+
+template <int CIN, int COUT, int TPAR, int OCC>
+__global__ __launch_bounds__(WG, OCC) void enc_mfma(EncArgs p) {
+    constexpr int NT = COUT / 32, MG = (WG / 64) / NT, KC = CIN / 16, KSTEPS = 9 * KC;
+    constexpr int CPP = CIN / 8, PS = CIN * 2;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntile = wave % NT, mgroup = wave / NT;
+    const int TR = p.TR, TC = p.TC;
+    const int tsz = TR * TC * PS;
+
+    half8 bf[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++) bf[ks] = p.wfrag[(ntile * KSTEPS + ks) * 64 + lane];
+    const int co = ntile * 32 + (lane & 31);
+    const float bias = p.epi[co], scale = p.epi[COUT + co], shift = p.epi[2 * COUT + co];
+    const float *tm = p.epi + 3 * COUT;
+
+    const int n_items = p.B * p.nbands;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int b = item / p.nbands, band = item - b * p.nbands;
+        const int y0 = band * p.RB;
+        const int rows = min(p.RB, 2 * p.Hp - y0);
+        __syncthreads();
+        // ---- stage the band (all T) into LDS, 16 bytes per work item, swizzled
+        const int nchunks = BN_T * (rows + 2) * TC * CPP;
+        for (int i = tid; i < nchunks; i += WG) {
+            const int ch = i % CPP;
+            const int pix = i / CPP;
+            const int t = pix / ((rows + 2) * TC);
+            const int rem = pix - t * (rows + 2) * TC;
+            const int r = rem / TC, c = rem - r * TC;
+            const int y = y0 - 1 + r, x = c - 1;
+            uint4 v = {0, 0, 0, 0};
+            if (y >= 0 && y < p.H && x >= 0 && x < p.W)
+                v = *reinterpret_cast<const uint4 *>(
+                    p.in + ((((size_t)b * BN_T + t) * p.H + y) * p.W + x) * CIN + ch * 8);
+            const int sw = ch ^ enc_swz<CIN>(c, r);
+            *reinterpret_cast<uint4 *>(smem + t * tsz + (r * TC + c) * PS + sw * 16) = v;
+        }
+        __syncthreads();
+        // ---- compute
+        const int nwin = (rows / 2) * p.Wp;
+        const int ntiles = (nwin + 7) / 8;
+        const int m = lane & 31, kh = lane >> 5;
+        for (int tile = mgroup; tile < ntiles; tile += MG) {
+            const int win = min(tile * 8 + (m >> 2), nwin - 1);
+            const int wy = win / p.Wp, wx = win - wy * p.Wp;
+            const int yy0 = 2 * wy + ((m >> 1) & 1), xx0 = 2 * wx + (m & 1);
+            // TPAR T-slices are accumulated at a time (register budget); the pooled values of all
+            // four slices are kept for the temporal MLP.
+            float pooled4[BN_T][4];
+#pragma unroll
+            for (int t0 = 0; t0 < BN_T; t0 += TPAR) {
+                f32x16 acc[TPAR];
+#pragma unroll
+                for (int t = 0; t < TPAR; t++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[t][r] = bias;
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++) {
+                        const int yy = yy0 + ky, xx = xx0 + kx;
+                        const int pbase = (yy * TC + xx) * PS;
+                        const int s = enc_swz<CIN>(xx, yy);
+#pragma unroll
+                        for (int kc = 0; kc < KC; kc++) {
+                            const int off = pbase + (((kc * 2 + kh) ^ s) * 16);
+#pragma unroll
+                            for (int t = 0; t < TPAR; t++) {
+                                const half8 a = *reinterpret_cast<const half8 *>(smem + (t0 + t) * tsz + off);
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[(ky * 3 + kx) * KC + kc], acc[t],
+                                                                                0, 0, 0);
+                            }
+                        }
+                    }
+                // reg r -> row (r&3) + 8*(r>>2) + 4*kh -> window 2*(r>>2)+kh, position r&3
+#pragma unroll
+                for (int t = 0; t < TPAR; t++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        float mx = -INFINITY;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) mx = fmaxf(mx, fmaxf(acc[t][4 * g + q], 0.f) * scale + shift);
+                        pooled4[t0 + t][g] = mx;
+                    }
+            }
+            // ---- epilogue: temporal MLP + residual per pooled window, then store
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float pooled[BN_T];
+#pragma unroll
+                for (int t = 0; t < BN_T; t++) pooled[t] = pooled4[t][g];
+                float u[BN_T], v[BN_T];
+#pragma unroll
+                for (int j = 0; j < BN_T; j++) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int t = 0; t < BN_T; t++) a += tm[t * BN_T + j] * pooled[t];
+                    u[j] = fmaxf(a, 0.f);
+                }
+#pragma unroll
+                for (int j = 0; j < BN_T; j++) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int t = 0; t < BN_T; t++) a += tm[16 + t * BN_T + j] * u[t];
+                    v[j] = fmaxf(a, 0.f);
+                }
+                const int owin = tile * 8 + 2 * g + kh;
+                if (owin < nwin) {
+                    const int owy = owin / p.Wp, owx = owin - owy * p.Wp;
+                    const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
+#pragma unroll
+                    for (int t = 0; t < BN_T; t++)
+                        if (t < p.To) {
+                            const float o = fmaxf(v[t] + pooled[t], 0.f);
+                            p.out[((((size_t)b * p.To + t) * p.Ho + gy) * p.Wo + gx) * COUT + co] = __float2half(o);
+                        }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ decoder blocks 0..2
+// relu -> convT(4x4, s2) -> crop -> BN as a 2x2-tap convolution over the (Hi+1)x(Wi+1)
+// grid with N = 4 parities x COUT.
+template <int C>
+__device__ __forceinline__ int dec_swz(int xx) {
+    constexpr int CPP = C / 8;
+    return (xx / (16 / CPP)) % CPP;
+}
+
+template <int C1, int C2, int COUT>
+__global__ __launch_bounds__((4 * COUT / 32 > 4 ? 4 * COUT / 32 : 4) * 64, 2) void dec_mfma(DecArgs p) {
+    constexpr int C = C1 + C2, NTT = 4 * COUT / 32, NW = NTT > 4 ? NTT : 4, MG = NW / NTT;
+    constexpr int KC = C / 16, KSTEPS = 4 * KC, CPP = C / 8, PS = C * 2, NTHREADS = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntile = wave % NTT, mgroup = wave / NTT;
+    const int TR = p.Hi + 2, TC = p.Wi + 2;
+    const int fsz = TR * TC * PS;  // bytes per frame tile
+    const int GW = p.Wi + 1, G = (p.Hi + 1) * GW;
+
+    half8 bf[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++) bf[ks] = p.wfrag[(ntile * KSTEPS + ks) * 64 + lane];
+    const int n = ntile * 32 + (lane & 31);
+    const int phase = n / COUT, co = n % COUT, py = phase >> 1, px = phase & 1;
+    const float bias = p.epi[co], scale = p.epi[COUT + co], shift = p.epi[2 * COUT + co];
+
+    const int n_items = (p.B + p.FPI - 1) / p.FPI;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int b0 = item * p.FPI;
+        const int nf = min(p.FPI, p.B - b0);
+        __syncthreads();
+        // ---- stage nf frames: concat(relu(up), relu(skip[t=0])) with a zero border
+        const int nchunks = nf * TR * TC * CPP;
+        for (int i = tid; i < nchunks; i += NTHREADS) {
+            const int ch = i % CPP;
+            const int pix = i / CPP;
+            const int f = pix / (TR * TC);
+            const int rem = pix - f * TR * TC;
+            const int r = rem / TC, c = rem - r * TC;
+            const int y = r - 1, x = c - 1;
+            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (y >= 0 && y < p.Hi && x >= 0 && x < p.Wi) {
+                const int cb = ch * 8;
+                const __half *src;
+                if (cb < C1)
+                    src = p.up + ((((size_t)(b0 + f)) * p.Hi + y) * p.Wi + x) * C1 + cb;
+                else
+                    src = p.skip + ((((size_t)(b0 + f) * p.Ts) * p.Hi + y) * p.Wi + x) * C2 + (cb - C1);
+                v = *reinterpret_cast<const half8 *>(src);
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = v[j] > (_Float16)0 ? v[j] : (_Float16)0;
+            }
+            const int sw = ch ^ dec_swz<C>(c);
+            *reinterpret_cast<half8 *>(smem + f * fsz + (r * TC + c) * PS + sw * 16) = v;
+        }
+        __syncthreads();
+        // ---- compute over the flattened (frame, u, v) positions
+        const int npos = nf * G;
+        const int ntiles = (npos + 31) / 32;
+        const int m = lane & 31, kh = lane >> 5;
+        for (int tile = mgroup; tile < ntiles; tile += MG) {
+            const int q = min(tile * 32 + m, npos - 1);
+            const int f = q / G, qq = q - f * G;
+            const int u = qq / GW, v = qq - u * GW;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = bias;
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int bb = 0; bb < 2; bb++) {
+                    const int yy = u - a + 1, xx = v - bb + 1;
+                    const int pbase = f * fsz + (yy * TC + xx) * PS;
+                    const int s = dec_swz<C>(xx);
+#pragma unroll
+                    for (int kc = 0; kc < KC; kc++) {
+                        const half8 av = *reinterpret_cast<const half8 *>(smem + pbase + (((kc * 2 + kh) ^ s) * 16));
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bf[(a * 2 + bb) * KC + kc], acc, 0, 0, 0);
+                    }
+                }
+            // ---- epilogue: row = (r&3) + 8*(r>>2) + 4*kh
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int oq = tile * 32 + row;
+                if (oq < npos) {
+                    const int of = oq / G, oqq = oq - of * G;
+                    const int ou = oqq / GW, ov = oqq - ou * GW;
+                    const int Y = 2 * ou + py - p.cy, X = 2 * ov + px - p.cx;
+                    if (Y >= 0 && Y < p.Hd && X >= 0 && X < p.Wd)
+                        p.out[((((size_t)(b0 + of)) * p.Hd + Y) * p.Wd + X) * COUT + co] =
+                            __float2half(acc[r] * scale + shift);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ last block + final 1x1 + threshold
+// One thread per position (u,v) of the (Hi+1)x(Wi+1) grid: reads the 2x2 input
+// neighbourhood once and produces the four output parities (vector ALU, fp32).
+__global__ __launch_bounds__(256) void final_kernel(FinalArgs p) {
+    const int GW = p.Wi + 1, G = (p.Hi + 1) * GW;
+    const long long total = (long long)p.B * G;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int b = (int)(gid / G);
+    const int qq = (int)(gid - (long long)b * G);
+    const int u = qq / GW, v = qq - u * GW;
+    float acc[4];
+    const float fb = p.wf[512];
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc[k] = fb;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int bb = 0; bb < 2; bb++) {
+            const int iy = u - a, ix = v - bb;
+            if (iy < 0 || iy >= p.Hi || ix < 0 || ix >= p.Wi) continue;
+            const half8 *pu = reinterpret_cast<const half8 *>(p.up + (((size_t)b * p.Hi + iy) * p.Wi + ix) * 16);
+            const half8 *ps =
+                reinterpret_cast<const half8 *>(p.skip + ((((size_t)b * BN_T) * p.Hi + iy) * p.Wi + ix) * 16);
+            float x[32];
+            const half8 v0 = pu[0], v1 = pu[1], v2 = ps[0], v3 = ps[1];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                x[j] = fmaxf((float)v0[j], 0.f);
+                x[8 + j] = fmaxf((float)v1[j], 0.f);
+                x[16 + j] = fmaxf((float)v2[j], 0.f);
+                x[24 + j] = fmaxf((float)v3[j], 0.f);
+            }
+#pragma unroll
+            for (int py = 0; py < 2; py++)
+#pragma unroll
+                for (int px = 0; px < 2; px++) {
+                    const float *w = p.wf + ((py + 2 * a) * 4 + (px + 2 * bb)) * 32;
+                    float s = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 32; c++) s += w[c] * x[c];
+                    acc[py * 2 + px] += s;
+                }
+        }
+#pragma unroll
+    for (int py = 0; py < 2; py++)
+#pragma unroll
+        for (int px = 0; px < 2; px++) {
+            const int Y = 2 * u + py - p.cy, X = 2 * v + px - p.cx;
+            if (Y >= 0 && Y < p.Hd && X >= 0 && X < p.Wd) {
+                const size_t o = ((size_t)b * p.Hd + Y) * p.Wd + X;
+                const float l = acc[py * 2 + px];
+                if (p.logits) p.logits[o] = l;
+                if (p.mask) p.mask[o] = l > 0.f ? 1 : 0;
+            }
+        }
+}
+
+// ------------------------------------------------------------------ host-side weight preparation
+void prep_enc0(const float *k, const float *bias, const float *gamma, const float *beta, const float *mean,
+               const float *var, const float *w1, const float *w2, _Float16 *wfrag, float *epi) {
+    // 16x16x32 B fragment: lane l: n = l&15, k = 8*(l>>4)+j.  k <-> (kernel row, pixel, channel)
+    for (int ks = 0; ks < 2; ks++)
+        for (int l = 0; l < 64; l++)
+            for (int j = 0; j < 8; j++) {
+                const int n = l & 15, g = l >> 4;
+                const int px = 2 * (g & 1) + (j >> 2), ch = j & 3;
+                int ky = -1;
+                if (ks == 0) ky = g >> 1;
+                else if ((g >> 1) == 0) ky = 2;
+                float w = 0.f;
+                if (ky >= 0 && px < 3 && ch < 3) w = k[((ky * 3 + px) * 3 + ch) * 16 + n] / 6.0f;
+                wfrag[(ks * 64 + l) * 8 + j] = f2h(w);
+            }
+    for (int c = 0; c < 16; c++) {
+        const float sc = gamma[c] / std::sqrt(var[c] + BN_EPS);
+        epi[c] = bias[c];
+        epi[16 + c] = sc;
+        epi[32 + c] = beta[c] - mean[c] * sc;
+    }
+    std::memcpy(epi + 48, w1, 16 * sizeof(float));
+    std::memcpy(epi + 64, w2, 16 * sizeof(float));
+}
+
+void prep_enc(int cin, int cout, const float *k, const float *bias, const float *gamma, const float *beta,
+              const float *mean, const float *var, const float *w1, const float *w2, _Float16 *wfrag, float *epi) {
+    const int NT = cout / 32, KC = cin / 16, KSTEPS = 9 * KC;
+    // 32x32x16 B fragment: lane l: n = l&31, k = 8*(l>>5)+j
+    for (int nt = 0; nt < NT; nt++)
+        for (int ks = 0; ks < KSTEPS; ks++)
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 8; j++) {
+                    const int tap = ks / KC, kc = ks % KC;
+                    const int c = kc * 16 + 8 * (l >> 5) + j, n = nt * 32 + (l & 31);
+                    wfrag[(((size_t)nt * KSTEPS + ks) * 64 + l) * 8 + j] = f2h(k[((size_t)tap * cin + c) * cout + n]);
+                }
+    for (int c = 0; c < cout; c++) {
+        const float sc = gamma[c] / std::sqrt(var[c] + BN_EPS);
+        epi[c] = bias[c];
+        epi[cout + c] = sc;
+        epi[2 * cout + c] = beta[c] - mean[c] * sc;
+    }
+    std::memcpy(epi + 3 * cout, w1, 16 * sizeof(float));
+    std::memcpy(epi + 3 * cout + 16, w2, 16 * sizeof(float));
+}
+
+void prep_dec(int cin, int cout, const float *k, const float *bias, const float *gamma, const float *beta,
+              const float *mean, const float *var, _Float16 *wfrag, float *epi) {
+    const int NTT = 4 * cout / 32, KC = cin / 16, KSTEPS = 4 * KC;
+    for (int nt = 0; nt < NTT; nt++)
+        for (int ks = 0; ks < KSTEPS; ks++)
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 8; j++) {
+                    const int tap = ks / KC, kc = ks % KC, a = tap >> 1, bb = tap & 1;
+                    const int c = kc * 16 + 8 * (l >> 5) + j, n = nt * 32 + (l & 31);
+                    const int phase = n / cout, co = n % cout, py = phase >> 1, px = phase & 1;
+                    const int ky = py + 2 * a, kx = px + 2 * bb;
+                    wfrag[(((size_t)nt * KSTEPS + ks) * 64 + l) * 8 + j] =
+                        f2h(k[(((size_t)ky * 4 + kx) * cout + co) * cin + c]);
+                }
+    for (int c = 0; c < cout; c++) {
+        const float sc = gamma[c] / std::sqrt(var[c] + BN_EPS);
+        epi[c] = bias[c];
+        epi[cout + c] = sc;
+        epi[2 * cout + c] = beta[c] - mean[c] * sc;
+    }
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+template <typename K>
+int set_lds(covahip_ctx *ctx, K kernel, size_t lds) {
+    if (lds > 64 * 1024)
+        COVAHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return COVAHIP_OK;
+}
+
+}  // namespace
+
+int blobnet_prepare_mfma(covahip_ctx *ctx, covahip_blobnet *m, const float *w) {
+    // host view of the parameter blob (same order as bind_params in blobnet.hip)
+    struct HE { const float *k, *b, *gamma, *beta, *mean, *var, *w1, *w2; } he[BN_LEVELS];
+    struct HD { const float *k, *b, *gamma, *beta, *mean, *var; } hd[BN_LEVELS];
+    const float *p = w;
+    for (int i = 0; i < BN_LEVELS; i++) {
+        const int ci = m->enc_c[i], co = m->enc_c[i + 1];
+        he[i].k = p; p += 9 * ci * co;
+        he[i].b = p; p += co;
+        he[i].gamma = p; p += co;
+        he[i].beta = p; p += co;
+        he[i].mean = p; p += co;
+        he[i].var = p; p += co;
+        he[i].w1 = p; p += 16;
+        he[i].w2 = p; p += 16;
+    }
+    for (int j = 0; j < BN_LEVELS; j++) {
+        const int ci = m->dec_ci[j], co = m->dec_co[j];
+        hd[j].k = p; p += 16 * ci * co;
+        hd[j].b = p; p += co;
+        if (j < BN_LEVELS - 1) {
+            hd[j].gamma = p; p += co;
+            hd[j].beta = p; p += co;
+            hd[j].mean = p; p += co;
+            hd[j].var = p; p += co;
+        }
+    }
+    const float *fk = p, *fb = p + 16;
+
+    Prepared *pr = new Prepared();
+    size_t off = 0;
+    for (int i = 0; i < BN_LEVELS; i++) {
+        const int ci = m->enc_c[i], co = m->enc_c[i + 1];
+        const size_t nfrag = (i == 0) ? 2 * 64 : (size_t)(co / 32) * (9 * ci / 16) * 64;
+        pr->enc[i].wfrag = off; off = align256(off + nfrag * 16);
+        pr->enc[i].epi = off; off = align256(off + (3 * co + 32) * sizeof(float));
+    }
+    for (int j = 0; j < BN_LEVELS - 1; j++) {
+        const int ci = m->dec_ci[j], co = m->dec_co[j];
+        const size_t nfrag = (size_t)(4 * co / 32) * (4 * ci / 16) * 64;
+        pr->dec[j].wfrag = off; off = align256(off + nfrag * 16);
+        pr->dec[j].epi = off; off = align256(off + 3 * co * sizeof(float));
+    }
+    pr->final_w = off; off = align256(off + 513 * sizeof(float));
+    pr->total = off;
+
+    std::vector<uint8_t> host(off, 0);
+    prep_enc0(he[0].k, he[0].b, he[0].gamma, he[0].beta, he[0].mean, he[0].var, he[0].w1, he[0].w2,
+              (_Float16 *)(host.data() + pr->enc[0].wfrag), (float *)(host.data() + pr->enc[0].epi));
+    for (int i = 1; i < BN_LEVELS; i++)
+        prep_enc(m->enc_c[i], m->enc_c[i + 1], he[i].k, he[i].b, he[i].gamma, he[i].beta, he[i].mean, he[i].var,
+                 he[i].w1, he[i].w2, (_Float16 *)(host.data() + pr->enc[i].wfrag),
+                 (float *)(host.data() + pr->enc[i].epi));
+    for (int j = 0; j < BN_LEVELS - 1; j++)
+        prep_dec(m->dec_ci[j], m->dec_co[j], hd[j].k, hd[j].b, hd[j].gamma, hd[j].beta, hd[j].mean, hd[j].var,
+                 (_Float16 *)(host.data() + pr->dec[j].wfrag), (float *)(host.data() + pr->dec[j].epi));
+    {   // fold: logit = sum_c fk[c] * (convT_c(x) + b_c) + fb
+        float *wf = (float *)(host.data() + pr->final_w);
+        const int ci = m->dec_ci[3], co = m->dec_co[3];
+        for (int ky = 0; ky < 4; ky++)
+            for (int kx = 0; kx < 4; kx++)
+                for (int c = 0; c < ci; c++) {
+                    double s = 0.0;
+                    for (int o = 0; o < co; o++) s += (double)fk[o] * hd[3].k[(((size_t)ky * 4 + kx) * co + o) * ci + c];
+                    wf[(ky * 4 + kx) * 32 + c] = (float)s;
+                }
+        double bsum = fb[0];
+        for (int o = 0; o < co; o++) bsum += (double)fk[o] * hd[3].b[o];
+        wf[512] = (float)bsum;
+    }
+    COVAHIP_CHECK_HIP(ctx, hipMalloc(&m->d_prepared, off));
+    COVAHIP_CHECK_HIP(ctx, hipMemcpy(m->d_prepared, host.data(), off, hipMemcpyHostToDevice));
+    m->prepared_bytes = off;
+    m->prep = pr;
+    return COVAHIP_OK;
+}
+
+void blobnet_release_mfma(covahip_ctx *, covahip_blobnet *m) {
+    if (m->d_prepared) hipFree(m->d_prepared);
+    m->d_prepared = nullptr;
+    delete m->prep;
+    m->prep = nullptr;
+}
+
 int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_stack, int batch, float *d_logits,
                          uint8_t *d_mask) {
-    return blobnet_forward_naive(ctx, m, d_stack, batch, d_logits, d_mask);
+    const uint8_t *prep = (const uint8_t *)m->d_prepared;
+    const Prepared *pr = m->prep;
+    const int num_cu = ctx->props.multiProcessorCount;
+
+    // ---------------- encoder
+    for (int i = 0; i < BN_LEVELS; i++) {
+        const int H = m->lv[i].H, W = m->lv[i].W, Hp = H / 2, Wp = W / 2;
+        const int cin = m->enc_c[i];
+        const size_t px_bytes = (i == 0) ? 8 : (size_t)cin * 2;
+        // enc0 keeps one extra zero column: its K layout reads a 4th (zero-weight) pixel per tap row
+        const int TC = (i == 0) ? W + 3 : W + 2;
+        // band height: largest even RB whose tile (RB+2 rows, all T) fits in ~78 KB of LDS
+        // (two workgroups per CU; the 64->128 level keeps 144 weight VGPRs per wave and runs one
+        //  workgroup per CU with up to 150 KB)
+        const size_t lds_cap = (i == BN_LEVELS - 1) ? 150 * 1024 : 78 * 1024;
+        int RB = 2 * Hp;
+        while (RB > 2 && (size_t)BN_T * (RB + 2) * TC * px_bytes > lds_cap) RB -= 2;
+        const int nbands = (2 * Hp + RB - 1) / RB;
+        const size_t lds = (size_t)BN_T * (RB + 2) * TC * px_bytes;
+        if (lds > 160 * 1024 - 256) return COVAHIP_ERR_UNSUPPORTED;
+        const int items = batch * nbands;
+        const int grid = std::min(items, (i == BN_LEVELS - 1 ? 1 : 2) * num_cu);
+        if (i == 0) {
+            Enc0Args a;
+            a.in = d_stack; a.out = m->act[1];
+            a.wfrag = (const half8 *)(prep + pr->enc[0].wfrag); a.epi = (const float *)(prep + pr->enc[0].epi);
+            a.B = batch; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.Ho = m->lv[1].H; a.Wo = m->lv[1].W;
+            a.oy = H & 1; a.ox = W & 1; a.RB = RB; a.nbands = nbands; a.TR = RB + 2; a.TC = TC;
+            int rc = set_lds(ctx, enc0_mfma, lds);
+            if (rc) return rc;
+            ProfScope ps(ctx, "enc0_mfma");
+            hipLaunchKernelGGL(enc0_mfma, dim3(grid), dim3(WG), lds, ctx->stream, a);
+        } else {
+            EncArgs a;
+            a.in = m->act[i]; a.out = m->act[i + 1];
+            a.wfrag = (const half8 *)(prep + pr->enc[i].wfrag); a.epi = (const float *)(prep + pr->enc[i].epi);
+            a.B = batch; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.Ho = m->lv[i + 1].H; a.Wo = m->lv[i + 1].W;
+            a.oy = H & 1; a.ox = W & 1; a.To = (i == BN_LEVELS - 1) ? 1 : BN_T;
+            a.RB = RB; a.nbands = nbands; a.TR = RB + 2; a.TC = TC;
+            int rc = COVAHIP_OK;
+            if (i == 1) {
+                rc = set_lds(ctx, enc_mfma<16, 32, 4, 2>, lds);
+                if (rc) return rc;
+                ProfScope ps(ctx, "enc1_mfma");
+                hipLaunchKernelGGL((enc_mfma<16, 32, 4, 2>), dim3(grid), dim3(WG), lds, ctx->stream, a);
+            } else if (i == 2) {
+                rc = set_lds(ctx, enc_mfma<32, 64, 4, 2>, lds);
+                if (rc) return rc;
+                ProfScope ps(ctx, "enc2_mfma");
+                hipLaunchKernelGGL((enc_mfma<32, 64, 4, 2>), dim3(grid), dim3(WG), lds, ctx->stream, a);
+            } else {
+                rc = set_lds(ctx, enc_mfma<64, 128, 4, 1>, lds);
+                if (rc) return rc;
+                ProfScope ps(ctx, "enc3_mfma");
+                hipLaunchKernelGGL((enc_mfma<64, 128, 4, 1>), dim3(grid), dim3(WG), lds, ctx->stream, a);
+            }
+        }
+        COVAHIP_CHECK_HIP(ctx, hipGetLastError());
+    }
+    // ---------------- decoder blocks 0..2
+    for (int j = 0; j < BN_LEVELS - 1; j++) {
+        const BnLevelGeom in = m->lv[BN_LEVELS - j], out = m->lv[BN_LEVELS - 1 - j];
+        DecArgs a;
+        a.up = j == 0 ? nullptr : m->dact[j - 1];
+        a.skip = m->act[BN_LEVELS - j];
+        a.out = m->dact[j];
+        a.wfrag = (const half8 *)(prep + pr->dec[j].wfrag); a.epi = (const float *)(prep + pr->dec[j].epi);
+        a.B = batch; a.Hi = in.H; a.Wi = in.W; a.Hd = out.H; a.Wd = out.W; a.cy = m->dec_cy[j]; a.cx = m->dec_cx[j];
+        a.Ts = j == 0 ? 1 : BN_T;
+        const size_t fbytes = (size_t)(in.H + 2) * (in.W + 2) * m->dec_ci[j] * 2;
+        if (fbytes > 160 * 1024 - 256) return COVAHIP_ERR_UNSUPPORTED;
+        a.FPI = std::max<int>(1, (int)((72 * 1024) / fbytes));
+        const size_t lds = fbytes * a.FPI;
+        const int items = (batch + a.FPI - 1) / a.FPI;
+        const int grid = std::min(items, 2 * num_cu);
+        int rc;
+        if (j == 0) {
+            rc = set_lds(ctx, dec_mfma<0, 128, 64>, lds);
+            if (rc) return rc;
+            ProfScope ps(ctx, "dec0_mfma");
+            hipLaunchKernelGGL((dec_mfma<0, 128, 64>), dim3(grid), dim3(512), lds, ctx->stream, a);
+        } else if (j == 1) {
+            rc = set_lds(ctx, dec_mfma<64, 64, 32>, lds);
+            if (rc) return rc;
+            ProfScope ps(ctx, "dec1_mfma");
+            hipLaunchKernelGGL((dec_mfma<64, 64, 32>), dim3(grid), dim3(256), lds, ctx->stream, a);
+        } else {
+            rc = set_lds(ctx, dec_mfma<32, 32, 16>, lds);
+            if (rc) return rc;
+            ProfScope ps(ctx, "dec2_mfma");
+            hipLaunchKernelGGL((dec_mfma<32, 32, 16>), dim3(grid), dim3(256), lds, ctx->stream, a);
+        }
+        COVAHIP_CHECK_HIP(ctx, hipGetLastError());
+    }
+    // ---------------- last block + final conv + threshold
+    {
+        const BnLevelGeom in = m->lv[1], out = m->lv[0];
+        FinalArgs a;
+        a.up = m->dact[2]; a.skip = m->act[1]; a.wf = (const float *)(prep + pr->final_w);
+        a.logits = d_logits; a.mask = d_mask;
+        a.B = batch; a.Hi = in.H; a.Wi = in.W; a.Hd = out.H; a.Wd = out.W; a.cy = m->dec_cy[3]; a.cx = m->dec_cx[3];
+        const long long total = (long long)batch * (in.H + 1) * (in.W + 1);
+        ProfScope ps(ctx, "final_kernel");
+        hipLaunchKernelGGL(final_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, a);
+        COVAHIP_CHECK_HIP(ctx, hipGetLastError());
+    }
+    return COVAHIP_OK;
 }

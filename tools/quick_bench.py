@@ -1,0 +1,46 @@
+"""Developer helper: per-kernel times of the hot path at a given batch (device-resident inputs)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cova_amd import synth, weights as W  # noqa: E402
+from cova_amd.elements import BlobNetInfer, Context  # noqa: E402
+from cova_amd import _lib as L  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+H, Wd = 68, 120
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+ctx = Context(0)
+flat = W.random_init(1234)
+net = BlobNetInfer(ctx, flat, H, Wd, max_batch=B)
+stack = synth.stacked_batch(min(B, 64), H, Wd, seed=1, streams=8)
+stack = np.concatenate([stack] * (B // stack.shape[0] + 1))[:B]
+d_stack = ctx.malloc(stack.nbytes)
+ctx.h2d(d_stack, stack)
+max_boxes = 256
+d_boxes = ctx.malloc(B * max_boxes * 20)
+d_counts = ctx.malloc(B * 4)
+d_mask = ctx.malloc(B * H * Wd)
+for _ in range(3):
+    net.filter_device(d_stack, B, 1, d_boxes, d_counts, max_boxes, d_mask)
+ctx.sync()
+ctx.timer_start(0)
+for _ in range(steps):
+    net.filter_device(d_stack, B, 1, d_boxes, d_counts, max_boxes, d_mask)
+ctx.timer_stop(0)
+ms = ctx.timer_ms(0) / steps
+macs = net.macs_per_frame
+print(f"B={B}: {ms*1e3:.1f} us/batch  {B/ms*1e3:.0f} frames/s  MFMA util (alg) {2*macs*B/(ms*1e-3)/2.5e15*100:.1f}%")
+ctx.profile(True)
+for _ in range(steps):
+    net.filter_device(d_stack, B, 1, d_boxes, d_counts, max_boxes, d_mask)
+ctx.sync()
+prof = ctx.profile_read()
+tot = 0
+for k, (t, n) in sorted(prof.items()):
+    print(f"  {k:16s} {t/n*1e3:9.1f} us  x{n}")
+    tot += t / n
+print(f"  sum {tot*1e3:.1f} us")
