@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- compressed-domain frames/sec (BlobNet + bboxcc) at 1080p, b=256, N GPUs.
+
+One "step" = one pass of the hot path (covahip_filter_forward: BlobNet forward ->
+threshold -> bboxcc) over one batch of 256 synthetic 68x120 macroblock-grid stacks that
+are already resident in HBM (BASELINE.json configs[2]).  With --gpus N every rank runs
+the same batch size on its own GPU (frames/streams are independent: no collective on the
+data path), the timed region is bracketed by barrier + synchronize on both sides, the
+MAX over ranks is taken and rank 0 prints ONE JSON line.
+
+    python bench.py                       # N=1, defaults finish in about a minute
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H_MB, W_MB, T = 68, 120, 4        # 1080p macroblock grid (BASELINE.json), timestep 4
+BATCH = 256
+CC_THRESHOLD = 1                   # experiment/cova/config.yaml:59
+MAX_BOXES = 2048                   # >= ceil(H/2)*ceil(W/2) = 2040: no truncation possible
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16 MFMA peak
+
+
+def kernel_macs_per_frame():
+    """Algorithmic MACs per frame of each BlobNet kernel at 68x120."""
+    hs = [H_MB]; ws = [W_MB]
+    for _ in range(4):
+        hs.append((hs[-1] + 1) // 2); ws.append((ws[-1] + 1) // 2)
+    enc_c = [3, 16, 32, 64, 128]
+    out = {}
+    for i in range(4):
+        conv = T * hs[i] * ws[i] * 9 * enc_c[i] * enc_c[i + 1]
+        tmix = hs[i + 1] * ws[i + 1] * enc_c[i + 1] * 32
+        out[f"enc{i}_mfma"] = conv + tmix
+    dec_ci, dec_co = [128, 128, 64, 32], [64, 32, 16, 16]
+    for j in range(3):
+        out[f"dec{j}_mfma"] = hs[4 - j] * ws[4 - j] * 16 * dec_ci[j] * dec_co[j]
+    out["final_kernel"] = hs[1] * ws[1] * 16 * dec_ci[3] * dec_co[3] + H_MB * W_MB * 16
+    return out
+
+
+def cpu_baseline(flat, stack_sample, target_seconds=12.0):
+    """Times the CPU oracle (the build's C port of the reference path: BlobNet fp32 + regionprops)
+    on this host, on a bounded sample of the same workload."""
+    from oracle import ref
+    cores = os.cpu_count() or 1
+    n0 = min(len(stack_sample), max(2, cores))
+    t0 = time.perf_counter()
+    ref.blobnet_forward(flat, stack_sample[:n0], H_MB, W_MB)
+    dt = time.perf_counter() - t0
+    n = int(min(len(stack_sample), max(n0, target_seconds / max(dt / n0, 1e-6))))
+    n = max(n0, (n // n0) * n0)
+    passes = max(1, int(target_seconds / max(dt / n0 * n, 1e-6)))
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        _, mask = ref.blobnet_forward(flat, stack_sample[:n], H_MB, W_MB)
+    t_net = (time.perf_counter() - t0) / passes
+    t0 = time.perf_counter()
+    reps = 20
+    for _ in range(reps):
+        ref.regionprops_batch(mask, CC_THRESHOLD, MAX_BOXES)
+    t_cc = (time.perf_counter() - t0) / reps           # single thread, as the reference element runs
+    fps = n / (t_net + t_cc)
+    return {"value": round(fps, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} frames of the b=256 68x120 workload: oracle BlobNet fp32 (OpenMP, {cores} threads) "
+                      f"{n / t_net:.1f} frames/s + oracle bboxcc (1 thread) {n / t_cc:.0f} frames/s, serial sum",
+            "blobnet_frames_per_s": round(n / t_net, 2), "bboxcc_frames_per_s": round(n / t_cc, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from cova_amd.multigpu import Group
+    grp = Group()            # torch.distributed (RCCL) only when WORLD_SIZE > 1: rendezvous/barrier/MAX
+    rank, local_rank, world = grp.rank, grp.local_rank, grp.world
+
+    from cova_amd import synth, weights as W
+    from cova_amd.elements import BlobNetInfer, Context
+
+    ctx = Context(local_rank)
+    B = args.batch
+    flat = W.random_init(1234)
+    net = BlobNetInfer(ctx, flat, H_MB, W_MB, max_batch=B)
+    # synthetic metapreprocess output: 8 independent streams interleaved, distinct per rank
+    stack = synth.stacked_batch(B, H_MB, W_MB, seed=0xC07A + 1000 * rank, streams=8)
+    d_stack = ctx.malloc(stack.nbytes)
+    ctx.h2d(d_stack, stack)
+    d_boxes = ctx.malloc(B * MAX_BOXES * 20)
+    d_counts = ctx.malloc(B * 4)
+    d_mask = ctx.malloc(B * H_MB * W_MB)
+
+    def step():
+        net.filter_device(d_stack, B, CC_THRESHOLD, d_boxes, d_counts, MAX_BOXES, d_mask)
+
+    def barrier():
+        ctx.sync()           # the ctx's own HIP stream
+        grp.barrier()        # torch.cuda.synchronize() + dist.barrier() when world > 1
+
+    # ---- find the dominant kernel (profiled warm-up pass, not timed)
+    for _ in range(3):
+        step()
+    ctx.profile(True)
+    for _ in range(5):
+        step()
+    ctx.sync()
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    per_kernel_us = {k: t / n * 1e3 for k, (t, n) in prof.items()}
+    blob_kernels = {k: v for k, v in per_kernel_us.items() if k != "bboxcc_kernel"}
+    dominant = max(blob_kernels, key=blob_kernels.get)
+
+    for _ in range(args.warmup):
+        step()
+    # ---- timed region: K steps; only the dominant kernel carries HIP events (2 per step)
+    ctx.profile(True, only=dominant)
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start(0)
+    for _ in range(args.steps):
+        step()
+    ctx.timer_stop(0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ev_ms = ctx.timer_ms(0)
+    dom_ms, dom_n = ctx.profile_read()[dominant]
+    ctx.profile(False)
+
+    # ---- bboxcc roofline: events around it over K further steps (outside the timed region)
+    ctx.profile(True, only="bboxcc_kernel")
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    cc_ms, cc_n = ctx.profile_read()["bboxcc_kernel"]
+    ctx.profile(False)
+
+    # sanity on the outputs of the last step
+    counts = np.zeros(B, dtype=np.int32)
+    ctx.d2h(counts, d_counts)
+
+    elapsed = grp.max(elapsed)
+
+    if rank == 0:
+        macs = kernel_macs_per_frame()
+        dom_s = dom_ms / dom_n * 1e-3
+        dom_flop = 2.0 * macs[dominant] * B
+        ach_tflops = dom_flop / dom_s / 1e12
+        cc_s = cc_ms / cc_n * 1e-3
+        cc_gbs = B * H_MB * W_MB / cc_s / 1e9
+        total_flop = 2.0 * net.macs_per_frame * B
+        step_s = elapsed / args.steps
+        line = {
+            "metric": "compressed-domain frames/sec (BlobNet+bboxcc) at 1080p b=256",
+            "value": round(world * B * args.steps / elapsed, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(step_s * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": "BlobNet + bboxcc fused (covahip_filter_forward), 1080p macroblock grid 68x120, "
+                                   "T=4, inputs resident in HBM",
+                       "batch_per_gpu": B, "grid_mb": [H_MB, W_MB], "timestep": T, "cc_threshold": CC_THRESHOLD,
+                       "parallelism": f"{world} x independent per-GPU batches, no collective"},
+            "roofline": {"kernel": dominant, "bound": "mfma", "achieved": round(ach_tflops, 2),
+                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_tflops / MFMA_PEAK_TFLOPS, 4),
+                         "traffic": None,
+                         "algorithmic_flop_per_launch": dom_flop, "avg_launch_us": round(dom_s * 1e6, 2),
+                         "launches_timed": dom_n, "measured": "HIP events on the launch stream inside the timed region"},
+            "roofline_bboxcc": {"kernel": "bboxcc_kernel", "bound": "hbm", "achieved": round(cc_gbs, 2),
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(cc_gbs / HBM_PEAK_GBS, 5),
+                                "traffic": None, "algorithmic_bytes_per_launch": B * H_MB * W_MB,
+                                "avg_launch_us": round(cc_s * 1e6, 2),
+                                "note": "b=256 masks are 2.09 MB: launch-latency bound, see DESIGN.md batch sweep"},
+            "blobnet_mfma_util_whole_net": round(total_flop / (step_s - cc_s) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "per_kernel_us": {k: round(v, 2) for k, v in sorted(per_kernel_us.items())},
+            "hip_event_ms_per_step_rank0": round(ev_ms / args.steps, 4),
+            "boxes_per_frame_mean": float(counts.mean()),
+            "device": ctx.info(),
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(flat, stack)
+            line["gpu_over_cpu"] = round(line["value"] / world / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+
+    barrier()
+    ctx.close()
+    grp.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -74,6 +74,7 @@ PROTOTYPES = {
     "covahip_timer_stop": (C.c_int, [_P, C.c_int]),
     "covahip_timer_elapsed_ms": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
     "covahip_profile_enable": (C.c_int, [_P, C.c_int]),
+    "covahip_profile_filter": (C.c_int, [_P, C.c_char_p]),
     "covahip_profile_reset": (C.c_int, [_P]),
     "covahip_profile_read": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     "covahip_blobnet_load": (C.c_int, [_P, _P, _SZ, C.c_int, C.c_int, C.c_int, C.c_int]),

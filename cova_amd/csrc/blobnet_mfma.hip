@@ -21,8 +21,8 @@
 //     non-linearity between them and are folded into a single 32->1 transposed conv that
 //     runs on the vector ALU together with the threshold.
 //
-// Reference semantics: utils/model/{preprocessing,encoder,pointwise,decoder,blobnet}.py
-// (see oracle/blobnet_ref.c for the line-by-line citations).
+// Reference semantics: utils/model/preprocessing.py:6-7, encoder.py:30-80, pointwise.py:8-26,
+// decoder.py:5-134, blobnet.py:8-48; hyper-parameters utils/train-blobnet.py:57-69.
 #include <cmath>
 #include <cstring>
 #include <vector>

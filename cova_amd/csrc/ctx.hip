@@ -160,6 +160,12 @@ int covahip_profile_enable(covahip_ctx *ctx, int on) {
     return COVAHIP_OK;
 }
 
+int covahip_profile_filter(covahip_ctx *ctx, const char *kernel_name) {
+    if (!ctx) return COVAHIP_ERR_INVALID_ARG;
+    ctx->profile_filter = kernel_name ? kernel_name : "";
+    return COVAHIP_OK;
+}
+
 static void prof_drain(covahip_ctx *ctx) {
     for (auto &p : ctx->prof_pending) {
         float ms = 0.f;
@@ -201,6 +207,7 @@ int covahip_profile_read(covahip_ctx *ctx, covahip_kernel_time *out, int cap, in
 
 ProfScope::ProfScope(covahip_ctx *c, const char *name) : ctx(c) {
     if (!ctx->profile) return;
+    if (!ctx->profile_filter.empty() && ctx->profile_filter != name) return;
     covahip_ctx::ProfEntry e;
     e.name = name;
     if (!ctx->prof_pool.empty()) {

@@ -21,6 +21,7 @@ struct covahip_ctx {
     hipEvent_t t_stop[16]{};
     // per-kernel profiling
     bool profile = false;
+    std::string profile_filter;
     struct ProfEntry {
         std::string name;
         hipEvent_t a, b;

@@ -87,7 +87,8 @@ class Context:
         L.check(self._lib.covahip_timer_elapsed_ms(self.handle, slot, C.byref(ms)), "timer_elapsed", self.handle)
         return ms.value
 
-    def profile(self, on: bool):
+    def profile(self, on: bool, only: str | None = None):
+        L.check(self._lib.covahip_profile_filter(self.handle, only.encode() if only else None), "profile_filter")
         L.check(self._lib.covahip_profile_enable(self.handle, int(on)), "profile_enable")
         L.check(self._lib.covahip_profile_reset(self.handle), "profile_reset")
 

@@ -81,6 +81,9 @@ int covahip_timer_elapsed_ms(covahip_ctx *ctx, int slot, float *ms);
  * bracketed by HIP events on the ctx stream; covahip_profile_read then reports the
  * accumulated time and launch count per kernel name. */
 int covahip_profile_enable(covahip_ctx *ctx, int on);
+/* Restricts the event bracketing to one kernel name (NULL or "" = all kernels), so a
+ * timed region can carry the two events of its dominant kernel only. */
+int covahip_profile_filter(covahip_ctx *ctx, const char *kernel_name);
 int covahip_profile_reset(covahip_ctx *ctx);
 /* Fills up to cap entries; *n gets the number of distinct kernels seen. */
 typedef struct covahip_kernel_time {
