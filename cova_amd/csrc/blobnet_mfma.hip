@@ -24,6 +24,7 @@
 // Reference semantics: utils/model/preprocessing.py:6-7, encoder.py:30-80, pointwise.py:8-26,
 // decoder.py:5-134, blobnet.py:8-48; hyper-parameters utils/train-blobnet.py:57-69.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -55,12 +56,70 @@ struct Prepared {
     EncPrep enc[BN_LEVELS];
     DecPrep dec[BN_LEVELS - 1];
     size_t final_w;  // fp32 [4][4][32] folded (convT 32->16) x (1x1 16->1) weights, then folded bias
+    size_t zero;     // 256 zero bytes (LDS-DMA source for halo chunks)
     size_t total;
 };
 
 namespace {
 
 inline _Float16 f2h(float v) { return (_Float16)v; }
+
+// ------------------------------------------------------------------ helpers
+// Division by a launch-time constant d >= 2: q = umulhi(n, magic(d)), exact while n*d < 2^32.
+// (magic(1) = 0 marks the identity.)
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, uint32_t mul) { return mul ? __umulhi(n, mul) : n; }
+inline uint32_t magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) / d) + 1); }
+
+// relu -> BN affine -> 2x2 max-pool of the four conv outputs of one window.  BN runs between
+// ReLU and the pool (encoder.py:61-66) and gamma may be negative, so the pool picks the max
+// for scale >= 0 and the min otherwise: max_q(relu(a_q)*s + b) = relu(sel_q a_q)*s + b.
+// The conv bias commutes with max/min and is added after the selection.
+__device__ __forceinline__ float pool4(float a0, float a1, float a2, float a3, float bias, float scale,
+                                       float shift) {
+    const float mx = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+    const float mn = fminf(fminf(a0, a1), fminf(a2, a3));
+    const float sel = scale >= 0.f ? mx : mn;
+    return fmaxf(sel + bias, 0.f) * scale + shift;
+}
+
+// Uniform fp32 constants (temporal-MLP weights) are pulled into scalar registers once per kernel:
+// the kernels store to global memory, so without this the compiler must assume the stores alias
+// the constants and re-load them with vector loads after every store.
+__device__ __forceinline__ void load_uniform32(const float *src, float (&dst)[32]) {
+#pragma unroll
+    for (int i = 0; i < 32; i++)
+        dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, src[i])));
+}
+
+// PointWiseTN (pointwise.py:16-26): u = relu(W1^T p), v = relu(W2^T u), out = relu(v + p).
+__device__ __forceinline__ void tmix4(const float (&tm)[32], const float (&p)[BN_T], float (&o)[BN_T]) {
+    float u[BN_T];
+#pragma unroll
+    for (int j = 0; j < BN_T; j++) {
+        float a = 0.f;
+#pragma unroll
+        for (int t = 0; t < BN_T; t++) a += tm[t * BN_T + j] * p[t];
+        u[j] = fmaxf(a, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < BN_T; j++) {
+        float a = 0.f;
+#pragma unroll
+        for (int t = 0; t < BN_T; t++) a += tm[16 + t * BN_T + j] * u[t];
+        o[j] = fmaxf(fmaxf(a, 0.f) + p[j], 0.f);
+    }
+}
+
+// Asynchronous 16-byte global -> LDS copy (LDS-DMA): every lane supplies its own global source
+// address, the data lands at lds_base (wave-uniform) + lane*16.  Completion is covered by the
+// vmcnt(0) that __syncthreads() waits for.
+// The LDS base is made provably wave-uniform with readfirstlane (it goes to M0).
+typedef __attribute__((address_space(3))) void lds_void;
+__device__ __forceinline__ void glds16(const void *gsrc, uint8_t *lds_base_uniform) {
+    const uint32_t a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void *)lds_base_uniform);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (lds_void *)(uintptr_t)a, 16, 0, 0);
+}
 
 // ------------------------------------------------------------------ geometry structs
 struct Enc0Args {
@@ -70,6 +129,7 @@ struct Enc0Args {
     const float *epi;
     int B, H, W, Hp, Wp, Ho, Wo, oy, ox;
     int RB, nbands, TR, TC;
+    uint32_t mWp, mNb, mW4;
 };
 
 struct EncArgs {
@@ -79,6 +139,9 @@ struct EncArgs {
     const float *epi;
     int B, H, W, Hp, Wp, Ho, Wo, oy, ox, To;
     int RB, nbands, TR, TC;
+    uint32_t mWp, mNb, mRC;
+    const void *zero;  // >= 16 zero bytes in global memory (source of halo / padding chunks)
+    int dbg;           // experiment switches (COVAHIP_DBG): 1 skip tiles, 2 skip staging, 4 skip epilogue
 };
 
 struct DecArgs {
@@ -89,6 +152,8 @@ struct DecArgs {
     const float *epi;
     int B, Hi, Wi, Hd, Wd, cy, cx, Ts;
     int FPI;  // frames per work item
+    uint32_t mG, mGW, mRC;
+    const void *zero;
 };
 
 struct FinalArgs {
@@ -98,6 +163,7 @@ struct FinalArgs {
     float *logits;       // [B][Hd][Wd] or null
     uint8_t *mask;       // [B][Hd][Wd] or null
     int B, Hi, Wi, Hd, Wd, cy, cx;
+    uint32_t mG, mGW;
 };
 
 // ------------------------------------------------------------------ enc level 0
@@ -105,6 +171,8 @@ struct FinalArgs {
 // K layout: one K-step = 2 kernel rows x (4 pixels x 4 channels); pixel 3 and channel 3
 // carry zero weights, the 1/6 of clip(x,0,6)/6 is folded into the weights, so the LDS tile
 // holds min(x,6) as exact small integers in fp16, 8 bytes per macroblock.
+// Tile: row r <-> input row y0-1+r, col c <-> input col c-2 (cols 0,1 and W+2,W+3 are zero),
+// TC = W+4 so rows are 16-byte multiples and 4-pixel groups land 16-byte aligned.
 __global__ __launch_bounds__(WG) void enc0_mfma(Enc0Args p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -114,35 +182,67 @@ __global__ __launch_bounds__(WG) void enc0_mfma(Enc0Args p) {
     const half8 b0 = p.wfrag[lane], b1 = p.wfrag[64 + lane];
     const int co = lane & 15;
     const float bias = p.epi[co], scale = p.epi[16 + co], shift = p.epi[32 + co];
-    float w1[16], w2[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        w1[i] = p.epi[48 + i];
-        w2[i] = p.epi[64 + i];
-    }
+    float tm[32];
+    load_uniform32(p.epi + 48, tm);
 
     const int n_items = p.B * p.nbands;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int b = item / p.nbands, band = item - b * p.nbands;
+        const int b = fdiv(item, p.mNb), band = item - b * p.nbands;
         const int y0 = band * p.RB;
         const int rows = min(p.RB, 2 * p.Hp - y0);
+        const int n2 = rows + 2;
         __syncthreads();
-        // ---- stage: tile row r <-> input row y0-1+r, tile col c <-> input col c-1
-        const int npix = BN_T * (rows + 2) * TC;
-        for (int i = tid; i < npix; i += WG) {
-            const int t = i / ((rows + 2) * TC);
-            const int rem = i - t * (rows + 2) * TC;
-            const int r = rem / TC, c = rem - r * TC;
-            const int y = y0 - 1 + r, x = c - 1;
-            half4 v = {0, 0, 0, 0};
-            if (y >= 0 && y < p.H && x >= 0 && x < p.W) {
-                const uint32_t px = *reinterpret_cast<const uint32_t *>(
-                    p.in + ((((size_t)b * BN_T + t) * p.H + y) * p.W + x) * 4);
-                v[0] = (_Float16)(float)min(px & 0xFF, 6u);
-                v[1] = (_Float16)(float)min((px >> 8) & 0xFF, 6u);
-                v[2] = (_Float16)(float)min((px >> 16) & 0xFF, 6u);
+        // ---- stage: the band's (t, row, 4-pixel group) chunks are swept linearly; all global loads
+        // of a thread are issued before the first conversion so their latencies overlap.
+        {
+            const int W4 = p.W >> 2;                  // 16-byte chunks (4 macroblocks) per image row
+            const int per_t = n2 * W4, nchunk = BN_T * per_t;
+            constexpr int KMAX = 10;                  // chunks per thread this kernel is sized for (host checks)
+            uint4 v[KMAX];
+            int dsto[KMAX];
+#pragma unroll
+            for (int k = 0; k < KMAX; k++) {
+                const int i = tid + k * WG;
+                v[k] = make_uint4(0, 0, 0, 0);
+                dsto[k] = -1;
+                if (i < nchunk) {
+                    const int t = (i >= per_t) + (i >= 2 * per_t) + (i >= 3 * per_t), rem = i - t * per_t;
+                    const int r = fdiv(rem, p.mW4), c4 = rem - r * W4;
+                    const int y = y0 - 1 + r;
+                    dsto[k] = t * tsz + r * TC * 8 + 16 + c4 * 32;
+                    if (y >= 0 && y < p.H)
+                        v[k] = *reinterpret_cast<const uint4 *>(
+                            p.in + ((((size_t)b * BN_T + t) * p.H + y) * p.W + c4 * 4) * 4);
+                }
             }
-            *reinterpret_cast<half4 *>(smem + t * tsz + (r * TC + c) * 8) = v;
+#pragma unroll
+            for (int k = 0; k < KMAX; k++) {
+                if (dsto[k] >= 0) {
+                    const uint32_t px[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+                    half8 lo, hi;
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        lo[4 * q + 0] = (_Float16)fminf((float)(px[q] & 0xFF), 6.f);
+                        lo[4 * q + 1] = (_Float16)fminf((float)((px[q] >> 8) & 0xFF), 6.f);
+                        lo[4 * q + 2] = (_Float16)fminf((float)((px[q] >> 16) & 0xFF), 6.f);
+                        lo[4 * q + 3] = (_Float16)0;
+                        hi[4 * q + 0] = (_Float16)fminf((float)(px[2 + q] & 0xFF), 6.f);
+                        hi[4 * q + 1] = (_Float16)fminf((float)((px[2 + q] >> 8) & 0xFF), 6.f);
+                        hi[4 * q + 2] = (_Float16)fminf((float)((px[2 + q] >> 16) & 0xFF), 6.f);
+                        hi[4 * q + 3] = (_Float16)0;
+                    }
+                    *reinterpret_cast<half8 *>(smem + dsto[k]) = lo;        // tile cols 4c+2, 4c+3
+                    *reinterpret_cast<half8 *>(smem + dsto[k] + 16) = hi;   // tile cols 4c+4, 4c+5
+                }
+            }
+            // zero halo columns 0,1 and W+2,W+3 of every (t, row)
+            for (int i = tid; i < BN_T * n2 * 2; i += WG) {
+                const int rr = i >> 1;
+                const int t = (rr >= n2) + (rr >= 2 * n2) + (rr >= 3 * n2);
+                const int r = rr - t * n2;
+                *reinterpret_cast<uint4 *>(smem + t * tsz + r * TC * 8 + ((i & 1) ? (p.W + 2) * 8 : 0)) =
+                    make_uint4(0, 0, 0, 0);
+            }
         }
         __syncthreads();
         // ---- compute: M-tile = 4 pool windows (16 conv pixels), all 4 T
@@ -151,60 +251,38 @@ __global__ __launch_bounds__(WG) void enc0_mfma(Enc0Args p) {
         const int m = lane & 15, g = lane >> 4;
         for (int tile = wave; tile < ntiles; tile += WG / 64) {
             const int win = min(tile * 4 + (m >> 2), nwin - 1);
-            const int wy = win / p.Wp, wx = win - wy * p.Wp;
+            const int wy = fdiv(win, p.mWp), wx = win - wy * p.Wp;
             const int yy = 2 * wy + ((m >> 1) & 1), xx = 2 * wx + (m & 1);
+            // conv pixel x, tap kx reads input x+kx-1 = tile col x+kx+1
             // K-step 0: kernel rows 0/1 (g>>1), pixel pair g&1; K-step 1: kernel row 2 (g>>1 == 0)
-            const int off0 = ((yy + (g >> 1)) * TC + xx + 2 * (g & 1)) * 8;
-            const int off1 = ((yy + 2) * TC + xx + 2 * (g & 1)) * 8;
-            f32x4 acc[BN_T];
+            const int off0 = ((yy + (g >> 1)) * TC + xx + 1 + 2 * (g & 1)) * 8;
+            const int off1 = ((yy + 2) * TC + xx + 1 + 2 * (g & 1)) * 8;
+            float pooled[BN_T];
 #pragma unroll
             for (int t = 0; t < BN_T; t++) {
                 const uint8_t *base = smem + t * tsz;
-                half8 a0, a1;
                 const half4 l0 = *reinterpret_cast<const half4 *>(base + off0);
                 const half4 h0 = *reinterpret_cast<const half4 *>(base + off0 + 8);
                 const half4 l1 = *reinterpret_cast<const half4 *>(base + off1);
                 const half4 h1 = *reinterpret_cast<const half4 *>(base + off1 + 8);
-                a0 = __builtin_shufflevector(l0, h0, 0, 1, 2, 3, 4, 5, 6, 7);
-                a1 = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-                f32x4 c = {bias, bias, bias, bias};
+                const half8 a0 = __builtin_shufflevector(l0, h0, 0, 1, 2, 3, 4, 5, 6, 7);
+                const half8 a1 = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                f32x4 c = {0.f, 0.f, 0.f, 0.f};
                 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, c, 0, 0, 0);
-                acc[t] = c;
+                // D rows 4*(lane>>4)+r = window (lane>>4), position r
+                pooled[t] = pool4(c[0], c[1], c[2], c[3], bias, scale, shift);
             }
-            // ---- epilogue: D rows 4*(lane>>4)+r = window (lane>>4), position r
-            float pooled[BN_T];
-#pragma unroll
-            for (int t = 0; t < BN_T; t++) {
-                float mx = -INFINITY;
-#pragma unroll
-                for (int r = 0; r < 4; r++) mx = fmaxf(mx, fmaxf(acc[t][r], 0.f) * scale + shift);
-                pooled[t] = mx;
-            }
-            float u[BN_T], v[BN_T];
-#pragma unroll
-            for (int j = 0; j < BN_T; j++) {
-                float a = 0.f;
-#pragma unroll
-                for (int t = 0; t < BN_T; t++) a += w1[t * BN_T + j] * pooled[t];
-                u[j] = fmaxf(a, 0.f);
-            }
-#pragma unroll
-            for (int j = 0; j < BN_T; j++) {
-                float a = 0.f;
-#pragma unroll
-                for (int t = 0; t < BN_T; t++) a += w2[t * BN_T + j] * u[t];
-                v[j] = fmaxf(a, 0.f);
-            }
+            float o[BN_T];
+            tmix4(tm, pooled, o);
             const int owin = tile * 4 + g;
             if (owin < nwin) {
-                const int owy = owin / p.Wp, owx = owin - owy * p.Wp;
+                const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
                 const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
+                __half *dstp = p.out + (((size_t)b * BN_T * p.Ho + gy) * p.Wo + gx) * 16 + co;
+                const size_t tstride = (size_t)p.Ho * p.Wo * 16;
 #pragma unroll
-                for (int t = 0; t < BN_T; t++) {
-                    const float o = fmaxf(v[t] + pooled[t], 0.f);
-                    p.out[((((size_t)b * BN_T + t) * p.Ho + gy) * p.Wo + gx) * 16 + co] = __float2half(o);
-                }
+                for (int t = 0; t < BN_T; t++) dstp[t * tstride] = __float2half(o[t]);
             }
         }
     }
@@ -235,38 +313,48 @@ __global__ __launch_bounds__(WG, OCC) void enc_mfma(EncArgs p) {
     for (int ks = 0; ks < KSTEPS; ks++) bf[ks] = p.wfrag[(ntile * KSTEPS + ks) * 64 + lane];
     const int co = ntile * 32 + (lane & 31);
     const float bias = p.epi[co], scale = p.epi[COUT + co], shift = p.epi[2 * COUT + co];
-    const float *tm = p.epi + 3 * COUT;
+    float tm[32];
+    load_uniform32(p.epi + 3 * COUT, tm);
 
     const int n_items = p.B * p.nbands;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int b = item / p.nbands, band = item - b * p.nbands;
+        const int b = fdiv(item, p.mNb), band = item - b * p.nbands;
         const int y0 = band * p.RB;
         const int rows = min(p.RB, 2 * p.Hp - y0);
+        const int n2 = rows + 2;
         __syncthreads();
-        // ---- stage the band (all T) into LDS, 16 bytes per work item, swizzled
-        const int nchunks = BN_T * (rows + 2) * TC * CPP;
-        for (int i = tid; i < nchunks; i += WG) {
-            const int ch = i % CPP;
-            const int pix = i / CPP;
-            const int t = pix / ((rows + 2) * TC);
-            const int rem = pix - t * (rows + 2) * TC;
-            const int r = rem / TC, c = rem - r * TC;
-            const int y = y0 - 1 + r, x = c - 1;
-            uint4 v = {0, 0, 0, 0};
-            if (y >= 0 && y < p.H && x >= 0 && x < p.W)
-                v = *reinterpret_cast<const uint4 *>(
-                    p.in + ((((size_t)b * BN_T + t) * p.H + y) * p.W + x) * CIN + ch * 8);
-            const int sw = ch ^ enc_swz<CIN>(c, r);
-            *reinterpret_cast<uint4 *>(smem + t * tsz + (r * TC + c) * PS + sw * 16) = v;
+        // ---- stage the band with LDS-DMA: the tile is swept linearly in 16-byte chunks (64 per
+        // wave-instruction); chunk -> (row, col, physical chunk) -> swizzled source chunk; halo
+        // columns / out-of-image rows read the zero buffer.
+        if (!(p.dbg & 2)) {
+            const int RC = TC * CPP;  // chunks per tile row
+            const int nchunk = n2 * RC;
+            const __half *fbase = p.in + ((size_t)b * BN_T) * p.H * p.W * CIN;
+            for (int t = 0; t < BN_T; t++) {
+                uint8_t *tbase = smem + t * tsz;
+                const __half *tsrc = fbase + (size_t)t * p.H * p.W * CIN;
+                for (int s0 = wave * 64; s0 < nchunk; s0 += WG) {
+                    const int sidx = s0 + lane;
+                    if (sidx < nchunk) {
+                        const int r = fdiv(sidx, p.mRC), within = sidx - r * RC;
+                        const int c = within / CPP, chp = within % CPP;
+                        const int ch = chp ^ enc_swz<CIN>(c, r);
+                        const int y = y0 - 1 + r, x = c - 1;
+                        const void *src = p.zero;
+                        if (y >= 0 && y < p.H && x >= 0 && x < p.W) src = tsrc + ((size_t)y * p.W + x) * CIN + ch * 8;
+                        glds16(src, tbase + s0 * 16);
+                    }
+                }
+            }
         }
         __syncthreads();
         // ---- compute
         const int nwin = (rows / 2) * p.Wp;
-        const int ntiles = (nwin + 7) / 8;
+        const int ntiles = (p.dbg & 1) ? 0 : (nwin + 7) / 8;
         const int m = lane & 31, kh = lane >> 5;
         for (int tile = mgroup; tile < ntiles; tile += MG) {
             const int win = min(tile * 8 + (m >> 2), nwin - 1);
-            const int wy = win / p.Wp, wx = win - wy * p.Wp;
+            const int wy = fdiv(win, p.mWp), wx = win - wy * p.Wp;
             const int yy0 = 2 * wy + ((m >> 1) & 1), xx0 = 2 * wx + (m & 1);
             // TPAR T-slices are accumulated at a time (register budget); the pooled values of all
             // four slices are kept for the temporal MLP.
@@ -277,7 +365,7 @@ __global__ __launch_bounds__(WG, OCC) void enc_mfma(EncArgs p) {
 #pragma unroll
                 for (int t = 0; t < TPAR; t++)
 #pragma unroll
-                    for (int r = 0; r < 16; r++) acc[t][r] = bias;
+                    for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
 #pragma unroll
                 for (int ky = 0; ky < 3; ky++)
 #pragma unroll
@@ -300,44 +388,35 @@ __global__ __launch_bounds__(WG, OCC) void enc_mfma(EncArgs p) {
 #pragma unroll
                 for (int t = 0; t < TPAR; t++)
 #pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        float mx = -INFINITY;
+                    for (int g = 0; g < 4; g++)
+                        pooled4[t0 + t][g] = pool4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2],
+                                                   acc[t][4 * g + 3], bias, scale, shift);
+            }
+            if (p.dbg & 4) {
+                float sum = 0.f;
 #pragma unroll
-                        for (int q = 0; q < 4; q++) mx = fmaxf(mx, fmaxf(acc[t][4 * g + q], 0.f) * scale + shift);
-                        pooled4[t0 + t][g] = mx;
-                    }
+                for (int t = 0; t < BN_T; t++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) sum += pooled4[t][g];
+                if (sum == 12345.678f) p.out[0] = __float2half(sum);
+                continue;
             }
             // ---- epilogue: temporal MLP + residual per pooled window, then store
+            const size_t tstride = (size_t)p.Ho * p.Wo * COUT;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                float pooled[BN_T];
+                float pooled[BN_T], o[BN_T];
 #pragma unroll
                 for (int t = 0; t < BN_T; t++) pooled[t] = pooled4[t][g];
-                float u[BN_T], v[BN_T];
-#pragma unroll
-                for (int j = 0; j < BN_T; j++) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int t = 0; t < BN_T; t++) a += tm[t * BN_T + j] * pooled[t];
-                    u[j] = fmaxf(a, 0.f);
-                }
-#pragma unroll
-                for (int j = 0; j < BN_T; j++) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int t = 0; t < BN_T; t++) a += tm[16 + t * BN_T + j] * u[t];
-                    v[j] = fmaxf(a, 0.f);
-                }
+                tmix4(tm, pooled, o);
                 const int owin = tile * 8 + 2 * g + kh;
                 if (owin < nwin) {
-                    const int owy = owin / p.Wp, owx = owin - owy * p.Wp;
+                    const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
                     const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
+                    __half *dstp = p.out + (((size_t)b * p.To * p.Ho + gy) * p.Wo + gx) * COUT + co;
 #pragma unroll
                     for (int t = 0; t < BN_T; t++)
-                        if (t < p.To) {
-                            const float o = fmaxf(v[t] + pooled[t], 0.f);
-                            p.out[((((size_t)b * p.To + t) * p.Ho + gy) * p.Wo + gx) * COUT + co] = __float2half(o);
-                        }
+                        if (t < p.To) dstp[t * tstride] = __float2half(o[t]);
                 }
             }
         }
@@ -356,13 +435,13 @@ __device__ __forceinline__ int dec_swz(int xx) {
 template <int C1, int C2, int COUT>
 __global__ __launch_bounds__((4 * COUT / 32 > 4 ? 4 * COUT / 32 : 4) * 64, 2) void dec_mfma(DecArgs p) {
     constexpr int C = C1 + C2, NTT = 4 * COUT / 32, NW = NTT > 4 ? NTT : 4, MG = NW / NTT;
-    constexpr int KC = C / 16, KSTEPS = 4 * KC, CPP = C / 8, PS = C * 2, NTHREADS = NW * 64;
+    constexpr int KC = C / 16, KSTEPS = 4 * KC, CPP = C / 8, PS = C * 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntile = wave % NTT, mgroup = wave / NTT;
     const int TR = p.Hi + 2, TC = p.Wi + 2;
     const int fsz = TR * TC * PS;  // bytes per frame tile
-    const int GW = p.Wi + 1, G = (p.Hi + 1) * GW;
+    const int GW = p.Wi + 1, GH = p.Hi + 1, G = GH * GW;
 
     half8 bf[KSTEPS];
 #pragma unroll
@@ -376,29 +455,37 @@ __global__ __launch_bounds__((4 * COUT / 32 > 4 ? 4 * COUT / 32 : 4) * 64, 2) vo
         const int b0 = item * p.FPI;
         const int nf = min(p.FPI, p.B - b0);
         __syncthreads();
-        // ---- stage nf frames: concat(relu(up), relu(skip[t=0])) with a zero border
-        const int nchunks = nf * TR * TC * CPP;
-        for (int i = tid; i < nchunks; i += NTHREADS) {
-            const int ch = i % CPP;
-            const int pix = i / CPP;
-            const int f = pix / (TR * TC);
-            const int rem = pix - f * TR * TC;
-            const int r = rem / TC, c = rem - r * TC;
-            const int y = r - 1, x = c - 1;
-            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (y >= 0 && y < p.Hi && x >= 0 && x < p.Wi) {
-                const int cb = ch * 8;
-                const __half *src;
-                if (cb < C1)
-                    src = p.up + ((((size_t)(b0 + f)) * p.Hi + y) * p.Wi + x) * C1 + cb;
-                else
-                    src = p.skip + ((((size_t)(b0 + f) * p.Ts) * p.Hi + y) * p.Wi + x) * C2 + (cb - C1);
-                v = *reinterpret_cast<const half8 *>(src);
-#pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = v[j] > (_Float16)0 ? v[j] : (_Float16)0;
+        // ---- stage nf frames with LDS-DMA: concat(up, skip[t=0]) with a zero border.  Both
+        // sources already hold relu'd values (the up branch is stored after its consumer's ReLU,
+        // the skips end in a ReLU), so no arithmetic is needed on the way in.
+        {
+            const int RC = TC * CPP;
+            const int nchunk = TR * RC;
+            for (int f = 0; f < nf; f++) {
+                uint8_t *fb = smem + f * fsz;
+                const __half *su = p.up + ((size_t)(b0 + f)) * p.Hi * p.Wi * C1;  // unused when C1 == 0
+                const __half *ss = p.skip + ((size_t)(b0 + f) * p.Ts) * p.Hi * p.Wi * C2;
+                for (int s0 = wave * 64; s0 < nchunk; s0 += NW * 64) {
+                    const int sidx = s0 + lane;
+                    if (sidx < nchunk) {
+                        const int r = fdiv(sidx, p.mRC), within = sidx - r * RC;
+                        const int c = within / CPP, chp = within % CPP;
+                        const int cb = (chp ^ dec_swz<C>(c)) * 8;
+                        const int y = r - 1, x = c - 1;
+                        const void *src = p.zero;
+                        if (y >= 0 && y < p.Hi && x >= 0 && x < p.Wi) {
+                            const size_t pix = (size_t)y * p.Wi + x;
+                            if constexpr (C1 == 0) {
+                                src = ss + pix * C2 + cb;
+                            } else {
+                                if (cb < C1) src = su + pix * C1 + cb;
+                                else src = ss + pix * C2 + (cb - C1);
+                            }
+                        }
+                        glds16(src, fb + s0 * 16);
+                    }
+                }
             }
-            const int sw = ch ^ dec_swz<C>(c);
-            *reinterpret_cast<half8 *>(smem + f * fsz + (r * TC + c) * PS + sw * 16) = v;
         }
         __syncthreads();
         // ---- compute over the flattened (frame, u, v) positions
@@ -407,11 +494,11 @@ __global__ __launch_bounds__((4 * COUT / 32 > 4 ? 4 * COUT / 32 : 4) * 64, 2) vo
         const int m = lane & 31, kh = lane >> 5;
         for (int tile = mgroup; tile < ntiles; tile += MG) {
             const int q = min(tile * 32 + m, npos - 1);
-            const int f = q / G, qq = q - f * G;
-            const int u = qq / GW, v = qq - u * GW;
+            const int f = fdiv(q, p.mG), qq = q - f * G;
+            const int u = fdiv(qq, p.mGW), v = qq - u * GW;
             f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = bias;
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
 #pragma unroll
             for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -425,18 +512,32 @@ __global__ __launch_bounds__((4 * COUT / 32 > 4 ? 4 * COUT / 32 : 4) * 64, 2) vo
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bf[(a * 2 + bb) * KC + kc], acc, 0, 0, 0);
                     }
                 }
-            // ---- epilogue: row = (r&3) + 8*(r>>2) + 4*kh
+            // ---- epilogue: reg r -> row (r&3) + 8*(r>>2) + 4*kh; rows 4 apart are consecutive
+            // positions, so one (f,u,v) decomposition per group of four and increments after
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const int oq = tile * 32 + row;
-                if (oq < npos) {
-                    const int of = oq / G, oqq = oq - of * G;
-                    const int ou = oqq / GW, ov = oqq - ou * GW;
-                    const int Y = 2 * ou + py - p.cy, X = 2 * ov + px - p.cx;
-                    if (Y >= 0 && Y < p.Hd && X >= 0 && X < p.Wd)
-                        p.out[((((size_t)(b0 + of)) * p.Hd + Y) * p.Wd + X) * COUT + co] =
-                            __float2half(acc[r] * scale + shift);
+            for (int g = 0; g < 4; g++) {
+                const int oq0 = tile * 32 + 8 * g + 4 * kh;
+                int of = fdiv(oq0, p.mG);
+                const int oqq = oq0 - of * G;
+                int ou = fdiv(oqq, p.mGW);
+                int ov = oqq - ou * GW;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (oq0 + j < npos) {
+                        const int Y = 2 * ou + py - p.cy, X = 2 * ov + px - p.cx;
+                        if (Y >= 0 && Y < p.Hd && X >= 0 && X < p.Wd)
+                            p.out[((((size_t)(b0 + of)) * p.Hd + Y) * p.Wd + X) * COUT + co] =
+                                __float2half(fmaxf((acc[4 * g + j] + bias) * scale + shift, 0.f));
+                    }
+                    ov++;
+                    if (ov == GW) {
+                        ov = 0;
+                        ou++;
+                        if (ou == GH) {
+                            ou = 0;
+                            of++;
+                        }
+                    }
                 }
             }
         }
@@ -448,12 +549,10 @@ __global__ __launch_bounds__((4 * COUT / 32 > 4 ? 4 * COUT / 32 : 4) * 64, 2) vo
 // neighbourhood once and produces the four output parities (vector ALU, fp32).
 __global__ __launch_bounds__(256) void final_kernel(FinalArgs p) {
     const int GW = p.Wi + 1, G = (p.Hi + 1) * GW;
-    const long long total = (long long)p.B * G;
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const int b = (int)(gid / G);
-    const int qq = (int)(gid - (long long)b * G);
-    const int u = qq / GW, v = qq - u * GW;
+    const int b = blockIdx.y;
+    const int qq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qq >= G) return;
+    const int u = (int)fdiv((uint32_t)qq, p.mGW), v = qq - u * GW;
     float acc[4];
     const float fb = p.wf[512];
 #pragma unroll
@@ -627,6 +726,7 @@ int blobnet_prepare_mfma(covahip_ctx *ctx, covahip_blobnet *m, const float *w) {
         pr->dec[j].epi = off; off = align256(off + 3 * co * sizeof(float));
     }
     pr->final_w = off; off = align256(off + 513 * sizeof(float));
+    pr->zero = off; off = align256(off + 256);
     pr->total = off;
 
     std::vector<uint8_t> host(off, 0);
@@ -678,15 +778,17 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
         const int H = m->lv[i].H, W = m->lv[i].W, Hp = H / 2, Wp = W / 2;
         const int cin = m->enc_c[i];
         const size_t px_bytes = (i == 0) ? 8 : (size_t)cin * 2;
-        // enc0 keeps one extra zero column: its K layout reads a 4th (zero-weight) pixel per tap row
-        const int TC = (i == 0) ? W + 3 : W + 2;
+        // enc0: two zero columns left (16-byte aligned 4-pixel groups) and two right (halo + the 4th,
+        // zero-weight pixel its K layout reads per tap row)
+        const int TC = (i == 0) ? W + 4 : W + 2;
         // band height: largest even RB whose tile (RB+2 rows, all T) fits in ~78 KB of LDS
         // (two workgroups per CU; the 64->128 level keeps 144 weight VGPRs per wave and runs one
         //  workgroup per CU with up to 150 KB)
         const size_t lds_cap = (i == BN_LEVELS - 1) ? 150 * 1024 : 78 * 1024;
-        int RB = 2 * Hp;
-        while (RB > 2 && (size_t)BN_T * (RB + 2) * TC * px_bytes > lds_cap) RB -= 2;
-        const int nbands = (2 * Hp + RB - 1) / RB;
+        int RBmax = 2 * Hp;
+        while (RBmax > 2 && (size_t)BN_T * (RBmax + 2) * TC * px_bytes > lds_cap) RBmax -= 2;
+        const int nbands = (2 * Hp + RBmax - 1) / RBmax;
+        const int RB = 2 * ((Hp + nbands - 1) / nbands);  // balanced bands
         const size_t lds = (size_t)BN_T * (RB + 2) * TC * px_bytes;
         if (lds > 160 * 1024 - 256) return COVAHIP_ERR_UNSUPPORTED;
         const int items = batch * nbands;
@@ -697,6 +799,8 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
             a.wfrag = (const half8 *)(prep + pr->enc[0].wfrag); a.epi = (const float *)(prep + pr->enc[0].epi);
             a.B = batch; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.Ho = m->lv[1].H; a.Wo = m->lv[1].W;
             a.oy = H & 1; a.ox = W & 1; a.RB = RB; a.nbands = nbands; a.TR = RB + 2; a.TC = TC;
+            a.mWp = magic(Wp); a.mNb = magic(nbands); a.mW4 = magic(W / 4);
+            if (W % 4 || BN_T * (RB + 2) * (W / 4) > 10 * WG) return COVAHIP_ERR_UNSUPPORTED;
             int rc = set_lds(ctx, enc0_mfma, lds);
             if (rc) return rc;
             ProfScope ps(ctx, "enc0_mfma");
@@ -708,6 +812,8 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
             a.B = batch; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.Ho = m->lv[i + 1].H; a.Wo = m->lv[i + 1].W;
             a.oy = H & 1; a.ox = W & 1; a.To = (i == BN_LEVELS - 1) ? 1 : BN_T;
             a.RB = RB; a.nbands = nbands; a.TR = RB + 2; a.TC = TC;
+            a.mWp = magic(Wp); a.mNb = magic(nbands); a.mRC = magic(TC * (cin / 8)); a.zero = prep + pr->zero;
+            { const char *e = std::getenv("COVAHIP_DBG"); a.dbg = e ? std::atoi(e) : 0; }
             int rc = COVAHIP_OK;
             if (i == 1) {
                 rc = set_lds(ctx, enc_mfma<16, 32, 4, 2>, lds);
@@ -741,6 +847,8 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
         const size_t fbytes = (size_t)(in.H + 2) * (in.W + 2) * m->dec_ci[j] * 2;
         if (fbytes > 160 * 1024 - 256) return COVAHIP_ERR_UNSUPPORTED;
         a.FPI = std::max<int>(1, (int)((72 * 1024) / fbytes));
+        a.mG = magic((in.H + 1) * (in.W + 1)); a.mGW = magic(in.W + 1);
+        a.mRC = magic((in.W + 2) * (m->dec_ci[j] / 8)); a.zero = prep + pr->zero;
         const size_t lds = fbytes * a.FPI;
         const int items = (batch + a.FPI - 1) / a.FPI;
         const int grid = std::min(items, 2 * num_cu);
@@ -770,9 +878,11 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
         a.up = m->dact[2]; a.skip = m->act[1]; a.wf = (const float *)(prep + pr->final_w);
         a.logits = d_logits; a.mask = d_mask;
         a.B = batch; a.Hi = in.H; a.Wi = in.W; a.Hd = out.H; a.Wd = out.W; a.cy = m->dec_cy[3]; a.cx = m->dec_cx[3];
-        const long long total = (long long)batch * (in.H + 1) * (in.W + 1);
+        a.mG = magic((in.H + 1) * (in.W + 1)); a.mGW = magic(in.W + 1);
+        const int G = (in.H + 1) * (in.W + 1);
+        if (batch > 65535) return COVAHIP_ERR_UNSUPPORTED;
         ProfScope ps(ctx, "final_kernel");
-        hipLaunchKernelGGL(final_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(final_kernel, dim3((G + 255) / 256, batch), dim3(256), 0, ctx->stream, a);
         COVAHIP_CHECK_HIP(ctx, hipGetLastError());
     }
     return COVAHIP_OK;

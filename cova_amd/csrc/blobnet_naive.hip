@@ -121,7 +121,9 @@ __global__ void dec_naive(const __half *__restrict__ up, const __half *__restric
     float acc = p.b[co] + dec_point(up, skip, skip_t, p.k, b, Hi, Wi, C1, C2, Cout, co, y + cy, x + cx);
     const float scale = p.gamma[co] * rsqrtf(p.var[co] + BN_EPS);
     const float shift = p.beta[co] - p.mean[co] * scale;
-    out[(((size_t)b * Hd + y) * Wd + x) * Cout + co] = __float2half(acc * scale + shift);
+    // stored after the consumer's leading ReLU (its only consumer, decoder.py:9-11): same buffer
+    // semantics as the MFMA path
+    out[(((size_t)b * Hd + y) * Wd + x) * Cout + co] = __float2half(fmaxf(acc * scale + shift, 0.f));
 }
 
 // Last block + final 1x1 conv (decoder.py:131-134) + threshold (nvinfer segmentation
