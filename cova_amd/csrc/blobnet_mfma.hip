@@ -181,7 +181,8 @@ __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
     const int TR = p.TR, TC = p.TC;
     const int tsz = TR * TC * 8;  // bytes per T slice
 
-    const half8 b0 = p.wfrag[lane], b1 = p.wfrag[64 + lane];
+    const half8 be0 = p.wfrag[lane], be1 = p.wfrag[64 + lane];          // even-x weight set
+    const half8 bo0 = p.wfrag[128 + lane], bo1 = p.wfrag[192 + lane];   // odd-x weight set
     const int co = lane & 15;
     const float bias = p.epi[co], scale = p.epi[16 + co], shift = p.epi[32 + co];
     float tm[32];
@@ -247,49 +248,58 @@ __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
             }
         }
         __syncthreads();
-        // ---- compute: M-tile = 4 pool windows (16 conv pixels), all 4 T
+        // ---- compute.  One tile = 8 pool windows.  The 16 rows of an MFMA are the 8 windows x 2
+        // conv rows (dy) of ONE column parity: conv pixels with even x and with odd x go to two MFMAs
+        // with two weight sets, so that the 4-pixel K group every lane reads starts at an even tile
+        // column, i.e. is one 16-byte aligned ds_read_b128:
+        //   even x: tile cols [x, x+3]   = inputs x-2..x+1 -> weights [0, k0, k1, k2]
+        //   odd  x: tile cols [x+1, x+4] = inputs x-1..x+2 -> weights [k0, k1, k2, 0]
+        // (tile col = input col + 2).  D rows 4*(lane>>4)+r -> window 2*(lane>>4) + (r>>1), dy = r&1,
+        // so both windows of a lane pool in-register over {even, odd} x {dy}.
         const int nwin = (rows / 2) * p.Wp;
-        const int ntiles = (p.dbg & 1) ? 0 : (nwin + 3) / 4;
+        const int ntiles = (p.dbg & 1) ? 0 : (nwin + 7) / 8;
         const int m = lane & 15, g = lane >> 4;
         for (int tile = wave; tile < ntiles; tile += WG0 / 64) {
-            const int win = min(tile * 4 + (m >> 2), nwin - 1);
+            const int win = min(tile * 8 + (m >> 1), nwin - 1);
             const int wy = fdiv(win, p.mWp), wx = win - wy * p.Wp;
-            const int yy = 2 * wy + ((m >> 1) & 1), xx = 2 * wx + (m & 1);
-            // conv pixel x, tap kx reads input x+kx-1 = tile col x+kx+1
-            // K-step 0: kernel rows 0/1 (g>>1), pixel pair g&1; K-step 1: kernel row 2 (g>>1 == 0)
-            const int off0 = ((yy + (g >> 1)) * TC + xx + 1 + 2 * (g & 1)) * 8;
-            const int off1 = ((yy + 2) * TC + xx + 1 + 2 * (g & 1)) * 8;
-            float pooled[BN_T];
+            const int yy = 2 * wy + (m & 1), xe = 2 * wx;
+            // K-step 0: kernel rows 0/1 (g>>1), pixel pair g&1; K-step 1: kernel row 2 (zero weights for g>>1 == 1)
+            const int offe0 = ((yy + (g >> 1)) * TC + xe + 2 * (g & 1)) * 8;
+            const int offe1 = ((yy + 2) * TC + xe + 2 * (g & 1)) * 8;
+            float pooled[2][BN_T];
 #pragma unroll
             for (int t = 0; t < BN_T; t++) {
                 const uint8_t *base = smem + t * tsz;
-                const half4 l0 = *reinterpret_cast<const half4 *>(base + off0);
-                const half4 h0 = *reinterpret_cast<const half4 *>(base + off0 + 8);
-                const half4 l1 = *reinterpret_cast<const half4 *>(base + off1);
-                const half4 h1 = *reinterpret_cast<const half4 *>(base + off1 + 8);
-                const half8 a0 = __builtin_shufflevector(l0, h0, 0, 1, 2, 3, 4, 5, 6, 7);
-                const half8 a1 = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-                f32x4 c = {0.f, 0.f, 0.f, 0.f};
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, c, 0, 0, 0);
-                // D rows 4*(lane>>4)+r = window (lane>>4), position r
-                pooled[t] = pool4(c[0], c[1], c[2], c[3], bias, scale, shift);
+                const half8 ae0 = *reinterpret_cast<const half8 *>(base + offe0);
+                const half8 ae1 = *reinterpret_cast<const half8 *>(base + offe1);
+                const half8 ao0 = *reinterpret_cast<const half8 *>(base + offe0 + 16);
+                const half8 ao1 = *reinterpret_cast<const half8 *>(base + offe1 + 16);
+                f32x4 ce = {0.f, 0.f, 0.f, 0.f}, co_ = {0.f, 0.f, 0.f, 0.f};
+                ce = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae0, be0, ce, 0, 0, 0);
+                co_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao0, bo0, co_, 0, 0, 0);
+                ce = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae1, be1, ce, 0, 0, 0);
+                co_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao1, bo1, co_, 0, 0, 0);
+                pooled[0][t] = pool4(ce[0], ce[1], co_[0], co_[1], bias, scale, shift);
+                pooled[1][t] = pool4(ce[2], ce[3], co_[2], co_[3], bias, scale, shift);
             }
             if (p.dbg & 4) {
-                const float sum = pooled[0] + pooled[1] + pooled[2] + pooled[3];
+                const float sum = pooled[0][0] + pooled[0][1] + pooled[1][2] + pooled[1][3];
                 if (sum == 12345.678f) p.out[0] = __float2half(sum);
                 continue;
             }
-            float o[BN_T];
-            tmix4(tm, pooled, o);
-            const int owin = tile * 4 + g;
-            if (owin < nwin) {
-                const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
-                const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
-                __half *dstp = p.out + (((size_t)b * BN_T * p.Ho + gy) * p.Wo + gx) * 16 + co;
-                const size_t tstride = (size_t)p.Ho * p.Wo * 16;
+            const size_t tstride = (size_t)p.Ho * p.Wo * 16;
 #pragma unroll
-                for (int t = 0; t < BN_T; t++) dstp[t * tstride] = __float2half(o[t]);
+            for (int q = 0; q < 2; q++) {
+                float o[BN_T];
+                tmix4(tm, pooled[q], o);
+                const int owin = tile * 8 + 2 * g + q;
+                if (owin < nwin) {
+                    const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
+                    const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
+                    __half *dstp = p.out + (((size_t)b * BN_T * p.Ho + gy) * p.Wo + gx) * 16 + co;
+#pragma unroll
+                    for (int t = 0; t < BN_T; t++) dstp[t * tstride] = __float2half(o[t]);
+                }
             }
         }
     }
@@ -610,19 +620,23 @@ __global__ __launch_bounds__(256) void final_kernel(FinalArgs p) {
 // ------------------------------------------------------------------ host-side weight preparation
 void prep_enc0(const float *k, const float *bias, const float *gamma, const float *beta, const float *mean,
                const float *var, const float *w1, const float *w2, _Float16 *wfrag, float *epi) {
-    // 16x16x32 B fragment: lane l: n = l&15, k = 8*(l>>4)+j.  k <-> (kernel row, pixel, channel)
-    for (int ks = 0; ks < 2; ks++)
-        for (int l = 0; l < 64; l++)
-            for (int j = 0; j < 8; j++) {
-                const int n = l & 15, g = l >> 4;
-                const int px = 2 * (g & 1) + (j >> 2), ch = j & 3;
-                int ky = -1;
-                if (ks == 0) ky = g >> 1;
-                else if ((g >> 1) == 0) ky = 2;
-                float w = 0.f;
-                if (ky >= 0 && px < 3 && ch < 3) w = k[((ky * 3 + px) * 3 + ch) * 16 + n] / 6.0f;
-                wfrag[(ks * 64 + l) * 8 + j] = f2h(w);
-            }
+    // 16x16x32 B fragment: lane l: n = l&15, k = 8*(l>>4)+j.  k <-> (kernel row, pixel of the
+    // 4-pixel group, channel).  Set 0 serves even-x conv pixels (group = inputs x-2..x+1, so group
+    // pixel px carries tap kx = px-1), set 1 odd-x pixels (group = inputs x-1..x+2, kx = px).
+    for (int set = 0; set < 2; set++)
+        for (int ks = 0; ks < 2; ks++)
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 8; j++) {
+                    const int n = l & 15, g = l >> 4;
+                    const int px = 2 * (g & 1) + (j >> 2), ch = j & 3;
+                    const int kx = set == 0 ? px - 1 : px;
+                    int ky = -1;
+                    if (ks == 0) ky = g >> 1;
+                    else if ((g >> 1) == 0) ky = 2;
+                    float w = 0.f;
+                    if (ky >= 0 && kx >= 0 && kx < 3 && ch < 3) w = k[((ky * 3 + kx) * 3 + ch) * 16 + n] / 6.0f;
+                    wfrag[((set * 2 + ks) * 64 + l) * 8 + j] = f2h(w);
+                }
     for (int c = 0; c < 16; c++) {
         const float sc = gamma[c] / std::sqrt(var[c] + BN_EPS);
         epi[c] = bias[c];
@@ -722,7 +736,7 @@ int blobnet_prepare_mfma(covahip_ctx *ctx, covahip_blobnet *m, const float *w) {
     size_t off = 0;
     for (int i = 0; i < BN_LEVELS; i++) {
         const int ci = m->enc_c[i], co = m->enc_c[i + 1];
-        const size_t nfrag = (i == 0) ? 2 * 64 : (size_t)(co / 32) * (9 * ci / 16) * 64;
+        const size_t nfrag = (i == 0) ? 4 * 64 : (size_t)(co / 32) * (9 * ci / 16) * 64;
         pr->enc[i].wfrag = off; off = align256(off + nfrag * 16);
         pr->enc[i].epi = off; off = align256(off + (3 * co + 32) * sizeof(float));
     }
