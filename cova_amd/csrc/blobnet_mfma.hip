@@ -293,6 +293,7 @@ __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
                 float o[BN_T];
                 tmix4(tm, pooled[q], o);
                 const int owin = tile * 8 + 2 * g + q;
+                if ((p.dbg & 8) && o[0] + o[1] + o[2] + o[3] != 12345.678f) continue;
                 if (owin < nwin) {
                     const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
                     const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
