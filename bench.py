@@ -47,7 +47,7 @@ def kernel_macs_per_frame():
     dec_ci, dec_co = [128, 128, 64, 32], [64, 32, 16, 16]
     for j in range(3):
         out[f"dec{j}_mfma"] = hs[4 - j] * ws[4 - j] * 16 * dec_ci[j] * dec_co[j]
-    out["final_kernel"] = hs[1] * ws[1] * 16 * dec_ci[3] * dec_co[3] + H_MB * W_MB * 16
+    out["dec3_final_mfma"] = hs[1] * ws[1] * 16 * dec_ci[3] * dec_co[3] + H_MB * W_MB * 16
     return out
 
 

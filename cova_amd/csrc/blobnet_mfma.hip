@@ -55,7 +55,8 @@ struct DecPrep {
 struct Prepared {
     EncPrep enc[BN_LEVELS];
     DecPrep dec[BN_LEVELS - 1];
-    size_t final_w;  // fp32 [4][4][32] folded (convT 32->16) x (1x1 16->1) weights, then folded bias
+    size_t final_w;  // B fragments of the folded (convT 32->16) x (1x1 16->1) last block: [KSTEPS][64] x half8
+    size_t final_epi;  // folded bias (fp32)
     size_t zero;     // 256 zero bytes (LDS-DMA source for halo chunks)
     size_t total;
 };
@@ -148,23 +149,15 @@ struct EncArgs {
 struct DecArgs {
     const __half *up;    // [B][Hi][Wi][C1] or null
     const __half *skip;  // [B][Ts][Hi][Wi][C2], t = 0 used
-    __half *out;         // [B][Hd][Wd][COUT]
+    __half *out;         // [B][Hd][Wd][COUT]           (blocks 0..2)
+    float *logits;       // [B][Hd][Wd] or null         (last block)
+    uint8_t *mask;       // [B][Hd][Wd] or null         (last block)
     const half8 *wfrag;
-    const float *epi;
+    const float *epi;    // blocks 0..2: scale[COUT], shift'[COUT]; last block: folded bias
     int B, Hi, Wi, Hd, Wd, cy, cx, Ts;
-    int FPI;  // frames per work item
-    uint32_t mG, mGW, mRC;
+    int nbands;          // bands of grid rows per frame
+    uint32_t mNb, mGW, mRC;
     const void *zero;
-};
-
-struct FinalArgs {
-    const __half *up;    // [B][Hi][Wi][16]
-    const __half *skip;  // [B][T][Hi][Wi][16], t = 0
-    const float *wf;     // [4][4][32] + bias
-    float *logits;       // [B][Hd][Wd] or null
-    uint8_t *mask;       // [B][Hd][Wd] or null
-    int B, Hi, Wi, Hd, Wd, cy, cx;
-    uint32_t mG, mGW;
 };
 
 // ------------------------------------------------------------------ enc level 0
@@ -441,79 +434,88 @@ __global__ __launch_bounds__(WG, OCC) void enc_mfma(EncArgs p) {
     }
 }
 
-// ------------------------------------------------------------------ decoder blocks 0..2
-// relu -> convT(4x4, s2) -> crop -> BN as a 2x2-tap convolution over the (Hi+1)x(Wi+1)
-// grid with N = 4 parities x COUT.
+// ------------------------------------------------------------------ decoder blocks 0..3
+// relu -> convT(4x4, s2) -> crop -> BN as ONE 2x2-tap convolution over the (Hi+1)x(Wi+1) grid:
+//   out[2u+py-cy, 2v+px-cx][co] = sum_{a,b,c} in[u-a, v-b][c] * w[py+2a][px+2b][co][c]
+// with the four output parities stacked next to the output channels (4*COUT rows).
+// The MFMA runs "transposed": A = weight fragments (32 (parity,co) rows), B = activations
+// (32 grid positions), so a lane owns ONE position and its 16 accumulator registers are 4 groups
+// of 4 consecutive output channels -> one (u,v) decomposition per lane per tile and 8-byte packed
+// stores.  The last block (FINAL) has the final 1x1 conv folded in (no non-linearity between
+// them): 4 rows = the 4 parities, output = logit (+ threshold).
 template <int C>
 __device__ __forceinline__ int dec_swz(int xx) {
     constexpr int CPP = C / 8;
     return (xx / (16 / CPP)) % CPP;
 }
 
-template <int C1, int C2, int COUT>
-__global__ __launch_bounds__((4 * COUT / 32 > 4 ? 4 * COUT / 32 : 4) * 64, 2) void dec_mfma(DecArgs p) {
-    constexpr int C = C1 + C2, NTT = 4 * COUT / 32, NW = NTT > 4 ? NTT : 4, MG = NW / NTT;
+template <int C1, int C2, int COUT, bool FINAL>
+__global__ __launch_bounds__(((FINAL ? 1 : 4 * COUT / 32) > 4 ? 4 * COUT / 32 : 4) * 64, 2) void dec_mfma(DecArgs p) {
+    constexpr int C = C1 + C2, MT = FINAL ? 1 : 4 * COUT / 32, NW = MT > 4 ? MT : 4, PG = NW / MT;
     constexpr int KC = C / 16, KSTEPS = 4 * KC, CPP = C / 8, PS = C * 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntile = wave % NTT, mgroup = wave / NTT;
-    const int TR = p.Hi + 2, TC = p.Wi + 2;
-    const int fsz = TR * TC * PS;  // bytes per frame tile
-    const int GW = p.Wi + 1, GH = p.Hi + 1, G = GH * GW;
+    const int mtile = wave % MT, pgroup = wave / MT;
+    const int TC = p.Wi + 2;
+    const int GW = p.Wi + 1, GH = p.Hi + 1;
+    const int kh = lane >> 5;
 
-    half8 bf[KSTEPS];
+    half8 wf[KSTEPS];
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ks++) bf[ks] = p.wfrag[(ntile * KSTEPS + ks) * 64 + lane];
-    const int n = ntile * 32 + (lane & 31);
-    const int phase = n / COUT, co = n % COUT, py = phase >> 1, px = phase & 1;
-    const float bias = p.epi[co], scale = p.epi[COUT + co], shift = p.epi[2 * COUT + co];
+    for (int ks = 0; ks < KSTEPS; ks++) wf[ks] = p.wfrag[(mtile * KSTEPS + ks) * 64 + lane];
+    // per-register epilogue constants: reg 4g+j <-> row 8g + 4kh + j <-> (parity, co)
+    float es[16], eb[16];
+    if constexpr (!FINAL) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int n = mtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            es[r] = p.epi[n % COUT];
+            eb[r] = p.epi[COUT + n % COUT];
+        }
+    }
+    const float fbias = FINAL ? p.epi[0] : 0.f;
 
-    const int n_items = (p.B + p.FPI - 1) / p.FPI;
+    const int n_items = p.B * p.nbands;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int b0 = item * p.FPI;
-        const int nf = min(p.FPI, p.B - b0);
+        const int b = fdiv(item, p.mNb), band = item - b * p.nbands;
+        const int u0 = band * GH / p.nbands, u1 = (band + 1) * GH / p.nbands;
+        const int nu = u1 - u0;   // grid rows of this band; tile rows = nu + 1 (input rows u0-1 .. u1-1)
         __syncthreads();
-        // ---- stage nf frames with LDS-DMA: concat(up, skip[t=0]) with a zero border.  Both
-        // sources already hold relu'd values (the up branch is stored after its consumer's ReLU,
-        // the skips end in a ReLU), so no arithmetic is needed on the way in.
+        // ---- stage with LDS-DMA: concat(up, skip[t=0]); both sources hold relu'd values
         {
             const int RC = TC * CPP;
-            const int nchunk = TR * RC;
-            for (int f = 0; f < nf; f++) {
-                uint8_t *fb = smem + f * fsz;
-                const __half *su = p.up + ((size_t)(b0 + f)) * p.Hi * p.Wi * C1;  // unused when C1 == 0
-                const __half *ss = p.skip + ((size_t)(b0 + f) * p.Ts) * p.Hi * p.Wi * C2;
-                for (int s0 = wave * 64; s0 < nchunk; s0 += NW * 64) {
-                    const int sidx = s0 + lane;
-                    if (sidx < nchunk) {
-                        const int r = fdiv(sidx, p.mRC), within = sidx - r * RC;
-                        const int c = within / CPP, chp = within % CPP;
-                        const int cb = (chp ^ dec_swz<C>(c)) * 8;
-                        const int y = r - 1, x = c - 1;
-                        const void *src = p.zero;
-                        if (y >= 0 && y < p.Hi && x >= 0 && x < p.Wi) {
-                            const size_t pix = (size_t)y * p.Wi + x;
-                            if constexpr (C1 == 0) {
-                                src = ss + pix * C2 + cb;
-                            } else {
-                                if (cb < C1) src = su + pix * C1 + cb;
-                                else src = ss + pix * C2 + (cb - C1);
-                            }
+            const int nchunk = (nu + 1) * RC;
+            const __half *su = p.up + ((size_t)b) * p.Hi * p.Wi * C1;  // unused when C1 == 0
+            const __half *ss = p.skip + ((size_t)b * p.Ts) * p.Hi * p.Wi * C2;
+            for (int s0 = wave * 64; s0 < nchunk; s0 += NW * 64) {
+                const int sidx = s0 + lane;
+                if (sidx < nchunk) {
+                    const int r = fdiv(sidx, p.mRC), within = sidx - r * RC;
+                    const int c = within / CPP, chp = within % CPP;
+                    const int cb = (chp ^ dec_swz<C>(c)) * 8;
+                    const int y = u0 - 1 + r, x = c - 1;
+                    const void *src = p.zero;
+                    if (y >= 0 && y < p.Hi && x >= 0 && x < p.Wi) {
+                        const size_t pix = (size_t)y * p.Wi + x;
+                        if constexpr (C1 == 0) {
+                            src = ss + pix * C2 + cb;
+                        } else {
+                            if (cb < C1) src = su + pix * C1 + cb;
+                            else src = ss + pix * C2 + (cb - C1);
                         }
-                        glds16(src, fb + s0 * 16);
                     }
+                    glds16(src, smem + s0 * 16);
                 }
             }
         }
         __syncthreads();
-        // ---- compute over the flattened (frame, u, v) positions
-        const int npos = nf * G;
+        // ---- compute over the band's flattened (u, v) positions
+        const int npos = nu * GW;
         const int ntiles = (npos + 31) / 32;
-        const int m = lane & 31, kh = lane >> 5;
-        for (int tile = mgroup; tile < ntiles; tile += MG) {
-            const int q = min(tile * 32 + m, npos - 1);
-            const int f = fdiv(q, p.mG), qq = q - f * G;
-            const int u = fdiv(qq, p.mGW), v = qq - u * GW;
+        for (int tile = pgroup; tile < ntiles; tile += PG) {
+            const int q = tile * 32 + (lane & 31);
+            const int qc = min(q, npos - 1);
+            const int ul = fdiv(qc, p.mGW), v = qc - ul * GW;   // ul = u - u0
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[r] = 0.f;
@@ -521,101 +523,48 @@ __global__ __launch_bounds__((4 * COUT / 32 > 4 ? 4 * COUT / 32 : 4) * 64, 2) vo
             for (int a = 0; a < 2; a++)
 #pragma unroll
                 for (int bb = 0; bb < 2; bb++) {
-                    const int yy = u - a + 1, xx = v - bb + 1;
-                    const int pbase = f * fsz + (yy * TC + xx) * PS;
+                    const int yy = ul + 1 - a, xx = v + 1 - bb;   // tile coordinates of input (u-a, v-b)
+                    const int pbase = (yy * TC + xx) * PS;
                     const int s = dec_swz<C>(xx);
 #pragma unroll
                     for (int kc = 0; kc < KC; kc++) {
                         const half8 av = *reinterpret_cast<const half8 *>(smem + pbase + (((kc * 2 + kh) ^ s) * 16));
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bf[(a * 2 + bb) * KC + kc], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[(a * 2 + bb) * KC + kc], av, acc, 0, 0, 0);
                     }
                 }
-            // ---- epilogue: reg r -> row (r&3) + 8*(r>>2) + 4*kh; rows 4 apart are consecutive
-            // positions, so one (f,u,v) decomposition per group of four and increments after
+            if (q >= npos) continue;
+            const int u = u0 + ul;
+            if constexpr (FINAL) {
+                // rows 0..3 = parities (py,px) = (r>>1, r&1): only the kh == 0 half holds them
+                if (kh == 0) {
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int oq0 = tile * 32 + 8 * g + 4 * kh;
-                int of = fdiv(oq0, p.mG);
-                const int oqq = oq0 - of * G;
-                int ou = fdiv(oqq, p.mGW);
-                int ov = oqq - ou * GW;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (oq0 + j < npos) {
-                        const int Y = 2 * ou + py - p.cy, X = 2 * ov + px - p.cx;
-                        if (Y >= 0 && Y < p.Hd && X >= 0 && X < p.Wd)
-                            p.out[((((size_t)(b0 + of)) * p.Hd + Y) * p.Wd + X) * COUT + co] =
-                                __float2half(fmaxf((acc[4 * g + j] + bias) * scale + shift, 0.f));
-                    }
-                    ov++;
-                    if (ov == GW) {
-                        ov = 0;
-                        ou++;
-                        if (ou == GH) {
-                            ou = 0;
-                            of++;
+                    for (int r = 0; r < 4; r++) {
+                        const int Y = 2 * u + (r >> 1) - p.cy, X = 2 * v + (r & 1) - p.cx;
+                        if (Y >= 0 && Y < p.Hd && X >= 0 && X < p.Wd) {
+                            const size_t o = ((size_t)b * p.Hd + Y) * p.Wd + X;
+                            const float l = acc[r] + fbias;
+                            if (p.logits) p.logits[o] = l;
+                            if (p.mask) p.mask[o] = l > 0.f ? 1 : 0;
                         }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int n0 = mtile * 32 + 8 * g + 4 * kh;
+                    const int phase = n0 / COUT, co0 = n0 % COUT;
+                    const int Y = 2 * u + (phase >> 1) - p.cy, X = 2 * v + (phase & 1) - p.cx;
+                    if (Y >= 0 && Y < p.Hd && X >= 0 && X < p.Wd) {
+                        half4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            o[j] = (_Float16)fmaxf(acc[4 * g + j] * es[4 * g + j] + eb[4 * g + j], 0.f);
+                        *reinterpret_cast<half4 *>(p.out + (((size_t)b * p.Hd + Y) * p.Wd + X) * COUT + co0) = o;
                     }
                 }
             }
         }
     }
-}
-
-// ------------------------------------------------------------------ last block + final 1x1 + threshold
-// One thread per position (u,v) of the (Hi+1)x(Wi+1) grid: reads the 2x2 input
-// neighbourhood once and produces the four output parities (vector ALU, fp32).
-__global__ __launch_bounds__(256) void final_kernel(FinalArgs p) {
-    const int GW = p.Wi + 1, G = (p.Hi + 1) * GW;
-    const int b = blockIdx.y;
-    const int qq = blockIdx.x * blockDim.x + threadIdx.x;
-    if (qq >= G) return;
-    const int u = (int)fdiv((uint32_t)qq, p.mGW), v = qq - u * GW;
-    float acc[4];
-    const float fb = p.wf[512];
-#pragma unroll
-    for (int k = 0; k < 4; k++) acc[k] = fb;
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int bb = 0; bb < 2; bb++) {
-            const int iy = u - a, ix = v - bb;
-            if (iy < 0 || iy >= p.Hi || ix < 0 || ix >= p.Wi) continue;
-            const half8 *pu = reinterpret_cast<const half8 *>(p.up + (((size_t)b * p.Hi + iy) * p.Wi + ix) * 16);
-            const half8 *ps =
-                reinterpret_cast<const half8 *>(p.skip + ((((size_t)b * BN_T) * p.Hi + iy) * p.Wi + ix) * 16);
-            float x[32];
-            const half8 v0 = pu[0], v1 = pu[1], v2 = ps[0], v3 = ps[1];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                x[j] = fmaxf((float)v0[j], 0.f);
-                x[8 + j] = fmaxf((float)v1[j], 0.f);
-                x[16 + j] = fmaxf((float)v2[j], 0.f);
-                x[24 + j] = fmaxf((float)v3[j], 0.f);
-            }
-#pragma unroll
-            for (int py = 0; py < 2; py++)
-#pragma unroll
-                for (int px = 0; px < 2; px++) {
-                    const float *w = p.wf + ((py + 2 * a) * 4 + (px + 2 * bb)) * 32;
-                    float s = 0.f;
-#pragma unroll
-                    for (int c = 0; c < 32; c++) s += w[c] * x[c];
-                    acc[py * 2 + px] += s;
-                }
-        }
-#pragma unroll
-    for (int py = 0; py < 2; py++)
-#pragma unroll
-        for (int px = 0; px < 2; px++) {
-            const int Y = 2 * u + py - p.cy, X = 2 * v + px - p.cx;
-            if (Y >= 0 && Y < p.Hd && X >= 0 && X < p.Wd) {
-                const size_t o = ((size_t)b * p.Hd + Y) * p.Wd + X;
-                const float l = acc[py * 2 + px];
-                if (p.logits) p.logits[o] = l;
-                if (p.mask) p.mask[o] = l > 0.f ? 1 : 0;
-            }
-        }
 }
 
 // ------------------------------------------------------------------ host-side weight preparation
@@ -684,12 +633,36 @@ void prep_dec(int cin, int cout, const float *k, const float *bias, const float 
                     wfrag[(((size_t)nt * KSTEPS + ks) * 64 + l) * 8 + j] =
                         f2h(k[(((size_t)ky * 4 + kx) * cout + co) * cin + c]);
                 }
+    // epilogue: relu((acc + bias) * scale + shift) = relu(acc * scale + (bias * scale + shift))
     for (int c = 0; c < cout; c++) {
         const float sc = gamma[c] / std::sqrt(var[c] + BN_EPS);
-        epi[c] = bias[c];
-        epi[cout + c] = sc;
-        epi[2 * cout + c] = beta[c] - mean[c] * sc;
+        epi[c] = sc;
+        epi[cout + c] = bias[c] * sc + (beta[c] - mean[c] * sc);
     }
+}
+
+// last block folded with the final 1x1 conv: logit = sum_c fk[c]*(convT_c(x) + b_c) + fb.
+// Rows 0..3 of the single 32-row tile are the four parities, the rest are zero.
+void prep_final(int cin, int cout, const float *k, const float *bias, const float *fk, const float *fb,
+                _Float16 *wfrag, float *epi) {
+    const int KC = cin / 16, KSTEPS = 4 * KC;
+    for (int ks = 0; ks < KSTEPS; ks++)
+        for (int l = 0; l < 64; l++)
+            for (int j = 0; j < 8; j++) {
+                const int tap = ks / KC, kc = ks % KC, a = tap >> 1, bb = tap & 1;
+                const int c = kc * 16 + 8 * (l >> 5) + j, n = l & 31;
+                float w = 0.f;
+                if (n < 4) {
+                    const int ky = (n >> 1) + 2 * a, kx = (n & 1) + 2 * bb;
+                    double sacc = 0.0;
+                    for (int o = 0; o < cout; o++) sacc += (double)fk[o] * k[(((size_t)ky * 4 + kx) * cout + o) * cin + c];
+                    w = (float)sacc;
+                }
+                wfrag[((size_t)ks * 64 + l) * 8 + j] = f2h(w);
+            }
+    double bsum = fb[0];
+    for (int o = 0; o < cout; o++) bsum += (double)fk[o] * bias[o];
+    epi[0] = (float)bsum;
 }
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -747,7 +720,8 @@ int blobnet_prepare_mfma(covahip_ctx *ctx, covahip_blobnet *m, const float *w) {
         pr->dec[j].wfrag = off; off = align256(off + nfrag * 16);
         pr->dec[j].epi = off; off = align256(off + 3 * co * sizeof(float));
     }
-    pr->final_w = off; off = align256(off + 513 * sizeof(float));
+    pr->final_w = off; off = align256(off + (size_t)(4 * m->dec_ci[3] / 16) * 64 * 16);
+    pr->final_epi = off; off = align256(off + 16 * sizeof(float));
     pr->zero = off; off = align256(off + 256);
     pr->total = off;
 
@@ -761,20 +735,8 @@ int blobnet_prepare_mfma(covahip_ctx *ctx, covahip_blobnet *m, const float *w) {
     for (int j = 0; j < BN_LEVELS - 1; j++)
         prep_dec(m->dec_ci[j], m->dec_co[j], hd[j].k, hd[j].b, hd[j].gamma, hd[j].beta, hd[j].mean, hd[j].var,
                  (_Float16 *)(host.data() + pr->dec[j].wfrag), (float *)(host.data() + pr->dec[j].epi));
-    {   // fold: logit = sum_c fk[c] * (convT_c(x) + b_c) + fb
-        float *wf = (float *)(host.data() + pr->final_w);
-        const int ci = m->dec_ci[3], co = m->dec_co[3];
-        for (int ky = 0; ky < 4; ky++)
-            for (int kx = 0; kx < 4; kx++)
-                for (int c = 0; c < ci; c++) {
-                    double s = 0.0;
-                    for (int o = 0; o < co; o++) s += (double)fk[o] * hd[3].k[(((size_t)ky * 4 + kx) * co + o) * ci + c];
-                    wf[(ky * 4 + kx) * 32 + c] = (float)s;
-                }
-        double bsum = fb[0];
-        for (int o = 0; o < co; o++) bsum += (double)fk[o] * hd[3].b[o];
-        wf[512] = (float)bsum;
-    }
+    prep_final(m->dec_ci[3], m->dec_co[3], hd[3].k, hd[3].b, fk, fb, (_Float16 *)(host.data() + pr->final_w),
+               (float *)(host.data() + pr->final_epi));
     COVAHIP_CHECK_HIP(ctx, hipMalloc(&m->d_prepared, off));
     COVAHIP_CHECK_HIP(ctx, hipMemcpy(m->d_prepared, host.data(), off, hipMemcpyHostToDevice));
     m->prepared_bytes = off;
@@ -859,55 +821,55 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
         }
         COVAHIP_CHECK_HIP(ctx, hipGetLastError());
     }
-    // ---------------- decoder blocks 0..2
-    for (int j = 0; j < BN_LEVELS - 1; j++) {
+    // ---------------- decoder blocks 0..3 (the last one carries the folded final conv + threshold)
+    for (int j = 0; j < BN_LEVELS; j++) {
         const BnLevelGeom in = m->lv[BN_LEVELS - j], out = m->lv[BN_LEVELS - 1 - j];
+        const bool last = j == BN_LEVELS - 1;
         DecArgs a;
         a.up = j == 0 ? nullptr : m->dact[j - 1];
         a.skip = m->act[BN_LEVELS - j];
-        a.out = m->dact[j];
-        a.wfrag = (const half8 *)(prep + pr->dec[j].wfrag); a.epi = (const float *)(prep + pr->dec[j].epi);
+        a.out = last ? nullptr : m->dact[j];
+        a.logits = last ? d_logits : nullptr;
+        a.mask = last ? d_mask : nullptr;
+        a.wfrag = (const half8 *)(prep + (last ? pr->final_w : pr->dec[j].wfrag));
+        a.epi = (const float *)(prep + (last ? pr->final_epi : pr->dec[j].epi));
         a.B = batch; a.Hi = in.H; a.Wi = in.W; a.Hd = out.H; a.Wd = out.W; a.cy = m->dec_cy[j]; a.cx = m->dec_cx[j];
         a.Ts = j == 0 ? 1 : BN_T;
-        const size_t fbytes = (size_t)(in.H + 2) * (in.W + 2) * m->dec_ci[j] * 2;
-        if (fbytes > 160 * 1024 - 256) return COVAHIP_ERR_UNSUPPORTED;
-        a.FPI = std::max<int>(1, (int)((72 * 1024) / fbytes));
-        a.mG = magic((in.H + 1) * (in.W + 1)); a.mGW = magic(in.W + 1);
+        const int GH = in.H + 1;
+        const size_t row_bytes = (size_t)(in.W + 2) * m->dec_ci[j] * 2;
+        // bands of grid rows: LDS tile (rows+1 input rows) <= ~72 KB and >= 2 work items per CU
+        int nbands = 1;
+        while (nbands < GH && (((size_t)((GH + nbands - 1) / nbands) + 1) * row_bytes > 72 * 1024 ||
+                               (long long)batch * nbands < 2LL * num_cu))
+            nbands++;
+        const size_t lds = ((size_t)((GH + nbands - 1) / nbands) + 1) * row_bytes;
+        if (lds > 160 * 1024 - 256) return COVAHIP_ERR_UNSUPPORTED;
+        a.nbands = nbands; a.mNb = magic(nbands); a.mGW = magic(in.W + 1);
         a.mRC = magic((in.W + 2) * (m->dec_ci[j] / 8)); a.zero = prep + pr->zero;
-        const size_t lds = fbytes * a.FPI;
-        const int items = (batch + a.FPI - 1) / a.FPI;
+        const int items = batch * nbands;
         const int grid = std::min(items, 2 * num_cu);
         int rc;
         if (j == 0) {
-            rc = set_lds(ctx, dec_mfma<0, 128, 64>, lds);
+            rc = set_lds(ctx, dec_mfma<0, 128, 64, false>, lds);
             if (rc) return rc;
             ProfScope ps(ctx, "dec0_mfma");
-            hipLaunchKernelGGL((dec_mfma<0, 128, 64>), dim3(grid), dim3(512), lds, ctx->stream, a);
+            hipLaunchKernelGGL((dec_mfma<0, 128, 64, false>), dim3(grid), dim3(512), lds, ctx->stream, a);
         } else if (j == 1) {
-            rc = set_lds(ctx, dec_mfma<64, 64, 32>, lds);
+            rc = set_lds(ctx, dec_mfma<64, 64, 32, false>, lds);
             if (rc) return rc;
             ProfScope ps(ctx, "dec1_mfma");
-            hipLaunchKernelGGL((dec_mfma<64, 64, 32>), dim3(grid), dim3(256), lds, ctx->stream, a);
-        } else {
-            rc = set_lds(ctx, dec_mfma<32, 32, 16>, lds);
+            hipLaunchKernelGGL((dec_mfma<64, 64, 32, false>), dim3(grid), dim3(256), lds, ctx->stream, a);
+        } else if (j == 2) {
+            rc = set_lds(ctx, dec_mfma<32, 32, 16, false>, lds);
             if (rc) return rc;
             ProfScope ps(ctx, "dec2_mfma");
-            hipLaunchKernelGGL((dec_mfma<32, 32, 16>), dim3(grid), dim3(256), lds, ctx->stream, a);
+            hipLaunchKernelGGL((dec_mfma<32, 32, 16, false>), dim3(grid), dim3(256), lds, ctx->stream, a);
+        } else {
+            rc = set_lds(ctx, dec_mfma<16, 16, 16, true>, lds);
+            if (rc) return rc;
+            ProfScope ps(ctx, "dec3_final_mfma");
+            hipLaunchKernelGGL((dec_mfma<16, 16, 16, true>), dim3(grid), dim3(256), lds, ctx->stream, a);
         }
-        COVAHIP_CHECK_HIP(ctx, hipGetLastError());
-    }
-    // ---------------- last block + final conv + threshold
-    {
-        const BnLevelGeom in = m->lv[1], out = m->lv[0];
-        FinalArgs a;
-        a.up = m->dact[2]; a.skip = m->act[1]; a.wf = (const float *)(prep + pr->final_w);
-        a.logits = d_logits; a.mask = d_mask;
-        a.B = batch; a.Hi = in.H; a.Wi = in.W; a.Hd = out.H; a.Wd = out.W; a.cy = m->dec_cy[3]; a.cx = m->dec_cx[3];
-        a.mG = magic((in.H + 1) * (in.W + 1)); a.mGW = magic(in.W + 1);
-        const int G = (in.H + 1) * (in.W + 1);
-        if (batch > 65535) return COVAHIP_ERR_UNSUPPORTED;
-        ProfScope ps(ctx, "final_kernel");
-        hipLaunchKernelGGL(final_kernel, dim3((G + 255) / 256, batch), dim3(256), 0, ctx->stream, a);
         COVAHIP_CHECK_HIP(ctx, hipGetLastError());
     }
     return COVAHIP_OK;
