@@ -81,6 +81,7 @@ PROTOTYPES = {
     "covahip_blobnet_forward": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int]),
     "covahip_blobnet_macs_per_frame": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "covahip_blobnet_set_impl": (C.c_int, [_P, C.c_int]),
+    "covahip_blobnet_set_overlap": (C.c_int, [_P, C.c_int]),
     "covahip_bboxcc": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int]),
     "covahip_filter_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int]),
     "covahip_boxes_to_bbox": (None, [_P, C.c_int, _P]),

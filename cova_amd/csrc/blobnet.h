@@ -37,6 +37,7 @@ struct covahip_blobnet {
     size_t prepared_bytes = 0;
     struct Prepared *prep = nullptr;
     int impl = 1;  // 0 = naive direct kernels, 1 = MFMA kernels
+    int overlap = 0;  // split a batch in two halves on two HIP streams (off by default: no gain measured at b=256)
     int64_t macs_per_frame = 0;
 };
 
@@ -46,5 +47,7 @@ int blobnet_forward_naive(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d
 // blobnet_mfma.hip
 int blobnet_prepare_mfma(covahip_ctx *ctx, covahip_blobnet *m, const float *h_weights);
 void blobnet_release_mfma(covahip_ctx *ctx, covahip_blobnet *m);
+// frame0: index of the first workspace frame slot to use (two half-batches can be in flight on
+// two streams, each in its own slice of the activation workspace)
 int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_stack, int batch, float *d_logits,
-                         uint8_t *d_mask);
+                         uint8_t *d_mask, int frame0);

@@ -71,14 +71,53 @@ int covahip_blobnet_geometry(covahip_ctx *ctx, int *h, int *w) {
     return COVAHIP_OK;
 }
 
-int covahip_blobnet_forward_dev(covahip_ctx *ctx, const uint8_t *d_stack, int batch, float *d_logits,
-                                uint8_t *d_mask) {
+// BlobNet forward (+ optionally bboxcc) on device pointers.  With the MFMA path and a large enough
+// batch the work is split in two halves issued on two HIP streams: frames are independent, so the
+// launch gaps, fill/drain tails and latency-bound phases of one half overlap with the other half.
+static int filter_dev(covahip_ctx *ctx, const uint8_t *d_stack, int batch, float *d_logits, uint8_t *d_mask,
+                      bool with_cc, int area_thresh, covahip_box *d_boxes, int32_t *d_counts, int max_boxes) {
     covahip_blobnet *m = ctx->blobnet;
     if (!m) return COVAHIP_ERR_NOT_LOADED;
     if (batch > m->max_batch) return COVAHIP_ERR_INVALID_ARG;
     if (batch == 0) return COVAHIP_OK;
-    if (m->impl == 0) return blobnet_forward_naive(ctx, m, d_stack, batch, d_logits, d_mask);
-    return blobnet_forward_mfma(ctx, m, d_stack, batch, d_logits, d_mask);
+    const size_t hw = (size_t)m->H * m->W;
+    auto run = [&](int f0, int n) -> int {
+        const uint8_t *st = d_stack + (size_t)f0 * BN_T * hw * 4;
+        float *lg = d_logits ? d_logits + (size_t)f0 * hw : nullptr;
+        uint8_t *mk = d_mask ? d_mask + (size_t)f0 * hw : nullptr;
+        int rc;
+        if (m->impl == 0) {
+            if (f0 != 0) return COVAHIP_ERR_INVALID_ARG;
+            rc = blobnet_forward_naive(ctx, m, st, n, lg, mk);
+        } else {
+            rc = blobnet_forward_mfma(ctx, m, st, n, lg, mk, f0);
+        }
+        if (rc) return rc;
+        if (with_cc)
+            rc = covahip_bboxcc_launch(ctx, mk, n, m->H, m->W, area_thresh, d_boxes + (size_t)f0 * max_boxes,
+                                       d_counts + f0, max_boxes);
+        return rc;
+    };
+    const bool split = m->impl == 1 && m->overlap && batch >= 32 && ctx->stream2 && !ctx->profile_all();
+    if (!split) return run(0, batch);
+    const int h0 = (batch + 1) / 2;
+    hipStream_t main_stream = ctx->stream;
+    COVAHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_fork, main_stream));
+    COVAHIP_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    int rc = run(0, h0);
+    if (rc) return rc;
+    ctx->stream = ctx->stream2;  // launches of the second half go to the second stream
+    rc = run(h0, batch - h0);
+    ctx->stream = main_stream;
+    if (rc) return rc;
+    COVAHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+    COVAHIP_CHECK_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
+    return COVAHIP_OK;
+}
+
+int covahip_blobnet_forward_dev(covahip_ctx *ctx, const uint8_t *d_stack, int batch, float *d_logits,
+                                uint8_t *d_mask) {
+    return filter_dev(ctx, d_stack, batch, d_logits, d_mask, false, 0, nullptr, nullptr, 0);
 }
 
 extern "C" {
@@ -159,6 +198,12 @@ int covahip_blobnet_macs_per_frame(covahip_ctx *ctx, int64_t *macs) {
     return COVAHIP_OK;
 }
 
+int covahip_blobnet_set_overlap(covahip_ctx *ctx, int on) {
+    if (!ctx || !ctx->blobnet) return COVAHIP_ERR_NOT_LOADED;
+    ctx->blobnet->overlap = on != 0;
+    return COVAHIP_OK;
+}
+
 int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl) {
     if (!ctx || !ctx->blobnet) return COVAHIP_ERR_NOT_LOADED;
     if (impl != 0 && impl != 1) return COVAHIP_ERR_INVALID_ARG;
@@ -190,9 +235,7 @@ int covahip_filter_forward(covahip_ctx *ctx, const uint8_t *rgba_stack, int batc
             if (rc) return rc;
             d_mask = (uint8_t *)ctx->cc_scratch;
         }
-        int rc = covahip_blobnet_forward_dev(ctx, rgba_stack, batch, logits, d_mask);
-        if (rc) return rc;
-        return covahip_bboxcc_launch(ctx, d_mask, batch, m->H, m->W, area_thresh, boxes, counts, max_boxes);
+        return filter_dev(ctx, rgba_stack, batch, logits, d_mask, true, area_thresh, boxes, counts, max_boxes);
     }
     if (mem_kind != COVAHIP_MEM_HOST) return COVAHIP_ERR_INVALID_ARG;
     int rc = covahip_ensure_buffer(ctx, &ctx->stage_in, &ctx->stage_in_bytes, in_bytes);
@@ -206,9 +249,8 @@ int covahip_filter_forward(covahip_ctx *ctx, const uint8_t *rgba_stack, int batc
     covahip_box *d_boxes = (covahip_box *)(base + al(mask_bytes) + al(logit_bytes));
     int32_t *d_counts = (int32_t *)(base + al(mask_bytes) + al(logit_bytes) + al(box_bytes));
     COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(ctx->stage_in, rgba_stack, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-    rc = covahip_blobnet_forward_dev(ctx, (const uint8_t *)ctx->stage_in, batch, logits ? d_logits : nullptr, d_mask);
-    if (rc) return rc;
-    rc = covahip_bboxcc_launch(ctx, d_mask, batch, m->H, m->W, area_thresh, d_boxes, d_counts, max_boxes);
+    rc = filter_dev(ctx, (const uint8_t *)ctx->stage_in, batch, logits ? d_logits : nullptr, d_mask, true, area_thresh,
+                    d_boxes, d_counts, max_boxes);
     if (rc) return rc;
     if (logits) COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(logits, d_logits, logit_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (mask) COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(mask, d_mask, mask_bytes, hipMemcpyDeviceToHost, ctx->stream));

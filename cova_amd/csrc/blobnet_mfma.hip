@@ -309,9 +309,10 @@ __device__ __forceinline__ int enc_swz(int xx, int yy) {
     return ((xx / XS) % (CPP / 2)) | ((yy & 1) * (CPP / 2));
 }
 
-template <int CIN, int COUT, int TPAR, int OCC>
-__global__ __launch_bounds__(WG, OCC) void enc_mfma(EncArgs p) {
-    constexpr int NT = COUT / 32, MG = (WG / 64) / NT, KC = CIN / 16, KSTEPS = 9 * KC;
+template <int CIN, int COUT, int TPAR, int OCC, int NWV>
+__global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
+    constexpr int WGS = NWV * 64;
+    constexpr int NT = COUT / 32, MG = NWV / NT, KC = CIN / 16, KSTEPS = 9 * KC;
     constexpr int CPP = CIN / 8, PS = CIN * 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(WG, OCC) void enc_mfma(EncArgs p) {
             for (int t = 0; t < BN_T; t++) {
                 uint8_t *tbase = smem + t * tsz;
                 const __half *tsrc = fbase + (size_t)t * p.H * p.W * CIN;
-                for (int s0 = wave * 64; s0 < nchunk; s0 += WG) {
+                for (int s0 = wave * 64; s0 < nchunk; s0 += WGS) {
                     const int sidx = s0 + lane;
                     if (sidx < nchunk) {
                         const int r = fdiv(sidx, p.mRC), within = sidx - r * RC;
@@ -752,7 +753,18 @@ void blobnet_release_mfma(covahip_ctx *, covahip_blobnet *m) {
 }
 
 int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_stack, int batch, float *d_logits,
-                         uint8_t *d_mask) {
+                         uint8_t *d_mask, int frame0) {
+    // workspace slices of this call
+    __half *act[BN_LEVELS + 1] = {};
+    __half *dact[BN_LEVELS] = {};
+    for (int i = 1; i <= BN_LEVELS; i++) {
+        const size_t tt = (i == BN_LEVELS) ? 1 : BN_T;
+        act[i] = m->act[i] + (size_t)frame0 * tt * m->lv[i].H * m->lv[i].W * m->enc_c[i];
+    }
+    for (int j = 0; j < BN_LEVELS - 1; j++) {
+        const BnLevelGeom o = m->lv[BN_LEVELS - 1 - j];
+        dact[j] = m->dact[j] + (size_t)frame0 * o.H * o.W * m->dec_co[j];
+    }
     const uint8_t *prep = (const uint8_t *)m->d_prepared;
     const Prepared *pr = m->prep;
     const int num_cu = ctx->props.multiProcessorCount;
@@ -781,7 +793,7 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
         const int grid = std::min(items, (i == BN_LEVELS - 1 ? 1 : 2) * num_cu);
         if (i == 0) {
             Enc0Args a;
-            a.in = d_stack; a.out = m->act[1];
+            a.in = d_stack; a.out = act[1];
             a.wfrag = (const half8 *)(prep + pr->enc[0].wfrag); a.epi = (const float *)(prep + pr->enc[0].epi);
             a.B = batch; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.Ho = m->lv[1].H; a.Wo = m->lv[1].W;
             a.oy = H & 1; a.ox = W & 1; a.RB = RB; a.nbands = nbands; a.TR = RB + 2; a.TC = TC;
@@ -794,7 +806,7 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
             hipLaunchKernelGGL(enc0_mfma, dim3(grid), dim3(WG0), lds, ctx->stream, a);
         } else {
             EncArgs a;
-            a.in = m->act[i]; a.out = m->act[i + 1];
+            a.in = act[i]; a.out = act[i + 1];
             a.wfrag = (const half8 *)(prep + pr->enc[i].wfrag); a.epi = (const float *)(prep + pr->enc[i].epi);
             a.B = batch; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.Ho = m->lv[i + 1].H; a.Wo = m->lv[i + 1].W;
             a.oy = H & 1; a.ox = W & 1; a.To = (i == BN_LEVELS - 1) ? 1 : BN_T;
@@ -803,20 +815,20 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
             { const char *e = std::getenv("COVAHIP_DBG"); a.dbg = e ? std::atoi(e) : 0; }
             int rc = COVAHIP_OK;
             if (i == 1) {
-                rc = set_lds(ctx, enc_mfma<16, 32, 4, 2>, lds);
+                rc = set_lds(ctx, enc_mfma<16, 32, 2, 4, 8>, lds);
                 if (rc) return rc;
                 ProfScope ps(ctx, "enc1_mfma");
-                hipLaunchKernelGGL((enc_mfma<16, 32, 4, 2>), dim3(grid), dim3(WG), lds, ctx->stream, a);
+                hipLaunchKernelGGL((enc_mfma<16, 32, 2, 4, 8>), dim3(grid), dim3(512), lds, ctx->stream, a);
             } else if (i == 2) {
-                rc = set_lds(ctx, enc_mfma<32, 64, 4, 2>, lds);
+                rc = set_lds(ctx, enc_mfma<32, 64, 4, 2, 4>, lds);
                 if (rc) return rc;
                 ProfScope ps(ctx, "enc2_mfma");
-                hipLaunchKernelGGL((enc_mfma<32, 64, 4, 2>), dim3(grid), dim3(WG), lds, ctx->stream, a);
+                hipLaunchKernelGGL((enc_mfma<32, 64, 4, 2, 4>), dim3(grid), dim3(WG), lds, ctx->stream, a);
             } else {
-                rc = set_lds(ctx, enc_mfma<64, 128, 4, 1>, lds);
+                rc = set_lds(ctx, enc_mfma<64, 128, 2, 2, 8>, lds);
                 if (rc) return rc;
                 ProfScope ps(ctx, "enc3_mfma");
-                hipLaunchKernelGGL((enc_mfma<64, 128, 4, 1>), dim3(grid), dim3(WG), lds, ctx->stream, a);
+                hipLaunchKernelGGL((enc_mfma<64, 128, 2, 2, 8>), dim3(grid), dim3(512), lds, ctx->stream, a);
             }
         }
         COVAHIP_CHECK_HIP(ctx, hipGetLastError());
@@ -826,9 +838,9 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
         const BnLevelGeom in = m->lv[BN_LEVELS - j], out = m->lv[BN_LEVELS - 1 - j];
         const bool last = j == BN_LEVELS - 1;
         DecArgs a;
-        a.up = j == 0 ? nullptr : m->dact[j - 1];
-        a.skip = m->act[BN_LEVELS - j];
-        a.out = last ? nullptr : m->dact[j];
+        a.up = j == 0 ? nullptr : dact[j - 1];
+        a.skip = act[BN_LEVELS - j];
+        a.out = last ? nullptr : dact[j];
         a.logits = last ? d_logits : nullptr;
         a.mask = last ? d_mask : nullptr;
         a.wfrag = (const half8 *)(prep + (last ? pr->final_w : pr->dec[j].wfrag));

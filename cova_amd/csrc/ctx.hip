@@ -53,6 +53,9 @@ int covahip_ctx_create(int device_id, covahip_ctx **out) {
         hipEventCreate(&ctx->t_start[i]);
         hipEventCreate(&ctx->t_stop[i]);
     }
+    hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+    hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
+    hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
     *out = ctx;
     return COVAHIP_OK;
 }
@@ -61,6 +64,7 @@ void covahip_ctx_destroy(covahip_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
     covahip_blobnet_destroy(ctx);
     for (int i = 0; i < 16; i++) {
         hipEventDestroy(ctx->t_start[i]);
@@ -78,6 +82,9 @@ void covahip_ctx_destroy(covahip_ctx *ctx) {
     if (ctx->stage_out) hipFree(ctx->stage_out);
     if (ctx->cc_scratch) hipFree(ctx->cc_scratch);
     if (ctx->pinned) hipHostFree(ctx->pinned);
+    if (ctx->stream2) hipStreamDestroy(ctx->stream2);
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -14,6 +14,8 @@ struct covahip_blobnet;  // blobnet.hip
 struct covahip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;      // second stream for the half-batch overlap
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string last_hip_error;
     hipDeviceProp_t props{};
     // timers
@@ -40,6 +42,8 @@ struct covahip_ctx {
     void *cc_scratch = nullptr;
     size_t cc_scratch_bytes = 0;
     covahip_blobnet *blobnet = nullptr;
+    // per-kernel timing of EVERY kernel is only meaningful without cross-stream overlap
+    bool profile_all() const { return profile && profile_filter.empty(); }
 };
 
 #define COVAHIP_CHECK_HIP(ctx, expr)                                                        \

@@ -159,6 +159,9 @@ class BlobNetInfer:
     def set_impl(self, impl: str):
         L.check(self._lib.covahip_blobnet_set_impl(self.ctx.handle, {"naive": 0, "mfma": 1}[impl]), "set_impl")
 
+    def set_overlap(self, on: bool):
+        L.check(self._lib.covahip_blobnet_set_overlap(self.ctx.handle, int(on)), "set_overlap")
+
     @property
     def macs_per_frame(self) -> int:
         v = C.c_int64()

@@ -118,6 +118,9 @@ int covahip_blobnet_macs_per_frame(covahip_ctx *ctx, int64_t *macs);
 /* Debug switch: 1 = MFMA kernels (default), 0 = direct one-thread-per-output kernels
  * (on-GPU bring-up path; also selectable with COVAHIP_BLOBNET_IMPL=naive). */
 int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl);
+/* 1: batches >= 32 are issued as two half-batches on two HIP streams (frames are independent);
+ * 0 (default): one stream.  Per-kernel profiling of all kernels forces 0. */
+int covahip_blobnet_set_overlap(covahip_ctx *ctx, int on);
 
 /* ------------------------------------------------------------------- bboxcc
  * Replaces regionprops() (cova-rs/gst-plugins/src/bboxcc/process.rs:5-49): 8-connected
