@@ -184,8 +184,9 @@ __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
     const int n_items = p.B * p.nbands;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int b = fdiv(item, p.mNb), band = item - b * p.nbands;
-        const int y0 = band * p.RB;
-        const int rows = min(p.RB, 2 * p.Hp - y0);
+        // balanced bands of whole pool-window rows
+        const int y0 = 2 * ((band * p.Hp) / p.nbands);
+        const int rows = 2 * (((band + 1) * p.Hp) / p.nbands) - y0;
         const int n2 = rows + 2;
         __syncthreads();
         // ---- stage: the band's (t, row, 4-pixel group) chunks are swept linearly; all global loads
@@ -331,8 +332,9 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     const int n_items = p.B * p.nbands;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int b = fdiv(item, p.mNb), band = item - b * p.nbands;
-        const int y0 = band * p.RB;
-        const int rows = min(p.RB, 2 * p.Hp - y0);
+        // balanced bands of whole pool-window rows
+        const int y0 = 2 * ((band * p.Hp) / p.nbands);
+        const int rows = 2 * (((band + 1) * p.Hp) / p.nbands) - y0;
         const int n2 = rows + 2;
         __syncthreads();
         // ---- stage the band with LDS-DMA: the tile is swept linearly in 16-byte chunks (64 per
@@ -782,11 +784,20 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
         // band height: largest even RB whose tile (RB+2 rows, all T) fits in ~78 KB of LDS
         // (two workgroups per CU; the 64->128 level keeps 144 weight VGPRs per wave and runs one
         //  workgroup per CU with up to 150 KB)
-        const size_t lds_cap = (i == BN_LEVELS - 1) ? 150 * 1024 : 78 * 1024;
-        int RBmax = 2 * Hp;
-        while (RBmax > 2 && (size_t)BN_T * (RBmax + 2) * TC * px_bytes > lds_cap) RBmax -= 2;
-        const int nbands = (2 * Hp + RBmax - 1) / RBmax;
-        const int RB = 2 * ((Hp + nbands - 1) / nbands);  // balanced bands
+        const size_t lds_cap = (i == BN_LEVELS - 1) ? 150 * 1024 : 80 * 1024;
+        const int wgs_per_cu = (i == BN_LEVELS - 1) ? 1 : 2;
+        // band planner: bands of whole pool-window rows.  Every band costs a halo + a barrier pair,
+        // and the two workgroups of a CU share its throughput, so the fewest bands that fit in LDS
+        // win -- unless that leaves CUs without work, then more bands add parallelism.
+        int nbands = 0, RB = 0;
+        const long long slots = (long long)wgs_per_cu * num_cu;
+        for (int nb = 1; nb <= Hp; nb++) {
+            const int rb = (Hp + nb - 1) / nb;  // max window rows per band
+            if ((size_t)BN_T * (2 * rb + 2) * TC * px_bytes > lds_cap) continue;
+            nbands = nb; RB = 2 * rb;
+            if ((long long)batch * nb >= slots) break;
+        }
+        if (!nbands) return COVAHIP_ERR_UNSUPPORTED;
         const size_t lds = (size_t)BN_T * (RB + 2) * TC * px_bytes;
         if (lds > 160 * 1024 - 256) return COVAHIP_ERR_UNSUPPORTED;
         const int items = batch * nbands;
