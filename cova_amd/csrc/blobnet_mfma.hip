@@ -83,32 +83,35 @@ __device__ __forceinline__ float pool4(float a0, float a1, float a2, float a3, f
     return fmaxf(sel + bias, 0.f) * scale + shift;
 }
 
-// Uniform fp32 constants (temporal-MLP weights) are pulled into scalar registers once per kernel:
-// the kernels store to global memory, so without this the compiler must assume the stores alias
-// the constants and re-load them with vector loads after every store.
-__device__ __forceinline__ void load_uniform32(const float *src, float (&dst)[32]) {
+// PointWiseTN (pointwise.py:16-26): u = relu(W1^T p), v = relu(W2^T u), out = relu(v + p), on the
+// matrix pipe: the two 4x4 products run as v_mfma_f32_4x4x4_16B_f16 (16 independent 4x4x4 blocks
+// per instruction).  Operand maps: A[i][k] lives in lane i + 4*block (k in the 4 halves), B[k][j] in
+// lane j + 4*block, D[i][j] in lane j + 4*block, register i.  Every lane feeds ITS element's
+// 4 T-values as a B column and gets that element's 4 outputs back as its D column; the A rows
+// (row lane%4 of W^T) are per-lane constants.  Inputs of the products are rounded to fp16 (like
+// every other MFMA operand here); the residual uses the fp32 value.
+struct TmixW {
+    half4 a1, a2;
+};
+__device__ __forceinline__ TmixW load_tmix(const float *tm, int lane) {
+    const int i = lane & 3;
+    TmixW w;
 #pragma unroll
-    for (int i = 0; i < 32; i++)
-        dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, src[i])));
+    for (int t = 0; t < BN_T; t++) {
+        w.a1[t] = (_Float16)tm[t * BN_T + i];
+        w.a2[t] = (_Float16)tm[16 + t * BN_T + i];
+    }
+    return w;
 }
-
-// PointWiseTN (pointwise.py:16-26): u = relu(W1^T p), v = relu(W2^T u), out = relu(v + p).
-__device__ __forceinline__ void tmix4(const float (&tm)[32], const float (&p)[BN_T], float (&o)[BN_T]) {
-    float u[BN_T];
+__device__ __forceinline__ void tmix4(const TmixW &w, const float (&p)[BN_T], float (&o)[BN_T]) {
+    const half4 pb = {(_Float16)p[0], (_Float16)p[1], (_Float16)p[2], (_Float16)p[3]};
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 u = __builtin_amdgcn_mfma_f32_4x4x4f16(w.a1, pb, z, 0, 0, 0);
+    const half4 ub = {(_Float16)fmaxf(u[0], 0.f), (_Float16)fmaxf(u[1], 0.f), (_Float16)fmaxf(u[2], 0.f),
+                      (_Float16)fmaxf(u[3], 0.f)};
+    const f32x4 v = __builtin_amdgcn_mfma_f32_4x4x4f16(w.a2, ub, z, 0, 0, 0);
 #pragma unroll
-    for (int j = 0; j < BN_T; j++) {
-        float a = 0.f;
-#pragma unroll
-        for (int t = 0; t < BN_T; t++) a += tm[t * BN_T + j] * p[t];
-        u[j] = fmaxf(a, 0.f);
-    }
-#pragma unroll
-    for (int j = 0; j < BN_T; j++) {
-        float a = 0.f;
-#pragma unroll
-        for (int t = 0; t < BN_T; t++) a += tm[16 + t * BN_T + j] * u[t];
-        o[j] = fmaxf(fmaxf(a, 0.f) + p[j], 0.f);
-    }
+    for (int t = 0; t < BN_T; t++) o[t] = fmaxf(fmaxf(v[t], 0.f) + p[t], 0.f);
 }
 
 // Asynchronous 16-byte global -> LDS copy (LDS-DMA): every lane supplies its own global source
@@ -178,8 +181,7 @@ __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
     const half8 bo0 = p.wfrag[128 + lane], bo1 = p.wfrag[192 + lane];   // odd-x weight set
     const int co = lane & 15;
     const float bias = p.epi[co], scale = p.epi[16 + co], shift = p.epi[32 + co];
-    float tm[32];
-    load_uniform32(p.epi + 48, tm);
+    const TmixW tm = load_tmix(p.epi + 48, lane);
 
     const int n_items = p.B * p.nbands;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -326,8 +328,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     for (int ks = 0; ks < KSTEPS; ks++) bf[ks] = p.wfrag[(ntile * KSTEPS + ks) * 64 + lane];
     const int co = ntile * 32 + (lane & 31);
     const float bias = p.epi[co], scale = p.epi[COUT + co], shift = p.epi[2 * COUT + co];
-    float tm[32];
-    load_uniform32(p.epi + 3 * COUT, tm);
+    const TmixW tm = load_tmix(p.epi + 3 * COUT, lane);
 
     const int n_items = p.B * p.nbands;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
