@@ -51,6 +51,25 @@ def kernel_macs_per_frame():
     return out
 
 
+PMC_KERNEL_KEYS = {"enc0_mfma": "enc0_mfma", "enc1_mfma": "enc_mfma<16, 32", "enc2_mfma": "enc_mfma<32, 64",
+                   "enc3_mfma": "enc_mfma<64, 128", "dec0_mfma": "dec_mfma<0, 128", "dec1_mfma": "dec_mfma<64, 64",
+                   "dec2_mfma": "dec_mfma<32, 32", "dec3_final_mfma": "dec_mfma<16, 16", "bboxcc_kernel": "bboxcc_kernel"}
+
+
+def committed_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
+    (profiles/r*/traffic.json, FETCH_SIZE/WRITE_SIZE passes of tools/collect_profiles.sh, b=256)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
+    if not files or kernel not in PMC_KERNEL_KEYS:
+        return None, None
+    data = json.load(open(files[-1]))
+    for name, v in data.items():
+        if name.startswith(PMC_KERNEL_KEYS[kernel]):
+            return v["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def cpu_baseline(flat, stack_sample, target_seconds=12.0):
     """Times the CPU oracle (the build's C port of the reference path: BlobNet fp32 + regionprops)
     on this host, on a bounded sample of the same workload."""
@@ -166,6 +185,11 @@ def main():
         cc_gbs = B * H_MB * W_MB / cc_s / 1e9
         total_flop = 2.0 * net.macs_per_frame * B
         step_s = elapsed / args.steps
+        launches_per_step = max(1, round(dom_n / args.steps))      # 2 when the half-batch overlap is on
+        dom_flop /= launches_per_step
+        ach_tflops = dom_flop / dom_s / 1e12
+        dom_traffic, dom_traffic_src = committed_traffic(dominant) if B == BATCH else (None, None)
+        cc_traffic, _ = committed_traffic("bboxcc_kernel") if B == BATCH else (None, None)
         line = {
             "metric": "compressed-domain frames/sec (BlobNet+bboxcc) at 1080p b=256",
             "value": round(world * B * args.steps / elapsed, 1),
@@ -185,12 +209,13 @@ def main():
                        "parallelism": f"{world} x independent per-GPU batches, no collective"},
             "roofline": {"kernel": dominant, "bound": "mfma", "achieved": round(ach_tflops, 2),
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_tflops / MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None,
+                         "traffic": dom_traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
+                         "traffic_source": dom_traffic_src,
                          "algorithmic_flop_per_launch": dom_flop, "avg_launch_us": round(dom_s * 1e6, 2),
                          "launches_timed": dom_n, "measured": "HIP events on the launch stream inside the timed region"},
             "roofline_bboxcc": {"kernel": "bboxcc_kernel", "bound": "hbm", "achieved": round(cc_gbs, 2),
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(cc_gbs / HBM_PEAK_GBS, 5),
-                                "traffic": None, "algorithmic_bytes_per_launch": B * H_MB * W_MB,
+                                "traffic": cc_traffic, "algorithmic_bytes_per_launch": B * H_MB * W_MB,
                                 "avg_launch_us": round(cc_s * 1e6, 2),
                                 "note": "b=256 masks are 2.09 MB: launch-latency bound, see DESIGN.md batch sweep"},
             "blobnet_mfma_util_whole_net": round(total_flop / (step_s - cc_s) / 1e12 / MFMA_PEAK_TFLOPS, 4),
