@@ -1,0 +1,152 @@
+/*
+ * gst_element_driver.c -- drives the elements of libgstcova.so buffer by buffer (GstHarness /
+ * hand-linked pads) so that tests/ can compare their output with the oracle.  Test tool only.
+ *
+ * Record format used for buffer sequences on disk (little endian):
+ *   u8 kind, u64 pts, u32 flags, u32 len, len bytes payload
+ * kinds: 'B' buffer (metapreprocess / sorttracker / pipelines), 'E' encoded AU for cova.sink_enc,
+ *        'M' bbox buffer for cova.sink_mask, 'e' EOS on sink_enc, 'm' EOS on sink_mask.
+ * Output records: 'B' (pts, flags = GstBufferFlags, payload) and for cova 'L' (start of a BufferList).
+ */
+#include <gst/check/gstharness.h>
+#include <gst/gst.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { uint8_t kind; uint64_t pts; uint32_t flags, len; uint8_t *data; } rec_t;
+
+static int read_rec(FILE *f, rec_t *r) {
+    if (fread(&r->kind, 1, 1, f) != 1) return 0;
+    if (fread(&r->pts, 8, 1, f) != 1 || fread(&r->flags, 4, 1, f) != 1 || fread(&r->len, 4, 1, f) != 1) return 0;
+    r->data = r->len ? malloc(r->len) : NULL;
+    if (r->len && fread(r->data, 1, r->len, f) != r->len) return 0;
+    return 1;
+}
+static void write_rec(FILE *f, uint8_t kind, uint64_t pts, uint32_t flags, const void *data, uint32_t len) {
+    fwrite(&kind, 1, 1, f); fwrite(&pts, 8, 1, f); fwrite(&flags, 4, 1, f); fwrite(&len, 4, 1, f);
+    if (len) fwrite(data, 1, len, f);
+}
+static void write_buffer(FILE *f, GstBuffer *b) {
+    GstMapInfo m;
+    gst_buffer_map(b, &m, GST_MAP_READ);
+    write_rec(f, 'B', GST_BUFFER_PTS_IS_VALID(b) ? GST_BUFFER_PTS(b) : UINT64_MAX, GST_BUFFER_FLAGS(b), m.data, (uint32_t)m.size);
+    gst_buffer_unmap(b, &m);
+}
+static GstBuffer *buffer_from(const rec_t *r) {
+    GstBuffer *b = gst_buffer_new_allocate(NULL, r->len, NULL);
+    if (r->len) gst_buffer_fill(b, 0, r->data, r->len);
+    GST_BUFFER_PTS(b) = r->pts;
+    if (r->flags & 1) GST_BUFFER_FLAG_SET(b, GST_BUFFER_FLAG_DELTA_UNIT);
+    return b;
+}
+
+/* ---- generic: launch line + src caps, push 'B' records, write every output buffer ---- */
+static int run_harness(const char *launch, const char *srccaps, const char *in_path, const char *out_path) {
+    GstHarness *h = gst_harness_new_parse(launch);
+    FILE *fi = fopen(in_path, "rb"), *fo = fopen(out_path, "wb");
+    rec_t r;
+    int pushed = 0, pulled = 0;
+    GstBuffer *ob;
+    if (!h || !fi || !fo) { fprintf(stderr, "setup failed\n"); return 2; }
+    gst_harness_set_src_caps_str(h, srccaps);
+    while (read_rec(fi, &r)) {
+        if (r.kind == 'B') {
+            GstFlowReturn fr = gst_harness_push(h, buffer_from(&r));
+            if (fr != GST_FLOW_OK) { fprintf(stderr, "push failed: %s\n", gst_flow_get_name(fr)); return 3; }
+            pushed++;
+        }
+        free(r.data);
+        while ((ob = gst_harness_try_pull(h)) != NULL) { write_buffer(fo, ob); gst_buffer_unref(ob); pulled++; }
+    }
+    gst_harness_push_event(h, gst_event_new_eos());
+    while ((ob = gst_harness_try_pull(h)) != NULL) { write_buffer(fo, ob); gst_buffer_unref(ob); pulled++; }
+    {
+        GstCaps *c = gst_pad_get_current_caps(h->sinkpad);
+        gchar *s = c ? gst_caps_to_string(c) : g_strdup("(none)");
+        printf("{\"pushed\": %d, \"pulled\": %d, \"out_caps\": \"%s\"}\n", pushed, pulled, s);
+        g_free(s);
+        if (c) gst_caps_unref(c);
+    }
+    fclose(fi); fclose(fo);
+    gst_harness_teardown(h);
+    return 0;
+}
+
+/* ---- cova: two sink pads driven by hand ---- */
+static FILE *cova_out;
+static GstFlowReturn cova_chain_list(GstPad *pad, GstObject *parent, GstBufferList *list) {
+    guint n = gst_buffer_list_length(list);
+    write_rec(cova_out, 'L', n, 0, NULL, 0);
+    for (guint i = 0; i < n; i++) write_buffer(cova_out, gst_buffer_list_get(list, i));
+    gst_buffer_list_unref(list);
+    return GST_FLOW_OK;
+}
+static GstFlowReturn cova_chain(GstPad *pad, GstObject *parent, GstBuffer *b) {
+    write_rec(cova_out, 'L', 1, 0, NULL, 0);
+    write_buffer(cova_out, b);
+    gst_buffer_unref(b);
+    return GST_FLOW_OK;
+}
+static int cova_got_eos = 0;
+static gboolean cova_sink_event(GstPad *pad, GstObject *parent, GstEvent *ev) {
+    if (GST_EVENT_TYPE(ev) == GST_EVENT_EOS) cova_got_eos = 1;
+    gst_event_unref(ev);
+    return TRUE;
+}
+static void start_pad(GstPad *p, const char *stream, const char *caps) {
+    GstSegment seg;
+    gst_pad_set_active(p, TRUE);
+    gst_pad_push_event(p, gst_event_new_stream_start(stream));
+    if (caps) { GstCaps *c = gst_caps_from_string(caps); gst_pad_push_event(p, gst_event_new_caps(c)); gst_caps_unref(c); }
+    gst_segment_init(&seg, GST_FORMAT_TIME);
+    gst_pad_push_event(p, gst_event_new_segment(&seg));
+}
+static int run_cova(const char *props, const char *in_path, const char *out_path) {
+    gchar *desc = g_strdup_printf("cova %s", props);
+    GError *err = NULL;
+    GstElement *e = gst_parse_launch(desc, &err);
+    FILE *fi = fopen(in_path, "rb");
+    rec_t r;
+    guint64 d = 0, dd = 0, di = 0;
+    if (!e || !fi) { fprintf(stderr, "cova setup failed: %s\n", err ? err->message : "?"); return 2; }
+    cova_out = fopen(out_path, "wb");
+    GstPad *enc = gst_pad_new("enc_src", GST_PAD_SRC), *mask = gst_pad_new("mask_src", GST_PAD_SRC);
+    GstPad *sink = gst_pad_new("out_sink", GST_PAD_SINK);
+    gst_pad_set_chain_function(sink, cova_chain);
+    gst_pad_set_chain_list_function(sink, cova_chain_list);
+    gst_pad_set_event_function(sink, cova_sink_event);
+    gst_pad_set_active(sink, TRUE);
+    GstPad *e_enc = gst_element_get_static_pad(e, "sink_enc"), *e_mask = gst_element_get_static_pad(e, "sink_mask");
+    GstPad *e_src = gst_element_get_static_pad(e, "src");
+    if (gst_pad_link(enc, e_enc) != GST_PAD_LINK_OK || gst_pad_link(mask, e_mask) != GST_PAD_LINK_OK ||
+        gst_pad_link(e_src, sink) != GST_PAD_LINK_OK) { fprintf(stderr, "link failed\n"); return 2; }
+    gst_element_set_state(e, GST_STATE_PLAYING);
+    start_pad(enc, "enc", "video/x-h264");
+    start_pad(mask, "mask", "bbox, width=(int)80, height=(int)45");
+    int rc = 0;
+    while (read_rec(fi, &r)) {
+        GstFlowReturn fr = GST_FLOW_OK;
+        if (r.kind == 'E') fr = gst_pad_push(enc, buffer_from(&r));
+        else if (r.kind == 'M') fr = gst_pad_push(mask, buffer_from(&r));
+        else if (r.kind == 'e') gst_pad_push_event(enc, gst_event_new_eos());
+        else if (r.kind == 'm') gst_pad_push_event(mask, gst_event_new_eos());
+        free(r.data);
+        if (fr != GST_FLOW_OK) { fprintf(stderr, "flow %s at kind %c pts %llu\n", gst_flow_get_name(fr), r.kind, (unsigned long long)r.pts); rc = 3; break; }
+    }
+    g_object_get(e, "dropped", &d, "decoded-dependency", &dd, "decoded-inference", &di, NULL);
+    printf("{\"dropped\": %llu, \"decoded_dependency\": %llu, \"decoded_inference\": %llu, \"eos\": %d}\n",
+           (unsigned long long)d, (unsigned long long)dd, (unsigned long long)di, cova_got_eos);
+    fclose(fi); fclose(cova_out);
+    gst_element_set_state(e, GST_STATE_NULL);
+    return rc;
+}
+
+int main(int argc, char **argv) {
+    gst_init(&argc, &argv);
+    if (argc >= 6 && !strcmp(argv[1], "harness")) return run_harness(argv[2], argv[3], argv[4], argv[5]);
+    if (argc >= 5 && !strcmp(argv[1], "cova")) return run_cova(argv[2], argv[3], argv[4]);
+    fprintf(stderr, "usage: %s harness '<launch line>' '<src caps>' in.rec out.rec | cova '<props>' in.rec out.rec\n", argv[0]);
+    return 1;
+}

@@ -1,0 +1,189 @@
+"""The GStreamer elements of gst/libgstcova.so (reference names / pads / properties) driven buffer by
+buffer through gst/gst_element_driver and compared with the oracle restatements."""
+import json
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from cova_amd import _lib as L
+from cova_amd import elements as E
+from oracle import ref
+from oracle import sort_ref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GST = os.path.join(ROOT, "gst")
+DRIVER = os.path.join(GST, "gst_element_driver")
+CONDA = "/opt/conda"
+CLK = 1_000_000_000 // 30
+
+pytestmark = pytest.mark.skipif(
+    not (os.path.exists(os.path.join(CONDA, "lib", "libgstreamer-1.0.so")) and os.path.exists(DRIVER)
+         and os.path.exists(os.path.join(GST, "libgstcova.so"))),
+    reason="GStreamer 1.x under /opt/conda or the built plugin is missing")
+
+
+def _env(tmp):
+    env = dict(os.environ)
+    env.update({
+        "GST_PLUGIN_PATH": GST, "GST_PLUGIN_SYSTEM_PATH": os.path.join(CONDA, "lib", "gstreamer-1.0"),
+        "LD_LIBRARY_PATH": os.path.join(CONDA, "lib"), "GST_REGISTRY": str(tmp / "registry.bin"),
+        # conda ships an older libstdc++ than the one libcovahip.so was built against
+        "LD_PRELOAD": "/usr/lib/x86_64-linux-gnu/libstdc++.so.6", "GST_DEBUG": "1",
+    })
+    return env
+
+
+def _write(path, recs):
+    with open(path, "wb") as f:
+        for kind, pts, flags, payload in recs:
+            f.write(struct.pack("<BQII", ord(kind), pts, flags, len(payload)) + payload)
+
+
+def _read(path):
+    out = []
+    data = open(path, "rb").read()
+    off = 0
+    while off < len(data):
+        kind, pts, flags, n = struct.unpack_from("<BQII", data, off)
+        off += 17
+        out.append((chr(kind), pts, flags, data[off:off + n]))
+        off += n
+    return out
+
+
+def _run(args, tmp):
+    r = subprocess.run([DRIVER] + args, env=_env(tmp), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_inspect_lists_reference_elements_and_properties(tmp_path):
+    insp = os.path.join(CONDA, "bin", "gst-inspect-1.0")
+    want = {"metapreprocess": ["timestep", "gamma"], "bboxcc": ["cc-threshold"],
+            "sorttracker": ["iou-threshold", "maxage", "minhits"],
+            "cova": ["sort-iou", "sort-maxage", "sort-minhits", "port", "infer-i", "debug", "alpha", "beta", "dropped",
+                     "decoded-dependency", "decoded-inference"],
+            "blobnetinfer": ["model-weights-file", "gpu-id"]}
+    for el, props in want.items():
+        r = subprocess.run([insp, el], env=_env(tmp_path), capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stdout + r.stderr
+        for p in props:
+            assert f"  {p} " in r.stdout or f"  {p}:" in r.stdout, (el, p)
+    r = subprocess.run([insp, "cova"], env=_env(tmp_path), capture_output=True, text=True)
+    for pad in ("sink_mask", "sink_enc", "src"):
+        assert f"'{pad}'" in r.stdout
+
+
+@pytest.mark.parametrize("t,gamma", [(4, 1), (4, 2), (1, 1)])
+def test_metapreprocess_element(tmp_path, t, gamma):
+    w, h, n = 320, 240, 9                    # 20 x 15 macroblocks
+    spb = (w // 16) * (h // 16) * 4
+    rng = np.random.default_rng(t * 7 + gamma)
+    frames = rng.integers(0, 256, (n, w * h * 3 // 2), dtype=np.uint8)
+    _write(tmp_path / "in.rec", [("B", i * CLK, 0, frames[i].tobytes()) for i in range(n)])
+    info = _run(["harness", f"metapreprocess timestep={t} gamma={gamma}",
+                 f"video/x-raw,format=I420,width={w},height={h},framerate=30/1", str(tmp_path / "in.rec"),
+                 str(tmp_path / "out.rec")], tmp_path)
+    exp, idx = ref.metapreprocess(frames, spb, t, gamma)
+    outs = _read(tmp_path / "out.rec")
+    assert info["pulled"] == len(outs) == len(exp)
+    assert f"width=(int){w // 16}" in info["out_caps"] and f"height=(int){h // 16 * t}" in info["out_caps"]
+    assert "RGBA" in info["out_caps"]
+    for k, (kind, pts, flags, payload) in enumerate(outs):
+        assert pts == int(idx[k]) * CLK                      # output inherits the PTS of the current frame
+        assert payload == exp[k].tobytes()
+
+
+def _bb(rows):
+    out = np.zeros(len(rows), dtype=L.BBOX_DTYPE)
+    for i, r in enumerate(rows):
+        out[i] = E.make_bbox(*r)[0]
+    return out
+
+
+def test_sorttracker_element(tmp_path):
+    seq = [[(10 + 0.5 * i, 10, 5, 5), (40, 20 + 0.3 * i, 6, 4)] for i in range(30)] + [[]] * 15
+    _write(tmp_path / "in.rec", [("B", i * CLK, 0, E.serialize_vec(_bb(d))) for i, d in enumerate(seq)])
+    info = _run(["harness", "sorttracker maxage=10 minhits=5 iou-threshold=0.1", "bbox,width=80,height=45",
+                 str(tmp_path / "in.rec"), str(tmp_path / "out.rec")], tmp_path)
+    outs = _read(tmp_path / "out.rec")
+    assert info["pulled"] == len(seq) + 1                    # one buffer per input + the EOS finalize() buffer
+    r = R.Sort(10, 5, 0.1)
+    for i, d in enumerate(seq):
+        dead = r.update([R.Bbox(*b) for b in d], i * CLK)
+        got = E.deserialize_vec(outs[i][3])
+        flat = [b for t in dead for b in t.history]
+        assert len(got) == len(flat)
+        for g, e in zip(got, flat):
+            assert g["track_id"] == e.track_id and g["timestamp"] == e.timestamp
+            assert abs(float(g["left"]) - float(e.left)) < 1e-3 * max(1, abs(float(e.left)))
+    fin = E.deserialize_vec(outs[-1][3])
+    assert len(fin) == sum(len(t.history) for t in r.finalize())
+    assert sum(len(E.deserialize_vec(o[3])) for o in outs) > 0
+
+
+@pytest.mark.parametrize("props,kw", [("sort-maxage=10 sort-minhits=5", dict(sort_maxage=10, sort_minhits=5)),
+                                      ("sort-maxage=10 sort-minhits=5 infer-i=true",
+                                       dict(sort_maxage=10, sort_minhits=5, infer_i=True))])
+def test_cova_element(tmp_path, props, kw):
+    n, gop, lead = 700, 250, 280
+    dets = [[(5 + 0.4 * (i - 10), 5 + 0.2 * (i - 10), 6, 6)] if 10 <= i <= 120 else
+            ([(60 - 0.3 * (i - 200), 30, 8, 5)] if 200 <= i <= 420 else []) for i in range(n)]
+    recs = []
+    r = R.GopFilter(**kw)
+    for i in range(n + lead):
+        if i < n:
+            recs.append(("E", i * CLK, 0 if i % gop == 0 else 1, struct.pack("<I", i)))
+            r.push_enc(i, i * CLK, 0 if i % gop == 0 else R.DELTA_UNIT)
+        j = i - lead
+        if 0 <= j < n:
+            recs.append(("M", j * CLK, 0, E.serialize_vec(_bb(dets[j]))))
+            r.push_boxes([R.Bbox(*d) for d in dets[j]], j * CLK)
+    recs += [("e", 0, 0, b""), ("m", 0, 0, b"")]
+    r.eos()
+    _write(tmp_path / "in.rec", recs)
+    info = _run(["cova", props, str(tmp_path / "in.rec"), str(tmp_path / "out.rec")], tmp_path)
+    assert (info["dropped"], info["decoded_dependency"], info["decoded_inference"]) == \
+        (r.dropped, r.decoded_dependency, r.decoded_inference)
+    assert info["eos"] == 1                                  # EOS forwarded once both sinks saw it
+    outs = _read(tmp_path / "out.rec")
+    lists, cur = [], None
+    for kind, pts, flags, payload in outs:
+        if kind == "L":
+            cur = []
+            lists.append(cur)
+        else:
+            au = struct.unpack("<I", payload)[0]
+            cur.append((au, pts, bool(flags & 0x40), bool(flags & 0x1000)))  # GST_BUFFER_FLAG_DISCONT (64) / DROPPABLE (4096, cf. identity drop-buffer-flags=4096)
+    lists = [l for l in lists if l]
+    assert [[b[0] for b in l] for l in lists] == [[b[0] for b in l] for l in r.pushed]
+    for got, exp in zip(lists, r.pushed):
+        for (au, pts, discont, droppable), (eid, epts, eflags) in zip(got, exp):
+            assert pts == epts and discont == bool(eflags & R.DISCONT) and droppable == bool(eflags & R.DROPPABLE)
+
+
+@pytest.mark.gpu
+def test_blobnet_bboxcc_pipeline(tmp_path, weights_flat):
+    """blobnetinfer ! bboxcc on the GPU: bincode boxes identical to the C-ABI path on the same inputs."""
+    from cova_amd import synth, weights as W
+    from cova_amd.elements import BlobNetInfer, Context
+    h, w, n = 45, 80, 3
+    stack = synth.stacked_batch(n, h, w, seed=31)
+    wpath = tmp_path / "weights.bin"
+    wpath.write_bytes(W.to_bytes(weights_flat))
+    _write(tmp_path / "in.rec", [("B", i * CLK, 0, stack[i].tobytes()) for i in range(n)])
+    info = _run(["harness", f"blobnetinfer model-weights-file={wpath} ! bboxcc cc-threshold=1",
+                 f"video/x-raw,format=RGBA,width={w},height={4 * h},framerate=30/1", str(tmp_path / "in.rec"),
+                 str(tmp_path / "out.rec")], tmp_path)
+    outs = _read(tmp_path / "out.rec")
+    assert info["pulled"] == n and "bbox" in info["out_caps"]
+    ctx = Context(0)
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=n)
+    boxes, counts, mask = net.filter(stack, cc_threshold=1, max_boxes=2048, want_mask=True)
+    for i in range(n):
+        exp = E.serialize_vec(E.boxes_to_bbox(boxes[i, :counts[i]]))
+        assert outs[i][3] == exp and outs[i][1] == i * CLK
+    ctx.close()
