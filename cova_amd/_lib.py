@@ -80,6 +80,7 @@ PROTOTYPES = {
     "covahip_blobnet_load": (C.c_int, [_P, _P, _SZ, C.c_int, C.c_int, C.c_int, C.c_int]),
     "covahip_blobnet_forward": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int]),
     "covahip_blobnet_macs_per_frame": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "covahip_set_pipeline": (C.c_int, [_P, C.c_int]),
     "covahip_blobnet_set_impl": (C.c_int, [_P, C.c_int]),
     "covahip_blobnet_set_overlap": (C.c_int, [_P, C.c_int]),
     "covahip_bboxcc": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int]),

@@ -81,6 +81,10 @@ static int filter_dev(covahip_ctx *ctx, const uint8_t *d_stack, int batch, float
     if (batch > m->max_batch) return COVAHIP_ERR_INVALID_ARG;
     if (batch == 0) return COVAHIP_OK;
     const size_t hw = (size_t)m->H * m->W;
+    if (!(with_cc && ctx->pipeline_cc && m->impl == 1)) {
+        int rcj = covahip_join_aux(ctx);
+        if (rcj) return rcj;
+    }
     auto run = [&](int f0, int n) -> int {
         const uint8_t *st = d_stack + (size_t)f0 * BN_T * hw * 4;
         float *lg = d_logits ? d_logits + (size_t)f0 * hw : nullptr;
@@ -93,9 +97,27 @@ static int filter_dev(covahip_ctx *ctx, const uint8_t *d_stack, int batch, float
             rc = blobnet_forward_mfma(ctx, m, st, n, lg, mk, f0);
         }
         if (rc) return rc;
-        if (with_cc)
-            rc = covahip_bboxcc_launch(ctx, mk, n, m->H, m->W, area_thresh, d_boxes + (size_t)f0 * max_boxes,
-                                       d_counts + f0, max_boxes);
+        if (with_cc) {
+            const bool pipe = ctx->pipeline_cc && m->impl == 1 && ctx->stream2 && f0 == 0 && n == batch &&
+                              !ctx->profile_all();
+            if (pipe) {
+                // bboxcc of this batch goes to stream2 and overlaps the next batch's BlobNet; the next
+                // batch's mask-writing kernel waits for ev_cc_done (blobnet_forward_mfma), every
+                // consumer of the boxes joins through covahip_join_aux.
+                hipStream_t main_stream = ctx->stream;
+                COVAHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_mask_ready, main_stream));
+                COVAHIP_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_mask_ready, 0));
+                ctx->stream = ctx->stream2;
+                rc = covahip_bboxcc_launch(ctx, mk, n, m->H, m->W, area_thresh, d_boxes, d_counts, max_boxes);
+                ctx->stream = main_stream;
+                if (rc) return rc;
+                COVAHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_cc_done, ctx->stream2));
+                ctx->cc_pending = true;
+            } else {
+                rc = covahip_bboxcc_launch(ctx, mk, n, m->H, m->W, area_thresh, d_boxes + (size_t)f0 * max_boxes,
+                                           d_counts + f0, max_boxes);
+            }
+        }
         return rc;
     };
     const bool split = m->impl == 1 && m->overlap && batch >= 32 && ctx->stream2 && !ctx->profile_all();
@@ -198,6 +220,14 @@ int covahip_blobnet_macs_per_frame(covahip_ctx *ctx, int64_t *macs) {
     return COVAHIP_OK;
 }
 
+int covahip_set_pipeline(covahip_ctx *ctx, int on) {
+    if (!ctx) return COVAHIP_ERR_INVALID_ARG;
+    int rc = covahip_join_aux(ctx);
+    if (rc) return rc;
+    ctx->pipeline_cc = on != 0;
+    return COVAHIP_OK;
+}
+
 int covahip_blobnet_set_overlap(covahip_ctx *ctx, int on) {
     if (!ctx || !ctx->blobnet) return COVAHIP_ERR_NOT_LOADED;
     ctx->blobnet->overlap = on != 0;
@@ -251,6 +281,8 @@ int covahip_filter_forward(covahip_ctx *ctx, const uint8_t *rgba_stack, int batc
     COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(ctx->stage_in, rgba_stack, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     rc = filter_dev(ctx, (const uint8_t *)ctx->stage_in, batch, logits ? d_logits : nullptr, d_mask, true, area_thresh,
                     d_boxes, d_counts, max_boxes);
+    if (rc) return rc;
+    rc = covahip_join_aux(ctx);
     if (rc) return rc;
     if (logits) COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(logits, d_logits, logit_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (mask) COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(mask, d_mask, mask_bytes, hipMemcpyDeviceToHost, ctx->stream));

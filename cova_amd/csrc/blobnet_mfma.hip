@@ -891,6 +891,8 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
         } else {
             rc = set_lds(ctx, dec_mfma<16, 16, 16, true>, lds);
             if (rc) return rc;
+            // the previous batch's pipelined bboxcc may still be reading the mask this kernel rewrites
+            if (ctx->cc_pending) COVAHIP_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cc_done, 0));
             ProfScope ps(ctx, "dec3_final_mfma");
             hipLaunchKernelGGL((dec_mfma<16, 16, 16, true>), dim3(grid), dim3(256), lds, ctx->stream, a);
         }

@@ -48,6 +48,9 @@ class Context:
 
     __del__ = close
 
+    def set_pipeline(self, on: bool):
+        L.check(self._lib.covahip_set_pipeline(self.handle, int(on)), "covahip_set_pipeline", self.handle)
+
     def sync(self):
         L.check(self._lib.covahip_ctx_sync(self.handle), "covahip_ctx_sync", self.handle)
 

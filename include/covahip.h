@@ -113,6 +113,11 @@ int covahip_blobnet_load(covahip_ctx *ctx, const void *weights, size_t weights_b
  * covahip_ctx_sync); synchronous for host pointers.                               */
 int covahip_blobnet_forward(covahip_ctx *ctx, const uint8_t *rgba_stack, int batch, float *logits,
                             uint8_t *mask, int mem_kind);
+/* Cross-batch pipelining of covahip_filter_forward on device pointers (default off): the bboxcc of
+ * batch k runs on a second HIP stream while BlobNet of batch k+1 runs on the main one.  Results of
+ * a call are complete after covahip_ctx_sync / covahip_memcpy_d2h / covahip_timer_stop (each joins
+ * the second stream), exactly like any other asynchronous device-pointer call. */
+int covahip_set_pipeline(covahip_ctx *ctx, int on);
 /* Algorithmic MACs per frame of the loaded geometry. */
 int covahip_blobnet_macs_per_frame(covahip_ctx *ctx, int64_t *macs);
 /* Debug switch: 1 = MFMA kernels (default), 0 = direct one-thread-per-output kernels

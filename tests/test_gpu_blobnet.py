@@ -95,3 +95,49 @@ def test_fused_filter_matches_separate(ctx, weights_flat):
             np.testing.assert_array_equal(boxes[i, :n][f], rb[i, :n][g])
     _, mask2 = net.infer(stack)
     np.testing.assert_array_equal(mask, mask2)
+
+
+def test_pipelined_device_path_matches_unpipelined(ctx, weights_flat):
+    """covahip_filter_forward on device pointers pipelines bboxcc(k) behind BlobNet(k+1) on a second
+    stream; after a sync every step's boxes must equal the unpipelined result, also when consecutive
+    steps reuse the same mask / box buffers with different inputs."""
+    from cova_amd import _lib as L
+    h, w, b, mb = 68, 120, 64, 2048
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=b)
+    stacks = [synth.stacked_batch(b, h, w, seed=100 + k, streams=4) for k in range(3)]
+    d_stack = [ctx.malloc(s.nbytes) for s in stacks]
+    for d, s in zip(d_stack, stacks):
+        ctx.h2d(d, s)
+    d_boxes, d_counts, d_mask = ctx.malloc(b * mb * 20), ctx.malloc(b * 4), ctx.malloc(b * h * w)
+
+    def run(pipeline):
+        ctx.set_pipeline(pipeline)
+        res = []
+        for rep in range(2):
+            for k in range(3):
+                net.filter_device(d_stack[k], b, 1, d_boxes, d_counts, mb, d_mask)
+                if k == 2 or not pipeline:      # pipelined: let two steps overlap before reading back
+                    pass
+                boxes = np.zeros((b, mb), dtype=L.BOX_DTYPE)
+                counts = np.zeros(b, dtype=np.int32)
+                ctx.d2h(counts, d_counts)        # joins the second stream
+                ctx.d2h(boxes, d_boxes)
+                res.append((counts.copy(), boxes.copy()))
+        return res
+
+    ref_res = run(False)
+    pip_res = run(True)
+    for (c0, b0), (c1, b1) in zip(ref_res, pip_res):
+        np.testing.assert_array_equal(c0, c1)
+        for i in range(b):
+            np.testing.assert_array_equal(b0[i, :c0[i]], b1[i, :c1[i]])
+    # back-to-back steps without reading in between: only the last result is observable, and it is right
+    ctx.set_pipeline(True)
+    for k in (0, 1, 2, 0, 1):
+        net.filter_device(d_stack[k], b, 1, d_boxes, d_counts, mb, d_mask)
+    ctx.sync()
+    counts = np.zeros(b, dtype=np.int32)
+    ctx.d2h(counts, d_counts)
+    np.testing.assert_array_equal(counts, ref_res[1][0])
+    for p in d_stack + [d_boxes, d_counts, d_mask]:
+        ctx.free(p)
