@@ -58,6 +58,7 @@ struct Prepared {
     size_t final_w;  // B fragments of the folded (convT 32->16) x (1x1 16->1) last block: [KSTEPS][64] x half8
     size_t final_epi;  // folded bias (fp32)
     size_t zero;     // 256 zero bytes (LDS-DMA source for halo chunks)
+    bool allpos[BN_LEVELS];  // all BN scales of encoder level i are >= 0
     size_t total;
 };
 
@@ -75,12 +76,18 @@ inline uint32_t magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32
 // ReLU and the pool (encoder.py:61-66) and gamma may be negative, so the pool picks the max
 // for scale >= 0 and the min otherwise: max_q(relu(a_q)*s + b) = relu(sel_q a_q)*s + b.
 // The conv bias commutes with max/min and is added after the selection.
+// ALLPOS: every BN scale of the level is >= 0 (checked on the host), so the min path is dropped.
+template <bool ALLPOS>
 __device__ __forceinline__ float pool4(float a0, float a1, float a2, float a3, float bias, float scale,
                                        float shift) {
     const float mx = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
-    const float mn = fminf(fminf(a0, a1), fminf(a2, a3));
-    const float sel = scale >= 0.f ? mx : mn;
-    return fmaxf(sel + bias, 0.f) * scale + shift;
+    if constexpr (ALLPOS) {
+        return fmaxf(mx + bias, 0.f) * scale + shift;
+    } else {
+        const float mn = fminf(fminf(a0, a1), fminf(a2, a3));
+        const float sel = scale >= 0.f ? mx : mn;
+        return fmaxf(sel + bias, 0.f) * scale + shift;
+    }
 }
 
 // PointWiseTN (pointwise.py:16-26): u = relu(W1^T p), v = relu(W2^T u), out = relu(v + p), on the
@@ -169,6 +176,7 @@ struct DecArgs {
 // Tile: row r <-> input row y0-1+r, col c <-> input col c-2 (cols 0,1 and W+2,W+3 are zero),
 // TC = W+4 so rows are 16-byte multiples and 4-pixel groups land 16-byte aligned.
 constexpr int WG0 = 512;  // 8 waves: the per-tile dependency chain is latency bound, so run 4 waves per SIMD
+template <bool ALLPOS>
 __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -273,8 +281,8 @@ __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
                 co_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao0, bo0, co_, 0, 0, 0);
                 ce = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae1, be1, ce, 0, 0, 0);
                 co_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao1, bo1, co_, 0, 0, 0);
-                pooled[0][t] = pool4(ce[0], ce[1], co_[0], co_[1], bias, scale, shift);
-                pooled[1][t] = pool4(ce[2], ce[3], co_[2], co_[3], bias, scale, shift);
+                pooled[0][t] = pool4<ALLPOS>(ce[0], ce[1], co_[0], co_[1], bias, scale, shift);
+                pooled[1][t] = pool4<ALLPOS>(ce[2], ce[3], co_[2], co_[3], bias, scale, shift);
             }
             const size_t tstride = (size_t)p.Ho * p.Wo * 16;
 #pragma unroll
@@ -304,7 +312,7 @@ __device__ __forceinline__ int enc_swz(int xx, int yy) {
     return ((xx / XS) % (CPP / 2)) | ((yy & 1) * (CPP / 2));
 }
 
-template <int CIN, int COUT, int TPAR, int OCC, int NWV>
+template <int CIN, int COUT, int TPAR, int OCC, int NWV, bool ALLPOS>
 __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     constexpr int WGS = NWV * 64;
     constexpr int NT = COUT / 32, MG = NWV / NT, KC = CIN / 16, KSTEPS = 9 * KC;
@@ -396,9 +404,16 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
                 for (int t = 0; t < TPAR; t++)
 #pragma unroll
                     for (int g = 0; g < 4; g++)
-                        pooled4[t0 + t][g] = pool4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2],
+                        pooled4[t0 + t][g] = pool4<ALLPOS>(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2],
                                                    acc[t][4 * g + 3], bias, scale, shift);
             }
+            // Materialise all 16 pooled values here (empty asm = opaque use): the accumulators die
+            // before the epilogue starts.  Without this point hipcc interleaves the pooling of later
+            // T-slices with the epilogue and the 64->128 level spills >150 registers.
+#pragma unroll
+            for (int t = 0; t < BN_T; t++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) asm volatile("" : "+v"(pooled4[t][g]));
             // ---- epilogue: temporal MLP + residual per pooled window, then store
             const size_t tstride = (size_t)p.Ho * p.Wo * COUT;
 #pragma unroll
@@ -713,6 +728,10 @@ int blobnet_prepare_mfma(covahip_ctx *ctx, covahip_blobnet *m, const float *w) {
     pr->total = off;
 
     std::vector<uint8_t> host(off, 0);
+    for (int i = 0; i < BN_LEVELS; i++) {
+        pr->allpos[i] = true;
+        for (int c = 0; c < m->enc_c[i + 1]; c++) pr->allpos[i] = pr->allpos[i] && he[i].gamma[c] >= 0.f;
+    }
     prep_enc0(he[0].k, he[0].b, he[0].gamma, he[0].beta, he[0].mean, he[0].var, he[0].w1, he[0].w2,
               (_Float16 *)(host.data() + pr->enc[0].wfrag), (float *)(host.data() + pr->enc[0].epi));
     for (int i = 1; i < BN_LEVELS; i++)
@@ -794,10 +813,11 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
             a.oy = H & 1; a.ox = W & 1; a.RB = RB; a.nbands = nbands; a.TR = RB + 2; a.TC = TC;
             a.mWp = magic(Wp); a.mNb = magic(nbands); a.mW4 = magic(W / 4);
             if (W % 4 || BN_T * (RB + 2) * (W / 4) > 5 * WG0) return COVAHIP_ERR_UNSUPPORTED;
-            int rc = set_lds(ctx, enc0_mfma, lds);
+            int rc = pr->allpos[0] ? set_lds(ctx, enc0_mfma<true>, lds) : set_lds(ctx, enc0_mfma<false>, lds);
             if (rc) return rc;
             ProfScope ps(ctx, "enc0_mfma");
-            hipLaunchKernelGGL(enc0_mfma, dim3(grid), dim3(WG0), lds, ctx->stream, a);
+            if (pr->allpos[0]) hipLaunchKernelGGL(enc0_mfma<true>, dim3(grid), dim3(WG0), lds, ctx->stream, a);
+            else hipLaunchKernelGGL(enc0_mfma<false>, dim3(grid), dim3(WG0), lds, ctx->stream, a);
         } else {
             EncArgs a;
             a.in = act[i]; a.out = act[i + 1];
@@ -808,20 +828,23 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
             a.mWp = magic(Wp); a.mNb = magic(nbands); a.mRC = magic(TC * (cin / 8)); a.zero = prep + pr->zero;
             int rc = COVAHIP_OK;
             if (i == 1) {
-                rc = set_lds(ctx, enc_mfma<16, 32, 2, 4, 8>, lds);
+                rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true>, lds) : set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, false>, lds);
                 if (rc) return rc;
                 ProfScope ps(ctx, "enc1_mfma");
-                hipLaunchKernelGGL((enc_mfma<16, 32, 2, 4, 8>), dim3(grid), dim3(512), lds, ctx->stream, a);
+                if (pr->allpos[i]) hipLaunchKernelGGL((enc_mfma<16, 32, 2, 4, 8, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
+                else hipLaunchKernelGGL((enc_mfma<16, 32, 2, 4, 8, false>), dim3(grid), dim3(512), lds, ctx->stream, a);
             } else if (i == 2) {
-                rc = set_lds(ctx, enc_mfma<32, 64, 4, 2, 4>, lds);
+                rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<32, 64, 4, 2, 4, true>, lds) : set_lds(ctx, enc_mfma<32, 64, 4, 2, 4, false>, lds);
                 if (rc) return rc;
                 ProfScope ps(ctx, "enc2_mfma");
-                hipLaunchKernelGGL((enc_mfma<32, 64, 4, 2, 4>), dim3(grid), dim3(WG), lds, ctx->stream, a);
+                if (pr->allpos[i]) hipLaunchKernelGGL((enc_mfma<32, 64, 4, 2, 4, true>), dim3(grid), dim3(WG), lds, ctx->stream, a);
+                else hipLaunchKernelGGL((enc_mfma<32, 64, 4, 2, 4, false>), dim3(grid), dim3(WG), lds, ctx->stream, a);
             } else {
-                rc = set_lds(ctx, enc_mfma<64, 128, 2, 2, 8>, lds);
+                rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<64, 128, 2, 2, 8, true>, lds) : set_lds(ctx, enc_mfma<64, 128, 2, 2, 8, false>, lds);
                 if (rc) return rc;
                 ProfScope ps(ctx, "enc3_mfma");
-                hipLaunchKernelGGL((enc_mfma<64, 128, 2, 2, 8>), dim3(grid), dim3(512), lds, ctx->stream, a);
+                if (pr->allpos[i]) hipLaunchKernelGGL((enc_mfma<64, 128, 2, 2, 8, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
+                else hipLaunchKernelGGL((enc_mfma<64, 128, 2, 2, 8, false>), dim3(grid), dim3(512), lds, ctx->stream, a);
             }
         }
         COVAHIP_CHECK_HIP(ctx, hipGetLastError());
