@@ -102,7 +102,8 @@ def cpu_baseline(flat, stack_sample, target_seconds=10.0):
     try:
         import torch
         from tests import torch_blobnet as tb
-        torch.set_num_threads(cores)
+        tthreads = min(cores, 32)        # more threads than that slow these small convolutions down
+        torch.set_num_threads(tthreads)
         nt = min(len(stack_sample), 64)
         with torch.no_grad():
             tb.forward(flat, stack_sample[:8], H_MB, W_MB)                      # warm-up
@@ -113,6 +114,7 @@ def cpu_baseline(flat, stack_sample, target_seconds=10.0):
                 reps_t += 1
             t_torch = (time.perf_counter() - t0) / reps_t
         torch_fps = nt / (t_torch + t_cc * nt / n)
+        out["torch_cpu_threads"] = tthreads
         out["torch_cpu_blobnet_frames_per_s"] = round(nt / t_torch, 2)
         out["torch_cpu_combined_frames_per_s"] = round(torch_fps, 2)
         if torch_fps > best:
