@@ -60,3 +60,14 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in src.replace("# oracle-free", ""), f"{f} mentions the oracle"
+
+
+def test_null_and_invalid_arguments_do_not_need_a_gpu():
+    lib = L.lib()
+    assert lib.covahip_blobnet_load(None, b"x" * 64, 64, 68, 120, 4, 1) == 1
+    assert lib.covahip_ctx_sync(None) == 1
+    assert lib.covahip_sort_new(3, 3, 0.2, None) == 1
+    assert lib.covahip_stack_new(0, 4, 1, C.byref(C.c_void_p())) == 1
+    assert lib.covahip_stack_new(16, 0, 1, C.byref(C.c_void_p())) == 1
+    n = C.c_size_t()
+    assert lib.covahip_bbox_deserialize_vec(None, 0, None, 0, C.byref(n)) == 1
