@@ -1,0 +1,95 @@
+"""Size-independent properties of the HIP path at BASELINE sizes (b=256, 68x120), where running the
+oracle on everything would take too long for a test: conservation laws and invariances."""
+import numpy as np
+import pytest
+
+from cova_amd import _lib as L
+from cova_amd import synth
+from cova_amd.elements import BboxCc, BlobNetInfer
+
+pytestmark = pytest.mark.gpu
+H, W, B = 68, 120, 256
+
+
+def _boxes(ctx, masks, thr=1, cap=2048):
+    cc = BboxCc(ctx, cc_threshold=thr, max_boxes=cap)
+    return cc.regionprops(masks)
+
+
+@pytest.mark.parametrize("density", [0.03, 0.2, 0.45])
+def test_ccl_conservation_and_bounds(ctx, density):
+    masks = synth.random_masks(B, H, W, density, seed=int(density * 100))
+    boxes, counts = _boxes(ctx, masks)
+    for i in range(B):
+        b = boxes[i, :counts[i]]
+        # every foreground pixel belongs to exactly one component
+        assert int(b["area_px"].sum()) == int(masks[i].sum())
+        assert (b["left"] >= 0).all() and (b["top"] >= 0).all()
+        assert (b["left"] + b["width"] <= W).all() and (b["top"] + b["height"] <= H).all()
+        assert (b["area_px"] <= b["width"] * b["height"]).all() and (b["area_px"] >= 1).all()
+        # a component's box corners rows/cols really contain foreground
+        for bx in b[:5]:
+            sub = masks[i, bx["top"]:bx["top"] + bx["height"], bx["left"]:bx["left"] + bx["width"]]
+            assert sub[0].any() and sub[-1].any() and sub[:, 0].any() and sub[:, -1].any()
+
+
+def test_ccl_threshold_is_a_filter_of_the_unfiltered_list(ctx):
+    masks = synth.random_masks(B, H, W, 0.25, seed=77)
+    b1, c1 = _boxes(ctx, masks, 1)
+    b30, c30 = _boxes(ctx, masks, 30)
+    for i in range(0, B, 17):
+        full = b1[i, :c1[i]]
+        keep = full[full["area_px"] >= 30]
+        np.testing.assert_array_equal(keep, b30[i, :c30[i]])      # same boxes, same order
+
+
+def test_ccl_block_translation_invariance(ctx):
+    """Shifting a mask by one 2x2 block (2 px) right/down shifts every box and keeps the order."""
+    rng = np.random.default_rng(5)
+    m = np.zeros((64, H, W), np.uint8)
+    m[:, 2:H - 4, 2:W - 4] = (rng.random((64, H - 6, W - 6)) < 0.2)
+    shifted = np.zeros_like(m)
+    shifted[:, 2:, 2:] = m[:, :-2, :-2]
+    b0, c0 = _boxes(ctx, m)
+    b1, c1 = _boxes(ctx, shifted)
+    np.testing.assert_array_equal(c0, c1)
+    for i in range(64):
+        a, b = b0[i, :c0[i]], b1[i, :c1[i]]
+        np.testing.assert_array_equal(a["left"] + 2, b["left"])
+        np.testing.assert_array_equal(a["top"] + 2, b["top"])
+        np.testing.assert_array_equal(a["area_px"], b["area_px"])
+
+
+def test_ccl_is_deterministic_over_repeated_launches(ctx):
+    masks = synth.random_masks(B, H, W, 0.3, seed=9)
+    ref_b, ref_c = _boxes(ctx, masks)
+    for _ in range(5):
+        b, c = _boxes(ctx, masks)
+        np.testing.assert_array_equal(c, ref_c)
+        np.testing.assert_array_equal(b, ref_b)
+
+
+def test_blobnet_full_batch_determinism_and_permutation(ctx, weights_flat):
+    """Frames are independent: permuting the batch permutes the logits bit for bit, and two runs of the
+    same batch agree bit for bit (no atomics / no order dependence in the BlobNet kernels)."""
+    stack = synth.stacked_batch(B, H, W, seed=123, streams=8)
+    net = BlobNetInfer(ctx, weights_flat, H, W, max_batch=B)
+    l0, m0 = net.infer(stack)
+    l1, m1 = net.infer(stack)
+    np.testing.assert_array_equal(l0, l1)
+    perm = np.random.default_rng(0).permutation(B)
+    l2, m2 = net.infer(stack[perm])
+    np.testing.assert_array_equal(l0[perm], l2)
+    np.testing.assert_array_equal(m0[perm], m2)
+    assert 0.0 < m0.mean() < 1.0
+
+
+def test_fused_counts_match_separate_path_full_batch(ctx, weights_flat):
+    stack = synth.stacked_batch(B, H, W, seed=321, streams=8)
+    net = BlobNetInfer(ctx, weights_flat, H, W, max_batch=B)
+    boxes, counts, mask = net.filter(stack, cc_threshold=1, max_boxes=2048, want_mask=True)
+    b2, c2 = _boxes(ctx, mask)
+    np.testing.assert_array_equal(counts, c2)
+    assert int(boxes["area_px"].sum()) == int(mask.sum())          # checksum of checksums
+    for i in range(0, B, 31):
+        np.testing.assert_array_equal(boxes[i, :counts[i]], b2[i, :c2[i]])
