@@ -90,6 +90,9 @@ PROTOTYPES = {
     "covahip_bbox_deserialize_vec": (C.c_int, [_P, _SZ, _P, _SZ, C.POINTER(_SZ)]),
     "covahip_frame_serialize": (_SZ, [C.c_uint64, C.c_uint64, _P, _SZ, _P, _SZ, C.POINTER(C.c_int)]),
     "covahip_bbox_iou": (C.c_float, [_P, _P]),
+    "covahip_tfrecord_example": (_SZ, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _SZ, C.POINTER(C.c_int)]),
+    "covahip_bbox_csv": (_SZ, [_P, _SZ, C.c_int, _P, _SZ, C.POINTER(C.c_int)]),
+    "covahip_tracks_export": (_SZ, [C.c_uint64, C.c_uint64, _P, _P, _SZ, _P, _SZ, C.POINTER(C.c_int)]),
     "covahip_stack_new": (C.c_int, [_SZ, C.c_uint, C.c_uint, C.POINTER(_P)]),
     "covahip_stack_free": (None, [_P]),
     "covahip_stack_push": (C.c_int, [_P, _P, _SZ, _P, _SZ, C.POINTER(C.c_int)]),

@@ -926,3 +926,159 @@ int covahip_gopfilter_counters(const covahip_gopfilter *g, uint64_t *dropped, ui
 }
 
 }  // extern "C"
+
+// ============================================================== sink formats + track export
+// (data formats either side of the hot path)
+//   tfrecordsink  cova-rs/gst-plugins/src/tfrecordsink/imp.rs:69-198  one tf.train.Example per frame / GoP
+//   bboxsink      cova-rs/gst-plugins/src/bboxsink/imp.rs:252-270     serde CSV rows of Bbox
+//   track export  cova-rs/gst-plugins/src/cova/tracker.rs:59-83       LengthDelimitedCodec(bincode Frame)
+#include <charconv>
+#include <string>
+
+namespace {
+
+uint32_t crc32c_table[256];
+bool crc32c_ready = false;
+uint32_t crc32c(const uint8_t *p, size_t n) {  // Castagnoli, reflected, as TFRecord uses it
+    if (!crc32c_ready) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            crc32c_table[i] = c;
+        }
+        crc32c_ready = true;
+    }
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; i++) c = crc32c_table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+uint32_t masked_crc(const uint8_t *p, size_t n) {
+    const uint32_t c = crc32c(p, n);
+    return ((c >> 15) | (c << 17)) + 0xa282ead8u;
+}
+void put_varint(std::string &s, uint64_t v) {
+    while (v >= 0x80) { s.push_back((char)(v | 0x80)); v >>= 7; }
+    s.push_back((char)v);
+}
+void put_len_field(std::string &s, int field, const std::string &payload) {
+    put_varint(s, (uint64_t)(field << 3 | 2));
+    put_varint(s, payload.size());
+    s += payload;
+}
+
+// serde/csv formats f32 with ryu: shortest round-trip digits, always a ".0" on integral values,
+// exponents as "e21" / "e-7"
+std::string ryu_like(float v) {
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v > 0 ? "inf" : "-inf";
+    char buf[64];
+    auto r = std::to_chars(buf, buf + sizeof(buf), v);
+    std::string s(buf, r.ptr);
+    const size_t e = s.find('e');
+    if (e != std::string::npos) {
+        std::string mant = s.substr(0, e), ex = s.substr(e + 1);
+        bool neg = false;
+        if (!ex.empty() && (ex[0] == '+' || ex[0] == '-')) { neg = ex[0] == '-'; ex = ex.substr(1); }
+        while (ex.size() > 1 && ex[0] == '0') ex = ex.substr(1);
+        return mant + "e" + (neg ? "-" : "") + ex;
+    }
+    if (s.find('.') == std::string::npos) s += ".0";
+    return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+// One framed TFRecord record holding a tf.train.Example with the four bytes_list features
+// mb_type / mv_x / mv_y / gt, one w*h-byte string per frame (tfrecordsink/imp.rs:105-130), zero
+// filled up to `pad_to_frames` strings when that is larger than n_frames (the `gop` property,
+// imp.rs:156-167).  rgba: [n_frames][h][w][4]; gt: [n_frames][h*w].  Feature order is fixed here
+// (the reference's HashMap order is random): parity is at parsed-record level.
+size_t covahip_tfrecord_example(const uint8_t *rgba, const uint8_t *gt, int n_frames, int pad_to_frames, int w, int h,
+                                uint8_t *out, size_t cap, int *status) {
+    const size_t hw = (size_t)w * h;
+    const int total = pad_to_frames > n_frames ? pad_to_frames : n_frames;
+    static const char *names[4] = {"mb_type", "mv_x", "mv_y", "gt"};
+    std::string features;
+    for (int f = 0; f < 4; f++) {
+        std::string blist;
+        for (int i = 0; i < total; i++) {
+            std::string v(hw, '\0');
+            if (i < n_frames) {
+                if (f < 3) for (size_t p = 0; p < hw; p++) v[p] = (char)rgba[((size_t)i * hw + p) * 4 + f];
+                else if (gt) std::memcpy(&v[0], gt + (size_t)i * hw, hw);
+            }
+            put_len_field(blist, 1, v);                       // BytesList.value
+        }
+        std::string feature;
+        put_len_field(feature, 1, blist);                     // Feature.bytes_list
+        std::string entry;
+        put_len_field(entry, 1, names[f]);                    // map key
+        put_len_field(entry, 2, feature);                     // map value
+        put_len_field(features, 1, entry);                    // Features.feature
+    }
+    std::string example;
+    put_len_field(example, 1, features);                      // Example.features
+    const uint64_t len = example.size();
+    const size_t need = 8 + 4 + example.size() + 4;
+    if (status) *status = (out && need <= cap) ? COVAHIP_OK : COVAHIP_ERR_OVERFLOW;
+    if (out && need <= cap) {
+        std::memcpy(out, &len, 8);
+        const uint32_t c1 = masked_crc(out, 8);
+        std::memcpy(out + 8, &c1, 4);
+        std::memcpy(out + 12, example.data(), example.size());
+        const uint32_t c2 = masked_crc((const uint8_t *)example.data(), example.size());
+        std::memcpy(out + 12 + example.size(), &c2, 4);
+    }
+    return need;
+}
+
+// CSV text of bboxsink: header (serde field order of Bbox, bbox.rs:4-14) and one row per box;
+// None -> empty field.
+size_t covahip_bbox_csv(const covahip_bbox *boxes, size_t n, int with_header, char *out, size_t cap, int *status) {
+    std::string s;
+    if (with_header) s += "left,top,width,height,area,track_id,timestamp,class_id,confidence\n";
+    for (size_t i = 0; i < n; i++) {
+        const covahip_bbox &b = boxes[i];
+        s += ryu_like(b.left) + "," + ryu_like(b.top) + "," + ryu_like(b.width) + "," + ryu_like(b.height) + "," +
+             ryu_like(b.area) + ",";
+        if (b.has_track_id) s += std::to_string(b.track_id);
+        s += ",";
+        if (b.has_timestamp) s += std::to_string(b.timestamp);
+        s += ",";
+        if (b.has_class_id) s += std::to_string(b.class_id);
+        s += ",";
+        if (b.has_confidence) s += ryu_like(b.confidence);
+        s += "\n";
+    }
+    if (status) *status = (out && s.size() <= cap) ? COVAHIP_OK : COVAHIP_ERR_OVERFLOW;
+    if (out && s.size() <= cap) std::memcpy(out, s.data(), s.size());
+    return s.size();
+}
+
+// Track export of cova::Tracker (cova/tracker.rs:59-83): for every dead track one
+// LengthDelimitedCodec frame = 4-byte big-endian length + bincode(Frame{range_start, oldest,
+// bboxes = the track's history}).  tracks: flattened histories + per-track lengths as
+// covahip_sort_update returns them.  (The reference re-sends earlier frames because its buffer is
+// never cleared; that bug is not reproduced: each track is emitted once.)
+size_t covahip_tracks_export(uint64_t range_start, uint64_t oldest, const covahip_bbox *boxes, const uint32_t *track_lens,
+                             size_t n_tracks, uint8_t *out, size_t cap, int *status) {
+    size_t need = 0, off = 0;
+    for (size_t t = 0; t < n_tracks; t++) {
+        const size_t fl = covahip_frame_serialize(range_start, oldest, boxes + off, track_lens[t], nullptr, 0, nullptr);
+        if (out && need + 4 + fl <= cap) {
+            const uint32_t be = (uint32_t)fl;
+            out[need] = (uint8_t)(be >> 24); out[need + 1] = (uint8_t)(be >> 16);
+            out[need + 2] = (uint8_t)(be >> 8); out[need + 3] = (uint8_t)be;
+            int st = 0;
+            covahip_frame_serialize(range_start, oldest, boxes + off, track_lens[t], out + need + 4, fl, &st);
+        }
+        need += 4 + fl;
+        off += track_lens[t];
+    }
+    if (status) *status = (out && need <= cap) ? COVAHIP_OK : COVAHIP_ERR_OVERFLOW;
+    return need;
+}
+
+}  // extern "C"

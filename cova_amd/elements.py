@@ -259,6 +259,44 @@ def iou(a: np.ndarray, b: np.ndarray) -> float:
     return float(L.lib().covahip_bbox_iou(_ptr(a), _ptr(b)))
 
 
+def _sized_call(fn, what: str) -> bytes:
+    """Two-pass size query / fill convention of the byte-format entry points."""
+    need = fn(None, 0, None)
+    buf = np.zeros(max(need, 1), np.uint8)
+    st = C.c_int()
+    fn(_ptr(buf), need, C.byref(st))
+    L.check(st.value, what)
+    return buf[:need].tobytes()
+
+
+def tfrecord_example(rgba: np.ndarray, gt=None, gop: int = 0) -> bytes:
+    """One framed TFRecord record as `tfrecordsink` writes per GoP (tfrecordsink/imp.rs:69-198): features
+    mb_type / mv_x / mv_y = bytes 0 / 1 / 2 of every RGBA pixel per frame, gt = label bytes, zero-filled to `gop` frames."""
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+    n, h, w, _ = rgba.shape
+    g = None if gt is None else np.ascontiguousarray(gt, dtype=np.uint8).reshape(n, h * w)
+    lib = L.lib()
+    return _sized_call(lambda o, c, st: lib.covahip_tfrecord_example(_ptr(rgba), None if g is None else _ptr(g), n, gop, w, h,
+                                                                     o, c, st), "tfrecord_example")
+
+
+def bbox_csv(bboxes: np.ndarray, with_header: bool = True) -> str:
+    """The CSV rows `bboxsink` writes (bboxsink/imp.rs:252-270; serde field order of bbox.rs:12-27)."""
+    b = np.ascontiguousarray(bboxes, dtype=L.BBOX_DTYPE)
+    lib = L.lib()
+    return _sized_call(lambda o, c, st: lib.covahip_bbox_csv(_ptr(b), b.shape[0], int(with_header), o, c, st), "bbox_csv").decode()
+
+
+def tracks_export(range_start: int, oldest: int, dead_boxes: np.ndarray, track_lens: np.ndarray) -> bytes:
+    """Bytes the `cova` element's tracker task sends per finished GoP (cova/tracker.rs:59-83): per track a 4-byte
+    big-endian length followed by the bincode `Frame`."""
+    b = np.ascontiguousarray(dead_boxes, dtype=L.BBOX_DTYPE)
+    t = np.ascontiguousarray(track_lens, dtype=np.uint32)
+    lib = L.lib()
+    return _sized_call(lambda o, c, st: lib.covahip_tracks_export(range_start, oldest, _ptr(b), _ptr(t), t.shape[0], o, c, st),
+                       "tracks_export")
+
+
 # ------------------------------------------------------------------------------ bboxcc
 class BboxCc:
     """`bboxcc` (BaseTransform, AlwaysInPlace): property `cc-threshold` (default 30)."""

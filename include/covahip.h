@@ -172,6 +172,22 @@ size_t covahip_frame_serialize(uint64_t range_start, uint64_t oldest, const cova
 /* Bbox::iou (bbox.rs:39-56). */
 float covahip_bbox_iou(const covahip_bbox *a, const covahip_bbox *b);
 
+/* ------------------------------------------------------ sink formats, track export
+ * Data formats either side of the hot path.               */
+/* tfrecordsink (cova-rs/gst-plugins/src/tfrecordsink/imp.rs:69-198): one framed TFRecord record =
+ * tf.train.Example with bytes_list features mb_type / mv_x / mv_y / gt, one w*h string per frame,
+ * zero-filled to pad_to_frames strings (the `gop` property).  rgba: [n_frames][h][w][4] (a
+ * metapreprocess timestep=1 frame), gt: [n_frames][h*w] or NULL.  Returns the record size. */
+size_t covahip_tfrecord_example(const uint8_t *rgba, const uint8_t *gt, int n_frames, int pad_to_frames, int w, int h,
+                                uint8_t *out, size_t cap, int *status);
+/* bboxsink (cova-rs/gst-plugins/src/bboxsink/imp.rs:252-270): serde-CSV text, optional header. */
+size_t covahip_bbox_csv(const covahip_bbox *boxes, size_t n, int with_header, char *out, size_t cap, int *status);
+/* cova track export (cova-rs/gst-plugins/src/cova/tracker.rs:59-83): per dead track a 4-byte
+ * big-endian length + bincode Frame{range_start, oldest, history}; boxes/track_lens as returned by
+ * covahip_sort_update / covahip_sort_finalize. */
+size_t covahip_tracks_export(uint64_t range_start, uint64_t oldest, const covahip_bbox *boxes, const uint32_t *track_lens,
+                             size_t n_tracks, uint8_t *out, size_t cap, int *status);
+
 /* ------------------------------------------------- metapreprocess stacking
  * Host state of the `metapreprocess` element (cova-rs/gst-plugins/src/metapreprocess/
  * imp.rs:204-332): keeps the last timestep-1 inputs, emits one stacked frame every
