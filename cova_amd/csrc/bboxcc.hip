@@ -26,7 +26,7 @@
 
 namespace {
 
-constexpr int CC_THREADS = 256;
+constexpr int CC_THREADS = 1024;  // 16 waves: the union-find phases are LDS-latency bound, so run 4 waves per SIMD
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint32_t uf_find(const volatile uint32_t *lab, uint32_t i) {
@@ -79,6 +79,7 @@ __global__ __launch_bounds__(CC_THREADS) void bboxcc_kernel(const uint8_t *__res
     uint32_t *s_maxx = s_minx + NB;
     uint32_t *s_miny = s_maxx + NB;
     uint32_t *s_maxy = s_miny + NB;
+    uint8_t *binfo = (uint8_t *)(s_maxy + NB);            // [NB] fg nibble | conn nibble << 4
     __shared__ uint32_t wave_tot[CC_THREADS / 64];
 
     // ---- phase 0: clear packed rows (pads must be zero)
@@ -109,99 +110,73 @@ __global__ __launch_bounds__(CC_THREADS) void bboxcc_kernel(const uint8_t *__res
     }
     __syncthreads();
 
-    // ---- phase 2: per packed byte of a block row -> 4 blocks: nibble + connections
-    // A work item keeps its blocks' info in registers across the union phase.
+    // ---- phase 2: per packed byte of a block row -> 4 blocks: nibble + connections, parked as one
+    // byte per block (fg nibble | conn nibble << 4) so that the union / statistics phases run one
+    // block per work item.
     const int n_units = g.BH * NXB;
-    constexpr int MAX_UNITS = 4;  // units per thread this kernel is sized for (host checks)
-    uint32_t info[MAX_UNITS];     // per unit: 4 x 8 bits = fg nibble | conn nibble << 4
+    for (int q = tid; q < n_units; q += CC_THREADS) {
+        const int by = q / NXB, xc = q - by * NXB;
+        const int r = 2 * by;
+        // 24-bit windows: bit 8+k = pixel 8*xc+k; bits 7 / 16 = neighbours across bytes
+        const uint8_t *p0 = rb + (r + 0) * RS + xc;  // row r-1 (stored at index r), byte xc-1
+        const uint8_t *p1 = p0 + RS;                 // row r
+        const uint8_t *p2 = p1 + RS;                 // row r+1
+        const uint32_t up = p0[0] | (p0[1] << 8) | (p0[2] << 16);
+        const uint32_t ra = p1[0] | (p1[1] << 8) | (p1[2] << 16);
+        const uint32_t rc = p2[0] | (p2[1] << 8) | (p2[2] << 16);
 #pragma unroll
-    for (int u = 0; u < MAX_UNITS; u++) {
-        const int q = tid + u * CC_THREADS;
-        info[u] = 0;
-        if (q < n_units) {
-            const int by = q / NXB, xc = q - by * NXB;
-            const int r = 2 * by;
-            // 24-bit windows: bit 8+k = pixel 8*xc+k; bits 7 / 16 = neighbours across bytes
-            const uint8_t *p0 = rb + (r + 0) * RS + xc;  // row r-1 (stored at index r), byte xc-1
-            const uint8_t *p1 = p0 + RS;                 // row r
-            const uint8_t *p2 = p1 + RS;                 // row r+1
-            const uint32_t up = p0[0] | (p0[1] << 8) | (p0[2] << 16);
-            const uint32_t ra = p1[0] | (p1[1] << 8) | (p1[2] << 16);
-            const uint32_t rc = p2[0] | (p2[1] << 8) | (p2[2] << 16);
-            uint32_t packed = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int bx = xc * 4 + j;
-                const int s = 8 + 2 * j;  // bit of pixel column c = 2*bx
-                const uint32_t a = (ra >> s) & 1, b = (ra >> (s + 1)) & 1;
-                const uint32_t c = (rc >> s) & 1, d = (rc >> (s + 1)) & 1;
-                const uint32_t fg = a | (b << 1) | (c << 2) | (d << 3);
-                const uint32_t u_l = (up >> (s - 1)) & 1, u_0 = (up >> s) & 1, u_1 = (up >> (s + 1)) & 1,
-                               u_r = (up >> (s + 2)) & 1;
-                const uint32_t l_a = (ra >> (s - 1)) & 1, l_c = (rc >> (s - 1)) & 1;
-                const uint32_t cL = (a | c) & (l_a | l_c);
-                const uint32_t cUL = a & u_l;
-                const uint32_t cU = (a | b) & (u_0 | u_1);
-                const uint32_t cUR = b & u_r;
-                const uint32_t conn = cL | (cUL << 1) | (cU << 2) | (cUR << 3);
-                const uint32_t blk = by * BW + bx;
-                if (bx < BW) {
-                    lab[blk] = fg ? blk : NONE;
-                    s_area[blk] = 0;
-                    s_minx[blk] = 0x7FFFFFFF;
-                    s_maxx[blk] = 0;
-                    s_miny[blk] = 0x7FFFFFFF;
-                    s_maxy[blk] = 0;
-                    packed |= (fg | (conn << 4)) << (8 * j);
-                }
+        for (int j = 0; j < 4; j++) {
+            const int bx = xc * 4 + j;
+            const int s = 8 + 2 * j;  // bit of pixel column c = 2*bx
+            const uint32_t a = (ra >> s) & 1, b = (ra >> (s + 1)) & 1;
+            const uint32_t c = (rc >> s) & 1, d = (rc >> (s + 1)) & 1;
+            const uint32_t fg = a | (b << 1) | (c << 2) | (d << 3);
+            const uint32_t u_l = (up >> (s - 1)) & 1, u_0 = (up >> s) & 1, u_1 = (up >> (s + 1)) & 1,
+                           u_r = (up >> (s + 2)) & 1;
+            const uint32_t l_a = (ra >> (s - 1)) & 1, l_c = (rc >> (s - 1)) & 1;
+            const uint32_t cL = (a | c) & (l_a | l_c);
+            const uint32_t cUL = a & u_l;
+            const uint32_t cU = (a | b) & (u_0 | u_1);
+            const uint32_t cUR = b & u_r;
+            const uint32_t conn = cL | (cUL << 1) | (cU << 2) | (cUR << 3);
+            const uint32_t blk = by * BW + bx;
+            if (bx < BW) {
+                lab[blk] = fg ? blk : NONE;
+                s_area[blk] = 0;
+                s_minx[blk] = 0x7FFFFFFF;
+                s_maxx[blk] = 0;
+                s_miny[blk] = 0x7FFFFFFF;
+                s_maxy[blk] = 0;
+                binfo[blk] = (uint8_t)(fg | (conn << 4));
             }
-            info[u] = packed;
         }
     }
     __syncthreads();
 
     // ---- phase 3: unions with the four prior neighbours
-#pragma unroll
-    for (int u = 0; u < MAX_UNITS; u++) {
-        const int q = tid + u * CC_THREADS;
-        if (q < n_units && (info[u] & 0xF0F0F0F0u)) {
-            const int by = q / NXB, xc = q - by * NXB;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t conn = (info[u] >> (8 * j + 4)) & 0xF;
-                if (!conn) continue;
-                const uint32_t blk = by * BW + xc * 4 + j;
-                if (conn & 1) uf_union(lab, blk, blk - 1);
-                if (conn & 4) uf_union(lab, blk, blk - BW);
-                if (conn & 2) uf_union(lab, blk, blk - BW - 1);
-                if (conn & 8) uf_union(lab, blk, blk - BW + 1);
-            }
-        }
+    for (int blk = tid; blk < NB; blk += CC_THREADS) {
+        const uint32_t conn = binfo[blk] >> 4;
+        if (!conn) continue;
+        if (conn & 1) uf_union(lab, blk, blk - 1);
+        if (conn & 4) uf_union(lab, blk, blk - BW);
+        if (conn & 2) uf_union(lab, blk, blk - BW - 1);
+        if (conn & 8) uf_union(lab, blk, blk - BW + 1);
     }
     __syncthreads();
 
     // ---- phase 4+5: flatten and accumulate statistics on the root
-#pragma unroll
-    for (int u = 0; u < MAX_UNITS; u++) {
-        const int q = tid + u * CC_THREADS;
-        if (q < n_units && (info[u] & 0x0F0F0F0Fu)) {
-            const int by = q / NXB, xc = q - by * NXB;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t fg = (info[u] >> (8 * j)) & 0xF;
-                if (!fg) continue;
-                const uint32_t bx = xc * 4 + j;
-                const uint32_t blk = by * BW + bx;
-                const uint32_t root = uf_find(lab, blk);
-                const uint32_t x0 = 2 * bx + ((fg & 5) ? 0 : 1), x1 = 2 * bx + ((fg & 10) ? 1 : 0);
-                const uint32_t y0 = 2 * by + ((fg & 3) ? 0 : 1), y1 = 2 * by + ((fg & 12) ? 1 : 0);
-                atomicAdd(&s_area[root], __popc(fg));
-                atomicMin(&s_minx[root], x0);
-                atomicMax(&s_maxx[root], x1);
-                atomicMin(&s_miny[root], y0);
-                atomicMax(&s_maxy[root], y1);
-            }
-        }
+    for (int blk = tid; blk < NB; blk += CC_THREADS) {
+        const uint32_t fg = binfo[blk] & 0xF;
+        if (!fg) continue;
+        const uint32_t by = (uint32_t)blk / (uint32_t)BW, bx = blk - by * BW;
+        const uint32_t root = uf_find(lab, blk);
+        const uint32_t x0 = 2 * bx + ((fg & 5) ? 0 : 1), x1 = 2 * bx + ((fg & 10) ? 1 : 0);
+        const uint32_t y0 = 2 * by + ((fg & 3) ? 0 : 1), y1 = 2 * by + ((fg & 12) ? 1 : 0);
+        atomicAdd(&s_area[root], __popc(fg));
+        atomicMin(&s_minx[root], x0);
+        atomicMax(&s_maxx[root], x1);
+        atomicMin(&s_miny[root], y0);
+        atomicMax(&s_maxy[root], y1);
     }
     __syncthreads();
 
@@ -264,10 +239,9 @@ int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, in
     g.NXB = (w + 7) / 8;
     g.RS = g.NXB + 2;
     const size_t rb_bytes = (((size_t)(h + 3) * g.RS) + 15) & ~(size_t)15;
-    const size_t lds = rb_bytes + (size_t)g.NB * 4 * 6;
-    const int n_units = g.BH * g.NXB;
-    // Shapes the kernel and its grid assume (checked on the host before any launch).
-    if (lds + 64 > 160 * 1024 || n_units > 4 * CC_THREADS) return COVAHIP_ERR_UNSUPPORTED;
+    const size_t lds = rb_bytes + (size_t)g.NB * 4 * 6 + (((size_t)g.NB + 15) & ~(size_t)15);
+    // Shapes the kernel assumes (checked on the host before any launch).
+    if (lds + 64 > 160 * 1024) return COVAHIP_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {

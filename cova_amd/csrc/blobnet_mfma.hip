@@ -24,6 +24,7 @@
 // Reference semantics: utils/model/preprocessing.py:6-7, encoder.py:30-80, pointwise.py:8-26,
 // decoder.py:5-134, blobnet.py:8-48; hyper-parameters utils/train-blobnet.py:57-69.
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -34,6 +35,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -76,17 +78,21 @@ inline uint32_t magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32
 // ReLU and the pool (encoder.py:61-66) and gamma may be negative, so the pool picks the max
 // for scale >= 0 and the min otherwise: max_q(relu(a_q)*s + b) = relu(sel_q a_q)*s + b.
 // The conv bias commutes with max/min and is added after the selection.
-// ALLPOS: every BN scale of the level is >= 0 (checked on the host), so the min path is dropped.
+// ALLPOS: every BN scale s of the level is >= 0 (checked on the host).  Then s is folded into the
+// weights and the bias on the host (relu(x)*s = relu(x*s)) and, with b' = bias*s,
+//   relu(mx + b') + shift = max(mx, -b') + (b' + shift)
+// so one window costs two v_max3 and one add: e0 = -b', e1 = b' + shift.
+// Otherwise e0 = bias, e1 = scale, e2 = shift with unfolded weights.
 template <bool ALLPOS>
-__device__ __forceinline__ float pool4(float a0, float a1, float a2, float a3, float bias, float scale,
-                                       float shift) {
-    const float mx = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+__device__ __forceinline__ float pool4(float a0, float a1, float a2, float a3, float e0, float e1, float e2) {
     if constexpr (ALLPOS) {
-        return fmaxf(mx + bias, 0.f) * scale + shift;
+        const float t = fmaxf(fmaxf(a0, a1), a2);
+        return fmaxf(fmaxf(t, a3), e0) + e1;
     } else {
+        const float mx = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
         const float mn = fminf(fminf(a0, a1), fminf(a2, a3));
-        const float sel = scale >= 0.f ? mx : mn;
-        return fmaxf(sel + bias, 0.f) * scale + shift;
+        const float sel = e1 >= 0.f ? mx : mn;
+        return fmaxf(sel + e0, 0.f) * e1 + e2;
     }
 }
 
@@ -110,15 +116,21 @@ __device__ __forceinline__ TmixW load_tmix(const float *tm, int lane) {
     }
     return w;
 }
-__device__ __forceinline__ void tmix4(const TmixW &w, const float (&p)[BN_T], float (&o)[BN_T]) {
-    const half4 pb = {(_Float16)p[0], (_Float16)p[1], (_Float16)p[2], (_Float16)p[3]};
-    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ void tmix4(const TmixW &w, const float (&p)[BN_T], half4 &o) {
+    const f32x4 pv = {p[0], p[1], p[2], p[3]};
+    const half4 pb = __builtin_convertvector(pv, half4);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const half4 hz = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
     const f32x4 u = __builtin_amdgcn_mfma_f32_4x4x4f16(w.a1, pb, z, 0, 0, 0);
-    const half4 ub = {(_Float16)fmaxf(u[0], 0.f), (_Float16)fmaxf(u[1], 0.f), (_Float16)fmaxf(u[2], 0.f),
-                      (_Float16)fmaxf(u[3], 0.f)};
+    // relu after the rounding to fp16 (same value as rounding after the relu; packed max)
+    const half4 ub = __builtin_elementwise_max(__builtin_convertvector(u, half4), hz);
     const f32x4 v = __builtin_amdgcn_mfma_f32_4x4x4f16(w.a2, ub, z, 0, 0, 0);
+    // relu(relu(v) + p) = max(v + p, p, 0)
+    const f32x4 sum = v + pv;
+    f32x4 r;
 #pragma unroll
-    for (int t = 0; t < BN_T; t++) o[t] = fmaxf(fmaxf(v[t], 0.f) + p[t], 0.f);
+    for (int t = 0; t < BN_T; t++) r[t] = fmaxf(fmaxf(sum[t], pv[t]), 0.f);
+    o = __builtin_convertvector(r, half4);
 }
 
 // Asynchronous 16-byte global -> LDS copy (LDS-DMA): every lane supplies its own global source
@@ -141,6 +153,8 @@ struct Enc0Args {
     int B, H, W, Hp, Wp, Ho, Wo, oy, ox;
     int RB, nbands, TR, TC;
     uint32_t mWp, mNb, mW4;
+    int scr_off;   // byte offset of the per-wave output transpose scratch (1 KB per wave) in LDS
+    int dbg;
 };
 
 struct EncArgs {
@@ -152,6 +166,8 @@ struct EncArgs {
     int RB, nbands, TR, TC;
     uint32_t mWp, mNb, mRC;
     const void *zero;  // >= 16 zero bytes in global memory (source of halo / padding chunks)
+    int scr_off;       // byte offset of the per-wave output transpose scratch (2 KB per wave) in LDS (WIDE)
+    int dbg;
 };
 
 struct DecArgs {
@@ -179,6 +195,7 @@ constexpr int WG0 = 512;  // 8 waves: the per-tile dependency chain is latency b
 template <bool ALLPOS>
 __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if (p.dbg & 16) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int TR = p.TR, TC = p.TC;
     const int tsz = TR * TC * 8;  // bytes per T slice
@@ -186,10 +203,10 @@ __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
     const half8 be0 = p.wfrag[lane], be1 = p.wfrag[64 + lane];          // even-x weight set
     const half8 bo0 = p.wfrag[128 + lane], bo1 = p.wfrag[192 + lane];   // odd-x weight set
     const int co = lane & 15;
-    const float bias = p.epi[co], scale = p.epi[16 + co], shift = p.epi[32 + co];
+    const float e0 = p.epi[co], e1 = p.epi[16 + co], e2 = p.epi[32 + co];   // see pool4
     const TmixW tm = load_tmix(p.epi + 48, lane);
 
-    const int n_items = p.B * p.nbands;
+    const int n_items = (p.dbg & 8) ? 0 : p.B * p.nbands;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int b = fdiv(item, p.mNb), band = item - b * p.nbands;
         // balanced bands of whole pool-window rows
@@ -197,47 +214,56 @@ __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
         const int rows = 2 * (((band + 1) * p.Hp) / p.nbands) - y0;
         const int n2 = rows + 2;
         __syncthreads();
-        // ---- stage: the band's (t, row, 4-pixel group) chunks are swept linearly; all global loads
-        // of a thread are issued before the first conversion so their latencies overlap.
+        // ---- stage: a thread owns (row, 4-pixel group) chunks and fetches them for all four T slices
+        // (one address computation, all global loads issued before the first conversion).
+        // u8 -> fp16 without integer->float conversions: v_perm builds the fp16 bit pattern 0x6400 | n
+        // (= 1024 + n, exact for n < 1024) for two channels at a time, then a packed min with 1030
+        // (the clip at 6) and a packed subtract of 1024.  The alpha byte lands in channel 3, whose
+        // weights are zero.
         {
             const int W4 = p.W >> 2;                  // 16-byte chunks (4 macroblocks) per image row
-            const int per_t = n2 * W4, nchunk = BN_T * per_t;
-            constexpr int KMAX = 5;                   // chunks per thread this kernel is sized for (host checks)
-            uint4 v[KMAX];
-            int dsto[KMAX];
+            const int per_t = n2 * W4;
+            constexpr int KQ = 2;                     // chunk positions per thread this kernel is sized for (host checks)
+            const size_t tplane = (size_t)p.H * p.W * 4;
+            const uint8_t *fb = p.in + (size_t)b * BN_T * tplane;
+            uint4 v[KQ][BN_T];
+            int dsto[KQ];
 #pragma unroll
-            for (int k = 0; k < KMAX; k++) {
+            for (int k = 0; k < KQ; k++) {
                 const int i = tid + k * WG0;
-                v[k] = make_uint4(0, 0, 0, 0);
                 dsto[k] = -1;
-                if (i < nchunk) {
-                    const int t = (i >= per_t) + (i >= 2 * per_t) + (i >= 3 * per_t), rem = i - t * per_t;
-                    const int r = fdiv(rem, p.mW4), c4 = rem - r * W4;
+                if (i < per_t) {
+                    const int r = fdiv(i, p.mW4), c4 = i - r * W4;
                     const int y = y0 - 1 + r;
-                    dsto[k] = t * tsz + r * TC * 8 + 16 + c4 * 32;
-                    if (y >= 0 && y < p.H)
-                        v[k] = *reinterpret_cast<const uint4 *>(
-                            p.in + ((((size_t)b * BN_T + t) * p.H + y) * p.W + c4 * 4) * 4);
+                    dsto[k] = r * TC * 8 + 16 + c4 * 32;
+                    const bool in = y >= 0 && y < p.H && !(p.dbg & 2);
+                    const uint8_t *src = fb + ((size_t)y * p.W + c4 * 4) * 4;
+#pragma unroll
+                    for (int t = 0; t < BN_T; t++)
+                        v[k][t] = in ? *reinterpret_cast<const uint4 *>(src + t * tplane) : make_uint4(0, 0, 0, 0);
                 }
             }
+            const half2v clip = {(_Float16)1030.f, (_Float16)1030.f}, off = {(_Float16)1024.f, (_Float16)1024.f};
 #pragma unroll
-            for (int k = 0; k < KMAX; k++) {
+            for (int k = 0; k < KQ; k++) {
                 if (dsto[k] >= 0) {
-                    const uint32_t px[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-                    half8 lo, hi;
 #pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        lo[4 * q + 0] = (_Float16)fminf((float)(px[q] & 0xFF), 6.f);
-                        lo[4 * q + 1] = (_Float16)fminf((float)((px[q] >> 8) & 0xFF), 6.f);
-                        lo[4 * q + 2] = (_Float16)fminf((float)((px[q] >> 16) & 0xFF), 6.f);
-                        lo[4 * q + 3] = (_Float16)0;
-                        hi[4 * q + 0] = (_Float16)fminf((float)(px[2 + q] & 0xFF), 6.f);
-                        hi[4 * q + 1] = (_Float16)fminf((float)((px[2 + q] >> 8) & 0xFF), 6.f);
-                        hi[4 * q + 2] = (_Float16)fminf((float)((px[2 + q] >> 16) & 0xFF), 6.f);
-                        hi[4 * q + 3] = (_Float16)0;
+                    for (int t = 0; t < BN_T; t++) {
+                        const uint32_t px[4] = {v[k][t].x, v[k][t].y, v[k][t].z, v[k][t].w};
+                        uint32_t o[8];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t c01 = __builtin_amdgcn_perm(0x64646464u, px[q], 0x05010500u);
+                            const uint32_t c23 = __builtin_amdgcn_perm(0x64646464u, px[q], 0x05030502u);
+                            const half2v h01 = __builtin_elementwise_min(__builtin_bit_cast(half2v, c01), clip) - off;
+                            const half2v h23 = __builtin_elementwise_min(__builtin_bit_cast(half2v, c23), clip) - off;
+                            o[2 * q] = __builtin_bit_cast(uint32_t, h01);
+                            o[2 * q + 1] = __builtin_bit_cast(uint32_t, h23);
+                        }
+                        uint8_t *d = smem + t * tsz + dsto[k];
+                        *reinterpret_cast<uint4 *>(d) = make_uint4(o[0], o[1], o[2], o[3]);        // tile cols 4c+2, 4c+3
+                        *reinterpret_cast<uint4 *>(d + 16) = make_uint4(o[4], o[5], o[6], o[7]);   // tile cols 4c+4, 4c+5
                     }
-                    *reinterpret_cast<half8 *>(smem + dsto[k]) = lo;        // tile cols 4c+2, 4c+3
-                    *reinterpret_cast<half8 *>(smem + dsto[k] + 16) = hi;   // tile cols 4c+4, 4c+5
                 }
             }
             // zero halo columns 0,1 and W+2,W+3 of every (t, row)
@@ -261,7 +287,7 @@ __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
         const int nwin = (rows / 2) * p.Wp;
         const int ntiles = (nwin + 7) / 8;
         const int m = lane & 15, g = lane >> 4;
-        for (int tile = wave; tile < ntiles; tile += WG0 / 64) {
+        for (int tile = wave; tile < ((p.dbg & 4) ? 0 : ntiles); tile += WG0 / 64) {
             const int win = min(tile * 8 + (m >> 1), nwin - 1);
             const int wy = fdiv(win, p.mWp), wx = win - wy * p.Wp;
             const int yy = 2 * wy + (m & 1), xe = 2 * wx;
@@ -281,21 +307,36 @@ __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
                 co_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao0, bo0, co_, 0, 0, 0);
                 ce = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae1, be1, ce, 0, 0, 0);
                 co_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao1, bo1, co_, 0, 0, 0);
-                pooled[0][t] = pool4<ALLPOS>(ce[0], ce[1], co_[0], co_[1], bias, scale, shift);
-                pooled[1][t] = pool4<ALLPOS>(ce[2], ce[3], co_[2], co_[3], bias, scale, shift);
+                pooled[0][t] = pool4<ALLPOS>(ce[0], ce[1], co_[0], co_[1], e0, e1, e2);
+                pooled[1][t] = pool4<ALLPOS>(ce[2], ce[3], co_[2], co_[3], e0, e1, e2);
             }
-            const size_t tstride = (size_t)p.Ho * p.Wo * 16;
+            // ---- store through a wave-private LDS transpose: the lanes drop their 2-byte values into
+            // S[t][window][channel] (the global layout of the tile: 32 contiguous bytes per window and T
+            // slice) and every lane then moves one 16-byte piece, so a tile leaves the wave as ONE
+            // global_store_dwordx4 instead of eight 2-byte stores.  LDS operations of one wave execute
+            // in order, so no workgroup barrier is involved.
+            const uint32_t tstride = (uint32_t)(p.Ho * p.Wo * 16);
+            __half *const ob = p.out + (size_t)b * BN_T * tstride;   // wave-uniform; lanes add a 32-bit offset
+            uint8_t *const scr = smem + p.scr_off + wave * 1024;
 #pragma unroll
             for (int q = 0; q < 2; q++) {
-                float o[BN_T];
+                half4 o;
                 tmix4(tm, pooled[q], o);
-                const int owin = tile * 8 + 2 * g + q;
-                if (owin < nwin) {
+                _Float16 *sw = reinterpret_cast<_Float16 *>(scr + (2 * g + q) * 32) + co;
+#pragma unroll
+                for (int t = 0; t < BN_T; t++) sw[t * 128] = o[t];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            {
+                const int owin = tile * 8 + ((lane >> 1) & 7);
+                if (owin < nwin && !(p.dbg & 1)) {
                     const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
                     const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
-                    __half *dstp = p.out + (((size_t)b * BN_T * p.Ho + gy) * p.Wo + gx) * 16 + co;
-#pragma unroll
-                    for (int t = 0; t < BN_T; t++) dstp[t * tstride] = __float2half(o[t]);
+                    const uint32_t eo = (uint32_t)((gy * p.Wo + gx) * 16 + 8 * (lane & 1));
+                    const uint4 v = *reinterpret_cast<const uint4 *>(scr + lane * 16);
+                    *reinterpret_cast<uint4 *>(ob + (lane >> 4) * tstride + eo) = v;
                 }
             }
         }
@@ -312,12 +353,13 @@ __device__ __forceinline__ int enc_swz(int xx, int yy) {
     return ((xx / XS) % (CPP / 2)) | ((yy & 1) * (CPP / 2));
 }
 
-template <int CIN, int COUT, int TPAR, int OCC, int NWV, bool ALLPOS>
+template <int CIN, int COUT, int TPAR, int OCC, int NWV, bool WIDE, bool ALLPOS>
 __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     constexpr int WGS = NWV * 64;
     constexpr int NT = COUT / 32, MG = NWV / NT, KC = CIN / 16, KSTEPS = 9 * KC;
     constexpr int CPP = CIN / 8, PS = CIN * 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if (p.dbg & 16) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntile = wave % NT, mgroup = wave / NT;
     const int TR = p.TR, TC = p.TC;
@@ -327,10 +369,10 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ks++) bf[ks] = p.wfrag[(ntile * KSTEPS + ks) * 64 + lane];
     const int co = ntile * 32 + (lane & 31);
-    const float bias = p.epi[co], scale = p.epi[COUT + co], shift = p.epi[2 * COUT + co];
+    const float e0 = p.epi[co], e1 = p.epi[COUT + co], e2 = p.epi[2 * COUT + co];   // see pool4
     const TmixW tm = load_tmix(p.epi + 3 * COUT, lane);
 
-    const int n_items = p.B * p.nbands;
+    const int n_items = (p.dbg & 8) ? 0 : p.B * p.nbands;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int b = fdiv(item, p.mNb), band = item - b * p.nbands;
         // balanced bands of whole pool-window rows
@@ -340,25 +382,26 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
         __syncthreads();
         // ---- stage the band with LDS-DMA: the tile is swept linearly in 16-byte chunks (64 per
         // wave-instruction); chunk -> (row, col, physical chunk) -> swizzled source chunk; halo
-        // columns / out-of-image rows read the zero buffer.
+        // columns / out-of-image rows read the zero buffer.  The decomposition is done once per chunk
+        // position and reused for the four T slices (source + t * plane, LDS + t * tsz).
         {
             const int RC = TC * CPP;  // chunks per tile row
             const int nchunk = n2 * RC;
-            const __half *fbase = p.in + ((size_t)b * BN_T) * p.H * p.W * CIN;
-            for (int t = 0; t < BN_T; t++) {
-                uint8_t *tbase = smem + t * tsz;
-                const __half *tsrc = fbase + (size_t)t * p.H * p.W * CIN;
-                for (int s0 = wave * 64; s0 < nchunk; s0 += WGS) {
-                    const int sidx = s0 + lane;
-                    if (sidx < nchunk) {
-                        const int r = fdiv(sidx, p.mRC), within = sidx - r * RC;
-                        const int c = within / CPP, chp = within % CPP;
-                        const int ch = chp ^ enc_swz<CIN>(c, r);
-                        const int y = y0 - 1 + r, x = c - 1;
-                        const void *src = p.zero;
-                        if (y >= 0 && y < p.H && x >= 0 && x < p.W) src = tsrc + ((size_t)y * p.W + x) * CIN + ch * 8;
-                        glds16(src, tbase + s0 * 16);
-                    }
+            const size_t tplane = (size_t)p.H * p.W * CIN * 2;   // bytes
+            const uint8_t *fbase = reinterpret_cast<const uint8_t *>(p.in) + (size_t)b * BN_T * tplane;
+            for (int s0 = wave * 64; s0 < nchunk; s0 += WGS) {
+                const int sidx = s0 + lane;
+                if (sidx < nchunk) {
+                    const int r = fdiv(sidx, p.mRC), within = sidx - r * RC;
+                    const int c = within / CPP, chp = within % CPP;
+                    const int ch = chp ^ enc_swz<CIN>(c, r);
+                    const int y = y0 - 1 + r, x = c - 1;
+                    const bool in = y >= 0 && y < p.H && x >= 0 && x < p.W && !(p.dbg & 2);
+                    const uint8_t *src = in ? fbase + ((size_t)(y * p.W + x) * CIN + ch * 8) * 2
+                                            : reinterpret_cast<const uint8_t *>(p.zero);
+                    const size_t step = in ? tplane : 0;
+#pragma unroll
+                    for (int t = 0; t < BN_T; t++) glds16(src + t * step, smem + t * tsz + s0 * 16);
                 }
             }
         }
@@ -367,7 +410,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
         const int nwin = (rows / 2) * p.Wp;
         const int ntiles = (nwin + 7) / 8;
         const int m = lane & 31, kh = lane >> 5;
-        for (int tile = mgroup; tile < ntiles; tile += MG) {
+        for (int tile = mgroup; tile < ((p.dbg & 4) ? 0 : ntiles); tile += MG) {
             const int win = min(tile * 8 + (m >> 2), nwin - 1);
             const int wy = fdiv(win, p.mWp), wx = win - wy * p.Wp;
             const int yy0 = 2 * wy + ((m >> 1) & 1), xx0 = 2 * wx + (m & 1);
@@ -405,7 +448,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
 #pragma unroll
                     for (int g = 0; g < 4; g++)
                         pooled4[t0 + t][g] = pool4<ALLPOS>(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2],
-                                                   acc[t][4 * g + 3], bias, scale, shift);
+                                                   acc[t][4 * g + 3], e0, e1, e2);
             }
             // Materialise all 16 pooled values here (empty asm = opaque use): the accumulators die
             // before the epilogue starts.  Without this point hipcc interleaves the pooling of later
@@ -415,21 +458,57 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
 #pragma unroll
                 for (int g = 0; g < 4; g++) asm volatile("" : "+v"(pooled4[t][g]));
             // ---- epilogue: temporal MLP + residual per pooled window, then store
-            const size_t tstride = (size_t)p.Ho * p.Wo * COUT;
+            const uint32_t tstride = (uint32_t)(p.Ho * p.Wo * COUT);
+            __half *const ob = p.out + (size_t)b * p.To * tstride;   // wave-uniform; lanes add a 32-bit offset
+            if constexpr (WIDE) {
+                // wave-private LDS transpose (see enc0_mfma): S[t][window][32 channels], two 16-byte
+                // pieces per lane -> two global_store_dwordx4 per tile instead of sixteen 2-byte stores
+                uint8_t *const scr = smem + p.scr_off + wave * 2048;
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                float pooled[BN_T], o[BN_T];
+                for (int g = 0; g < 4; g++) {
+                    float pooled[BN_T];
+                    half4 o;
 #pragma unroll
-                for (int t = 0; t < BN_T; t++) pooled[t] = pooled4[t][g];
-                tmix4(tm, pooled, o);
-                const int owin = tile * 8 + 2 * g + kh;
-                if (owin < nwin) {
+                    for (int t = 0; t < BN_T; t++) pooled[t] = pooled4[t][g];
+                    tmix4(tm, pooled, o);
+                    _Float16 *sw = reinterpret_cast<_Float16 *>(scr + (2 * g + kh) * 64) + (lane & 31);
+#pragma unroll
+                    for (int t = 0; t < BN_T; t++) sw[t * 256] = o[t];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int owin = tile * 8 + ((lane >> 2) & 7);
+                if (owin < nwin && !(p.dbg & 1)) {
                     const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
                     const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
-                    __half *dstp = p.out + (((size_t)b * p.To * p.Ho + gy) * p.Wo + gx) * COUT + co;
+                    const uint32_t eo = (uint32_t)((gy * p.Wo + gx) * COUT + ntile * 32 + 8 * (lane & 3));
 #pragma unroll
-                    for (int t = 0; t < BN_T; t++)
-                        if (t < p.To) dstp[t * tstride] = __float2half(o[t]);
+                    for (int j = 0; j < 2; j++) {
+                        const int t = 2 * j + (lane >> 5);
+                        if (t < p.To) {
+                            const uint4 v = *reinterpret_cast<const uint4 *>(scr + (j * 64 + lane) * 16);
+                            *reinterpret_cast<uint4 *>(ob + t * tstride + eo) = v;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    float pooled[BN_T];
+                    half4 o;
+#pragma unroll
+                    for (int t = 0; t < BN_T; t++) pooled[t] = pooled4[t][g];
+                    tmix4(tm, pooled, o);
+                    const int owin = tile * 8 + 2 * g + kh;
+                    if (owin < nwin && (!(p.dbg & 1) || o[0] == (_Float16)12345.f)) {
+                        const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
+                        const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
+                        const uint32_t eo = (uint32_t)((gy * p.Wo + gx) * COUT + co);
+#pragma unroll
+                        for (int t = 0; t < BN_T; t++)
+                            if (t < p.To) reinterpret_cast<_Float16 *>(ob + t * tstride)[eo] = o[t];
+                    }
                 }
             }
         }
@@ -570,8 +649,29 @@ __global__ __launch_bounds__(((FINAL ? 1 : 4 * COUT / 32) > 4 ? 4 * COUT / 32 : 
 }
 
 // ------------------------------------------------------------------ host-side weight preparation
-void prep_enc0(const float *k, const float *bias, const float *gamma, const float *beta, const float *mean,
+// Epilogue constants of an encoder level (see pool4): BN folded into the weights when every scale is >= 0.
+void enc_epilogue(int cout, bool allpos, const float *bias, const float *gamma, const float *beta, const float *mean,
+                  const float *var, std::vector<float> &wscale, float *epi) {
+    wscale.assign(cout, 1.f);
+    for (int c = 0; c < cout; c++) {
+        const float sc = gamma[c] / std::sqrt(var[c] + BN_EPS), sh = beta[c] - mean[c] * sc;
+        if (allpos) {
+            wscale[c] = sc;
+            epi[c] = -(bias[c] * sc);
+            epi[cout + c] = bias[c] * sc + sh;
+            epi[2 * cout + c] = 0.f;
+        } else {
+            epi[c] = bias[c];
+            epi[cout + c] = sc;
+            epi[2 * cout + c] = sh;
+        }
+    }
+}
+
+void prep_enc0(bool allpos, const float *k, const float *bias, const float *gamma, const float *beta, const float *mean,
                const float *var, const float *w1, const float *w2, _Float16 *wfrag, float *epi) {
+    std::vector<float> ws;
+    enc_epilogue(16, allpos, bias, gamma, beta, mean, var, ws, epi);
     // 16x16x32 B fragment: lane l: n = l&15, k = 8*(l>>4)+j.  k <-> (kernel row, pixel of the
     // 4-pixel group, channel).  Set 0 serves even-x conv pixels (group = inputs x-2..x+1, so group
     // pixel px carries tap kx = px-1), set 1 odd-x pixels (group = inputs x-1..x+2, kx = px).
@@ -586,22 +686,18 @@ void prep_enc0(const float *k, const float *bias, const float *gamma, const floa
                     if (ks == 0) ky = g >> 1;
                     else if ((g >> 1) == 0) ky = 2;
                     float w = 0.f;
-                    if (ky >= 0 && kx >= 0 && kx < 3 && ch < 3) w = k[((ky * 3 + kx) * 3 + ch) * 16 + n] / 6.0f;
+                    if (ky >= 0 && kx >= 0 && kx < 3 && ch < 3) w = k[((ky * 3 + kx) * 3 + ch) * 16 + n] * ws[n] / 6.0f;
                     wfrag[((set * 2 + ks) * 64 + l) * 8 + j] = f2h(w);
                 }
-    for (int c = 0; c < 16; c++) {
-        const float sc = gamma[c] / std::sqrt(var[c] + BN_EPS);
-        epi[c] = bias[c];
-        epi[16 + c] = sc;
-        epi[32 + c] = beta[c] - mean[c] * sc;
-    }
     std::memcpy(epi + 48, w1, 16 * sizeof(float));
     std::memcpy(epi + 64, w2, 16 * sizeof(float));
 }
 
-void prep_enc(int cin, int cout, const float *k, const float *bias, const float *gamma, const float *beta,
+void prep_enc(bool allpos, int cin, int cout, const float *k, const float *bias, const float *gamma, const float *beta,
               const float *mean, const float *var, const float *w1, const float *w2, _Float16 *wfrag, float *epi) {
     const int NT = cout / 32, KC = cin / 16, KSTEPS = 9 * KC;
+    std::vector<float> ws;
+    enc_epilogue(cout, allpos, bias, gamma, beta, mean, var, ws, epi);
     // 32x32x16 B fragment: lane l: n = l&31, k = 8*(l>>5)+j
     for (int nt = 0; nt < NT; nt++)
         for (int ks = 0; ks < KSTEPS; ks++)
@@ -609,14 +705,8 @@ void prep_enc(int cin, int cout, const float *k, const float *bias, const float 
                 for (int j = 0; j < 8; j++) {
                     const int tap = ks / KC, kc = ks % KC;
                     const int c = kc * 16 + 8 * (l >> 5) + j, n = nt * 32 + (l & 31);
-                    wfrag[(((size_t)nt * KSTEPS + ks) * 64 + l) * 8 + j] = f2h(k[((size_t)tap * cin + c) * cout + n]);
+                    wfrag[(((size_t)nt * KSTEPS + ks) * 64 + l) * 8 + j] = f2h(k[((size_t)tap * cin + c) * cout + n] * ws[n]);
                 }
-    for (int c = 0; c < cout; c++) {
-        const float sc = gamma[c] / std::sqrt(var[c] + BN_EPS);
-        epi[c] = bias[c];
-        epi[cout + c] = sc;
-        epi[2 * cout + c] = beta[c] - mean[c] * sc;
-    }
     std::memcpy(epi + 3 * cout, w1, 16 * sizeof(float));
     std::memcpy(epi + 3 * cout + 16, w2, 16 * sizeof(float));
 }
@@ -732,10 +822,10 @@ int blobnet_prepare_mfma(covahip_ctx *ctx, covahip_blobnet *m, const float *w) {
         pr->allpos[i] = true;
         for (int c = 0; c < m->enc_c[i + 1]; c++) pr->allpos[i] = pr->allpos[i] && he[i].gamma[c] >= 0.f;
     }
-    prep_enc0(he[0].k, he[0].b, he[0].gamma, he[0].beta, he[0].mean, he[0].var, he[0].w1, he[0].w2,
+    prep_enc0(pr->allpos[0], he[0].k, he[0].b, he[0].gamma, he[0].beta, he[0].mean, he[0].var, he[0].w1, he[0].w2,
               (_Float16 *)(host.data() + pr->enc[0].wfrag), (float *)(host.data() + pr->enc[0].epi));
     for (int i = 1; i < BN_LEVELS; i++)
-        prep_enc(m->enc_c[i], m->enc_c[i + 1], he[i].k, he[i].b, he[i].gamma, he[i].beta, he[i].mean, he[i].var,
+        prep_enc(pr->allpos[i], m->enc_c[i], m->enc_c[i + 1], he[i].k, he[i].b, he[i].gamma, he[i].beta, he[i].mean, he[i].var,
                  he[i].w1, he[i].w2, (_Float16 *)(host.data() + pr->enc[i].wfrag),
                  (float *)(host.data() + pr->enc[i].epi));
     for (int j = 0; j < BN_LEVELS - 1; j++)
@@ -787,21 +877,35 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
         // band height: largest even RB whose tile (RB+2 rows, all T) fits in ~78 KB of LDS
         // (two workgroups per CU; the 64->128 level keeps 144 weight VGPRs per wave and runs one
         //  workgroup per CU with up to 150 KB)
-        const size_t lds_cap = (i == BN_LEVELS - 1) ? 150 * 1024 : 80 * 1024;
+        // output transpose scratch behind the tile: 1 KB per wave at level 0, 2 KB per wave at levels 1 and 3
+        // (level 2 keeps 2-byte stores: its 80 KB tile leaves no room beside a second workgroup)
+        static const int enc_waves[BN_LEVELS] = {WG0 / 64, 8, 4, 8};
+        static const bool enc_wide[BN_LEVELS] = {true, true, false, true};
+        const size_t scr_bytes = (i == 0) ? (size_t)enc_waves[0] * 1024 : (enc_wide[i] ? (size_t)enc_waves[i] * 2048 : 0);
+        const size_t lds_cap = ((i == BN_LEVELS - 1) ? 150 * 1024 : 80 * 1024) - scr_bytes;
         const int wgs_per_cu = (i == BN_LEVELS - 1) ? 1 : 2;
-        // band planner: bands of whole pool-window rows.  Every band costs a halo + a barrier pair,
-        // and the two workgroups of a CU share its throughput, so the fewest bands that fit in LDS
-        // win -- unless that leaves CUs without work, then more bands add parallelism.
+        // band planner: bands of whole pool-window rows.  Workgroups are persistent (wgs_per_cu per CU)
+        // and take items round-robin, so a launch lasts ceil(items / slots) rounds of one band each;
+        // a band costs its window rows plus about one row of halo staging + barriers.  Pick the band
+        // count that fits in LDS and minimises rounds x (rows + 1).
         int nbands = 0, RB = 0;
         const long long slots = (long long)wgs_per_cu * num_cu;
+        long long best = -1;
         for (int nb = 1; nb <= Hp; nb++) {
             const int rb = (Hp + nb - 1) / nb;  // max window rows per band
             if ((size_t)BN_T * (2 * rb + 2) * TC * px_bytes > lds_cap) continue;
-            nbands = nb; RB = 2 * rb;
-            if ((long long)batch * nb >= slots) break;
+            const long long rounds = ((long long)batch * nb + slots - 1) / slots;
+            const long long cost = rounds * (rb + 1);
+            if (best < 0 || cost < best) { best = cost; nbands = nb; RB = 2 * rb; }
+        }
+        if (const char *ov = std::getenv("COVAHIP_DEV_ENC_NB")) {   // developer override: "nb0,nb1,nb2,nb3" (0 = planner)
+            int v[BN_LEVELS] = {0, 0, 0, 0};
+            std::sscanf(ov, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
+            if (v[i] > 0 && v[i] <= Hp) { nbands = v[i]; RB = 2 * ((Hp + nbands - 1) / nbands); }
         }
         if (!nbands) return COVAHIP_ERR_UNSUPPORTED;
-        const size_t lds = (size_t)BN_T * (RB + 2) * TC * px_bytes;
+        const size_t tile_bytes = (((size_t)BN_T * (RB + 2) * TC * px_bytes) + 15) & ~(size_t)15;
+        const size_t lds = tile_bytes + scr_bytes;
         if (lds > 160 * 1024 - 256) return COVAHIP_ERR_UNSUPPORTED;
         const int items = batch * nbands;
         const int grid = std::min(items, (i == BN_LEVELS - 1 ? 1 : 2) * num_cu);
@@ -811,8 +915,9 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
             a.wfrag = (const half8 *)(prep + pr->enc[0].wfrag); a.epi = (const float *)(prep + pr->enc[0].epi);
             a.B = batch; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.Ho = m->lv[1].H; a.Wo = m->lv[1].W;
             a.oy = H & 1; a.ox = W & 1; a.RB = RB; a.nbands = nbands; a.TR = RB + 2; a.TC = TC;
-            a.mWp = magic(Wp); a.mNb = magic(nbands); a.mW4 = magic(W / 4);
-            if (W % 4 || BN_T * (RB + 2) * (W / 4) > 5 * WG0) return COVAHIP_ERR_UNSUPPORTED;
+            a.mWp = magic(Wp); a.mNb = magic(nbands); a.mW4 = magic(W / 4); a.scr_off = (int)tile_bytes;
+            a.dbg = std::getenv("COVAHIP_DEV_DBG") ? std::atoi(std::getenv("COVAHIP_DEV_DBG")) : 0;
+            if (W % 4 || (RB + 2) * (W / 4) > 2 * WG0) return COVAHIP_ERR_UNSUPPORTED;
             int rc = pr->allpos[0] ? set_lds(ctx, enc0_mfma<true>, lds) : set_lds(ctx, enc0_mfma<false>, lds);
             if (rc) return rc;
             ProfScope ps(ctx, "enc0_mfma");
@@ -825,26 +930,27 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
             a.B = batch; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.Ho = m->lv[i + 1].H; a.Wo = m->lv[i + 1].W;
             a.oy = H & 1; a.ox = W & 1; a.To = (i == BN_LEVELS - 1) ? 1 : BN_T;
             a.RB = RB; a.nbands = nbands; a.TR = RB + 2; a.TC = TC;
-            a.mWp = magic(Wp); a.mNb = magic(nbands); a.mRC = magic(TC * (cin / 8)); a.zero = prep + pr->zero;
+            a.mWp = magic(Wp); a.mNb = magic(nbands); a.mRC = magic(TC * (cin / 8)); a.zero = prep + pr->zero; a.scr_off = (int)tile_bytes;
+            a.dbg = std::getenv("COVAHIP_DEV_DBG") ? std::atoi(std::getenv("COVAHIP_DEV_DBG")) : 0;
             int rc = COVAHIP_OK;
             if (i == 1) {
-                rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true>, lds) : set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, false>, lds);
+                rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true, true>, lds) : set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true, false>, lds);
                 if (rc) return rc;
                 ProfScope ps(ctx, "enc1_mfma");
-                if (pr->allpos[i]) hipLaunchKernelGGL((enc_mfma<16, 32, 2, 4, 8, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
-                else hipLaunchKernelGGL((enc_mfma<16, 32, 2, 4, 8, false>), dim3(grid), dim3(512), lds, ctx->stream, a);
+                if (pr->allpos[i]) hipLaunchKernelGGL((enc_mfma<16, 32, 2, 4, 8, true, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
+                else hipLaunchKernelGGL((enc_mfma<16, 32, 2, 4, 8, true, false>), dim3(grid), dim3(512), lds, ctx->stream, a);
             } else if (i == 2) {
-                rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<32, 64, 4, 2, 4, true>, lds) : set_lds(ctx, enc_mfma<32, 64, 4, 2, 4, false>, lds);
+                rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<32, 64, 4, 2, 4, false, true>, lds) : set_lds(ctx, enc_mfma<32, 64, 4, 2, 4, false, false>, lds);
                 if (rc) return rc;
                 ProfScope ps(ctx, "enc2_mfma");
-                if (pr->allpos[i]) hipLaunchKernelGGL((enc_mfma<32, 64, 4, 2, 4, true>), dim3(grid), dim3(WG), lds, ctx->stream, a);
-                else hipLaunchKernelGGL((enc_mfma<32, 64, 4, 2, 4, false>), dim3(grid), dim3(WG), lds, ctx->stream, a);
+                if (pr->allpos[i]) hipLaunchKernelGGL((enc_mfma<32, 64, 4, 2, 4, false, true>), dim3(grid), dim3(WG), lds, ctx->stream, a);
+                else hipLaunchKernelGGL((enc_mfma<32, 64, 4, 2, 4, false, false>), dim3(grid), dim3(WG), lds, ctx->stream, a);
             } else {
-                rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<64, 128, 2, 2, 8, true>, lds) : set_lds(ctx, enc_mfma<64, 128, 2, 2, 8, false>, lds);
+                rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<64, 128, 2, 2, 8, true, true>, lds) : set_lds(ctx, enc_mfma<64, 128, 2, 2, 8, true, false>, lds);
                 if (rc) return rc;
                 ProfScope ps(ctx, "enc3_mfma");
-                if (pr->allpos[i]) hipLaunchKernelGGL((enc_mfma<64, 128, 2, 2, 8, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
-                else hipLaunchKernelGGL((enc_mfma<64, 128, 2, 2, 8, false>), dim3(grid), dim3(512), lds, ctx->stream, a);
+                if (pr->allpos[i]) hipLaunchKernelGGL((enc_mfma<64, 128, 2, 2, 8, true, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
+                else hipLaunchKernelGGL((enc_mfma<64, 128, 2, 2, 8, true, false>), dim3(grid), dim3(512), lds, ctx->stream, a);
             }
         }
         COVAHIP_CHECK_HIP(ctx, hipGetLastError());

@@ -34,6 +34,8 @@ ctx.timer_stop(0)
 ms = ctx.timer_ms(0) / steps
 macs = net.macs_per_frame
 print(f"B={B}: {ms*1e3:.1f} us/batch  {B/ms*1e3:.0f} frames/s  MFMA util (alg) {2*macs*B/(ms*1e-3)/2.5e15*100:.1f}%")
+if len(sys.argv) > 3 and sys.argv[3] == "noprofile":
+    sys.exit(0)
 ctx.profile(True)
 for _ in range(steps):
     net.filter_device(d_stack, B, 1, d_boxes, d_counts, max_boxes, d_mask)
