@@ -135,7 +135,7 @@ __device__ __forceinline__ void tmix4(const TmixW &w, const float (&p)[BN_T], ha
 
 // Asynchronous 16-byte global -> LDS copy (LDS-DMA): every lane supplies its own global source
 // address, the data lands at lds_base (wave-uniform) + lane*16.  Completion is covered by the
-// vmcnt(0) that __syncthreads() waits for.
+// an explicit wait_vmem() before the workgroup barrier.
 // The LDS base is made provably wave-uniform with readfirstlane (it goes to M0).
 typedef __attribute__((address_space(3))) void lds_void;
 __device__ __forceinline__ void glds16(const void *gsrc, uint8_t *lds_base_uniform) {
@@ -143,6 +143,17 @@ __device__ __forceinline__ void glds16(const void *gsrc, uint8_t *lds_base_unifo
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
                                      (lds_void *)(uintptr_t)a, 16, 0, 0);
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter, i.e. every wave would sit at the barrier until its own global stores have been written
+// to L2; the kernels below never read back what they store, so only LDS needs ordering.  Where an
+// LDS-DMA copy (a vector-memory operation) has to have landed, wait_vmem() is called explicitly.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+__device__ __forceinline__ void wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0), nothing else
 
 // ------------------------------------------------------------------ geometry structs
 struct Enc0Args {
@@ -182,6 +193,8 @@ struct DecArgs {
     int nbands;          // bands of grid rows per frame
     uint32_t mNb, mGW, mRC;
     const void *zero;
+    int mask_off;        // last block: byte offset of the band's mask rows in LDS
+    int dbg;
 };
 
 // ------------------------------------------------------------------ enc level 0
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
         const int y0 = 2 * ((band * p.Hp) / p.nbands);
         const int rows = 2 * (((band + 1) * p.Hp) / p.nbands) - y0;
         const int n2 = rows + 2;
-        __syncthreads();
+        if (p.dbg & 32) __syncthreads(); else lds_barrier();
         // ---- stage: a thread owns (row, 4-pixel group) chunks and fetches them for all four T slices
         // (one address computation, all global loads issued before the first conversion).
         // u8 -> fp16 without integer->float conversions: v_perm builds the fp16 bit pattern 0x6400 | n
@@ -275,7 +288,7 @@ __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
                     make_uint4(0, 0, 0, 0);
             }
         }
-        __syncthreads();
+        if (p.dbg & 32) __syncthreads(); else lds_barrier();
         // ---- compute.  One tile = 8 pool windows.  The 16 rows of an MFMA are the 8 windows x 2
         // conv rows (dy) of ONE column parity: conv pixels with even x and with odd x go to two MFMAs
         // with two weight sets, so that the 4-pixel K group every lane reads starts at an even tile
@@ -379,7 +392,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
         const int y0 = 2 * ((band * p.Hp) / p.nbands);
         const int rows = 2 * (((band + 1) * p.Hp) / p.nbands) - y0;
         const int n2 = rows + 2;
-        __syncthreads();
+        lds_barrier();
         // ---- stage the band with LDS-DMA: the tile is swept linearly in 16-byte chunks (64 per
         // wave-instruction); chunk -> (row, col, physical chunk) -> swizzled source chunk; halo
         // columns / out-of-image rows read the zero buffer.  The decomposition is done once per chunk
@@ -405,7 +418,8 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
                 }
             }
         }
-        __syncthreads();
+        wait_vmem();
+        lds_barrier();
         // ---- compute
         const int nwin = (rows / 2) * p.Wp;
         const int ntiles = (nwin + 7) / 8;
@@ -556,12 +570,12 @@ __global__ __launch_bounds__(((FINAL ? 1 : 4 * COUT / 32) > 4 ? 4 * COUT / 32 : 
     }
     const float fbias = FINAL ? p.epi[0] : 0.f;
 
-    const int n_items = p.B * p.nbands;
+    const int n_items = (p.dbg & 8) ? 0 : p.B * p.nbands;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int b = fdiv(item, p.mNb), band = item - b * p.nbands;
         const int u0 = band * GH / p.nbands, u1 = (band + 1) * GH / p.nbands;
         const int nu = u1 - u0;   // grid rows of this band; tile rows = nu + 1 (input rows u0-1 .. u1-1)
-        __syncthreads();
+        lds_barrier();
         // ---- stage with LDS-DMA: concat(up, skip[t=0]); both sources hold relu'd values
         {
             const int RC = TC * CPP;
@@ -576,7 +590,7 @@ __global__ __launch_bounds__(((FINAL ? 1 : 4 * COUT / 32) > 4 ? 4 * COUT / 32 : 
                     const int cb = (chp ^ dec_swz<C>(c)) * 8;
                     const int y = u0 - 1 + r, x = c - 1;
                     const void *src = p.zero;
-                    if (y >= 0 && y < p.Hi && x >= 0 && x < p.Wi) {
+                    if (y >= 0 && y < p.Hi && x >= 0 && x < p.Wi && !(p.dbg & 2)) {
                         const size_t pix = (size_t)y * p.Wi + x;
                         if constexpr (C1 == 0) {
                             src = ss + pix * C2 + cb;
@@ -589,11 +603,16 @@ __global__ __launch_bounds__(((FINAL ? 1 : 4 * COUT / 32) > 4 ? 4 * COUT / 32 : 
                 }
             }
         }
-        __syncthreads();
+        wait_vmem();
+        lds_barrier();
+        // last block: the band's mask rows [Yb, Ye) are assembled in LDS behind the tile and leave
+        // as coalesced 4-byte stores (they are contiguous in the mask tensor)
+        uint8_t *const mrows = smem + p.mask_off;
+        const int Yb = max(0, 2 * u0 - p.cy), Ye = min(p.Hd, 2 * u1 - p.cy);
         // ---- compute over the band's flattened (u, v) positions
         const int npos = nu * GW;
         const int ntiles = (npos + 31) / 32;
-        for (int tile = pgroup; tile < ntiles; tile += PG) {
+        for (int tile = pgroup; tile < ((p.dbg & 4) ? 0 : ntiles); tile += PG) {
             const int q = tile * 32 + (lane & 31);
             const int qc = min(q, npos - 1);
             const int ul = fdiv(qc, p.mGW), v = qc - ul * GW;   // ul = u - u0
@@ -613,7 +632,7 @@ __global__ __launch_bounds__(((FINAL ? 1 : 4 * COUT / 32) > 4 ? 4 * COUT / 32 : 
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[(a * 2 + bb) * KC + kc], av, acc, 0, 0, 0);
                     }
                 }
-            if (q >= npos) continue;
+            if (q >= npos || ((p.dbg & 1) && acc[0] != 12345.f)) continue;
             const int u = u0 + ul;
             if constexpr (FINAL) {
                 // rows 0..3 = parities (py,px) = (r>>1, r&1): only the kh == 0 half holds them
@@ -622,10 +641,9 @@ __global__ __launch_bounds__(((FINAL ? 1 : 4 * COUT / 32) > 4 ? 4 * COUT / 32 : 
                     for (int r = 0; r < 4; r++) {
                         const int Y = 2 * u + (r >> 1) - p.cy, X = 2 * v + (r & 1) - p.cx;
                         if (Y >= 0 && Y < p.Hd && X >= 0 && X < p.Wd) {
-                            const size_t o = ((size_t)b * p.Hd + Y) * p.Wd + X;
                             const float l = acc[r] + fbias;
-                            if (p.logits) p.logits[o] = l;
-                            if (p.mask) p.mask[o] = l > 0.f ? 1 : 0;
+                            if (p.logits) p.logits[((size_t)b * p.Hd + Y) * p.Wd + X] = l;
+                            mrows[(Y - Yb) * p.Wd + X] = l > 0.f ? 1 : 0;   // band mask, assembled in LDS
                         }
                     }
                 }
@@ -642,6 +660,19 @@ __global__ __launch_bounds__(((FINAL ? 1 : 4 * COUT / 32) > 4 ? 4 * COUT / 32 : 
                             o[j] = (_Float16)fmaxf(acc[4 * g + j] * es[4 * g + j] + eb[4 * g + j], 0.f);
                         *reinterpret_cast<half4 *>(p.out + (((size_t)b * p.Hd + Y) * p.Wd + X) * COUT + co0) = o;
                     }
+                }
+            }
+        }
+        if constexpr (FINAL) {
+            if (p.mask) {
+                lds_barrier();
+                uint8_t *dst = p.mask + ((size_t)b * p.Hd + Yb) * p.Wd;
+                const int nbytes = (Ye - Yb) * p.Wd;
+                if ((p.Wd & 3) == 0 && (reinterpret_cast<uintptr_t>(p.mask) & 3) == 0) {
+                    for (int i = tid; i < nbytes / 4; i += NW * 64)
+                        reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(mrows)[i];
+                } else {
+                    for (int i = tid; i < nbytes; i += NW * 64) dst[i] = mrows[i];
                 }
             }
         }
@@ -908,7 +939,12 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
         const size_t lds = tile_bytes + scr_bytes;
         if (lds > 160 * 1024 - 256) return COVAHIP_ERR_UNSUPPORTED;
         const int items = batch * nbands;
-        const int grid = std::min(items, (i == BN_LEVELS - 1 ? 1 : 2) * num_cu);
+        int grid = std::min(items, (i == BN_LEVELS - 1 ? 1 : 2) * num_cu);
+        if (const char *ov = std::getenv("COVAHIP_DEV_ENC_GRID")) {   // developer override: workgroups per CU per level (0 = keep)
+            int v[BN_LEVELS] = {0, 0, 0, 0};
+            std::sscanf(ov, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
+            if (v[i] > 0) grid = std::min(items, v[i] * num_cu);
+        }
         if (i == 0) {
             Enc0Args a;
             a.in = d_stack; a.out = act[1];
@@ -971,17 +1007,38 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
         a.Ts = j == 0 ? 1 : BN_T;
         const int GH = in.H + 1;
         const size_t row_bytes = (size_t)(in.W + 2) * m->dec_ci[j] * 2;
-        // bands of grid rows: LDS tile (rows+1 input rows) <= ~72 KB and >= 2 work items per CU
+        // band planner.  A workgroup keeps its M-tile's weight fragments in registers, so the weights
+        // cross the L2 -> CU path once per workgroup: block 0 (256 KB of fragments per workgroup) runs
+        // one workgroup per CU over whole frames.  The lighter blocks are bound by the latency of
+        // stage -> barrier -> compute, which only other workgroups on the CU can hide: bands of at most
+        // ~30 KB of LDS so that four to five of them are resident per CU.
+        const size_t wbytes = (size_t)(last ? 1 : 4 * m->dec_co[j] / 32) * (4 * m->dec_ci[j] / 16) * 1024;
+        const bool heavy = wbytes >= 192 * 1024 && (size_t)(GH + 1) * row_bytes <= 72 * 1024;
         int nbands = 1;
-        while (nbands < GH && (((size_t)((GH + nbands - 1) / nbands) + 1) * row_bytes > 72 * 1024 ||
-                               (long long)batch * nbands < 2LL * num_cu))
-            nbands++;
-        const size_t lds = ((size_t)((GH + nbands - 1) / nbands) + 1) * row_bytes;
-        if (lds > 160 * 1024 - 256) return COVAHIP_ERR_UNSUPPORTED;
+        if (!heavy)
+            while (nbands < GH && (((size_t)((GH + nbands - 1) / nbands) + 1) * row_bytes > 30 * 1024 ||
+                                   (long long)batch * nbands < 2LL * num_cu))
+                nbands++;
+        if (const char *ov = std::getenv("COVAHIP_DEV_DEC_NB")) {   // developer override
+            int v[BN_LEVELS] = {0, 0, 0, 0};
+            std::sscanf(ov, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
+            if (v[j] > 0 && v[j] <= GH) nbands = v[j];
+        }
         a.nbands = nbands; a.mNb = magic(nbands); a.mGW = magic(in.W + 1);
         a.mRC = magic((in.W + 2) * (m->dec_ci[j] / 8)); a.zero = prep + pr->zero;
+        a.dbg = std::getenv("COVAHIP_DEV_DBG") ? std::atoi(std::getenv("COVAHIP_DEV_DBG")) >> 8 : 0;
+        const size_t tile_bytes = ((size_t)((GH + nbands - 1) / nbands) + 1) * row_bytes;
+        const size_t mask_bytes = last ? ((((size_t)2 * ((GH + nbands - 1) / nbands) * out.W) + 15) & ~(size_t)15) : 0;
+        const size_t lds = tile_bytes + mask_bytes;
+        a.mask_off = (int)tile_bytes;
+        if (lds > 160 * 1024 - 256) return COVAHIP_ERR_UNSUPPORTED;
         const int items = batch * nbands;
-        const int grid = std::min(items, 2 * num_cu);
+        int grid = std::min(items, (heavy ? 1 : 4) * num_cu);
+        if (const char *ov = std::getenv("COVAHIP_DEV_DEC_GRID")) {
+            int v[BN_LEVELS] = {0, 0, 0, 0};
+            std::sscanf(ov, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
+            if (v[j] > 0) grid = std::min(items, v[j] * num_cu);
+        }
         int rc;
         if (j == 0) {
             rc = set_lds(ctx, dec_mfma<0, 128, 64, false>, lds);
