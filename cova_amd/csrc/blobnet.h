@@ -37,6 +37,7 @@ struct covahip_blobnet {
     size_t prepared_bytes = 0;
     struct Prepared *prep = nullptr;
     int impl = 1;  // 0 = naive direct kernels, 1 = MFMA kernels
+    int fuse01 = 0;  // MFMA path: encoder levels 0 and 1 as one kernel (default off: measured slower)
     int overlap = 0;  // split a batch in two halves on two HIP streams (off by default: no gain measured at b=256)
     int64_t macs_per_frame = 0;
 };

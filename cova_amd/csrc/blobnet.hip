@@ -236,8 +236,9 @@ int covahip_blobnet_set_overlap(covahip_ctx *ctx, int on) {
 
 int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl) {
     if (!ctx || !ctx->blobnet) return COVAHIP_ERR_NOT_LOADED;
-    if (impl != 0 && impl != 1) return COVAHIP_ERR_INVALID_ARG;
-    ctx->blobnet->impl = impl;
+    if (impl < 0 || impl > 2) return COVAHIP_ERR_INVALID_ARG;
+    ctx->blobnet->impl = impl ? 1 : 0;
+    ctx->blobnet->fuse01 = impl == 2;
     return COVAHIP_OK;
 }
 

@@ -24,7 +24,6 @@
 // Reference semantics: utils/model/preprocessing.py:6-7, encoder.py:30-80, pointwise.py:8-26,
 // decoder.py:5-134, blobnet.py:8-48; hyper-parameters utils/train-blobnet.py:57-69.
 #include <cmath>
-#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -165,7 +164,6 @@ struct Enc0Args {
     int RB, nbands, TR, TC;
     uint32_t mWp, mNb, mW4;
     int scr_off;   // byte offset of the per-wave output transpose scratch (1 KB per wave) in LDS
-    int dbg;
 };
 
 struct EncArgs {
@@ -178,7 +176,6 @@ struct EncArgs {
     uint32_t mWp, mNb, mRC;
     const void *zero;  // >= 16 zero bytes in global memory (source of halo / padding chunks)
     int scr_off;       // byte offset of the per-wave output transpose scratch (2 KB per wave) in LDS (WIDE)
-    int dbg;
 };
 
 struct DecArgs {
@@ -194,7 +191,6 @@ struct DecArgs {
     uint32_t mNb, mGW, mRC;
     const void *zero;
     int mask_off;        // last block: byte offset of the band's mask rows in LDS
-    int dbg;
 };
 
 // ------------------------------------------------------------------ enc level 0
@@ -208,7 +204,6 @@ constexpr int WG0 = 512;  // 8 waves: the per-tile dependency chain is latency b
 template <bool ALLPOS>
 __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    if (p.dbg & 16) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int TR = p.TR, TC = p.TC;
     const int tsz = TR * TC * 8;  // bytes per T slice
@@ -219,14 +214,14 @@ __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
     const float e0 = p.epi[co], e1 = p.epi[16 + co], e2 = p.epi[32 + co];   // see pool4
     const TmixW tm = load_tmix(p.epi + 48, lane);
 
-    const int n_items = (p.dbg & 8) ? 0 : p.B * p.nbands;
+    const int n_items = p.B * p.nbands;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int b = fdiv(item, p.mNb), band = item - b * p.nbands;
         // balanced bands of whole pool-window rows
         const int y0 = 2 * ((band * p.Hp) / p.nbands);
         const int rows = 2 * (((band + 1) * p.Hp) / p.nbands) - y0;
         const int n2 = rows + 2;
-        if (p.dbg & 32) __syncthreads(); else lds_barrier();
+        lds_barrier();
         // ---- stage: a thread owns (row, 4-pixel group) chunks and fetches them for all four T slices
         // (one address computation, all global loads issued before the first conversion).
         // u8 -> fp16 without integer->float conversions: v_perm builds the fp16 bit pattern 0x6400 | n
@@ -249,7 +244,7 @@ __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
                     const int r = fdiv(i, p.mW4), c4 = i - r * W4;
                     const int y = y0 - 1 + r;
                     dsto[k] = r * TC * 8 + 16 + c4 * 32;
-                    const bool in = y >= 0 && y < p.H && !(p.dbg & 2);
+                    const bool in = y >= 0 && y < p.H;
                     const uint8_t *src = fb + ((size_t)y * p.W + c4 * 4) * 4;
 #pragma unroll
                     for (int t = 0; t < BN_T; t++)
@@ -288,7 +283,7 @@ __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
                     make_uint4(0, 0, 0, 0);
             }
         }
-        if (p.dbg & 32) __syncthreads(); else lds_barrier();
+        lds_barrier();
         // ---- compute.  One tile = 8 pool windows.  The 16 rows of an MFMA are the 8 windows x 2
         // conv rows (dy) of ONE column parity: conv pixels with even x and with odd x go to two MFMAs
         // with two weight sets, so that the 4-pixel K group every lane reads starts at an even tile
@@ -300,7 +295,7 @@ __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
         const int nwin = (rows / 2) * p.Wp;
         const int ntiles = (nwin + 7) / 8;
         const int m = lane & 15, g = lane >> 4;
-        for (int tile = wave; tile < ((p.dbg & 4) ? 0 : ntiles); tile += WG0 / 64) {
+        for (int tile = wave; tile < ntiles; tile += WG0 / 64) {
             const int win = min(tile * 8 + (m >> 1), nwin - 1);
             const int wy = fdiv(win, p.mWp), wx = win - wy * p.Wp;
             const int yy = 2 * wy + (m & 1), xe = 2 * wx;
@@ -344,7 +339,7 @@ __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             {
                 const int owin = tile * 8 + ((lane >> 1) & 7);
-                if (owin < nwin && !(p.dbg & 1)) {
+                if (owin < nwin) {
                     const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
                     const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
                     const uint32_t eo = (uint32_t)((gy * p.Wo + gx) * 16 + 8 * (lane & 1));
@@ -372,7 +367,6 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     constexpr int NT = COUT / 32, MG = NWV / NT, KC = CIN / 16, KSTEPS = 9 * KC;
     constexpr int CPP = CIN / 8, PS = CIN * 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    if (p.dbg & 16) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntile = wave % NT, mgroup = wave / NT;
     const int TR = p.TR, TC = p.TC;
@@ -385,7 +379,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     const float e0 = p.epi[co], e1 = p.epi[COUT + co], e2 = p.epi[2 * COUT + co];   // see pool4
     const TmixW tm = load_tmix(p.epi + 3 * COUT, lane);
 
-    const int n_items = (p.dbg & 8) ? 0 : p.B * p.nbands;
+    const int n_items = p.B * p.nbands;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int b = fdiv(item, p.mNb), band = item - b * p.nbands;
         // balanced bands of whole pool-window rows
@@ -409,7 +403,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
                     const int c = within / CPP, chp = within % CPP;
                     const int ch = chp ^ enc_swz<CIN>(c, r);
                     const int y = y0 - 1 + r, x = c - 1;
-                    const bool in = y >= 0 && y < p.H && x >= 0 && x < p.W && !(p.dbg & 2);
+                    const bool in = y >= 0 && y < p.H && x >= 0 && x < p.W;
                     const uint8_t *src = in ? fbase + ((size_t)(y * p.W + x) * CIN + ch * 8) * 2
                                             : reinterpret_cast<const uint8_t *>(p.zero);
                     const size_t step = in ? tplane : 0;
@@ -424,7 +418,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
         const int nwin = (rows / 2) * p.Wp;
         const int ntiles = (nwin + 7) / 8;
         const int m = lane & 31, kh = lane >> 5;
-        for (int tile = mgroup; tile < ((p.dbg & 4) ? 0 : ntiles); tile += MG) {
+        for (int tile = mgroup; tile < ntiles; tile += MG) {
             const int win = min(tile * 8 + (m >> 2), nwin - 1);
             const int wy = fdiv(win, p.mWp), wx = win - wy * p.Wp;
             const int yy0 = 2 * wy + ((m >> 1) & 1), xx0 = 2 * wx + (m & 1);
@@ -493,7 +487,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const int owin = tile * 8 + ((lane >> 2) & 7);
-                if (owin < nwin && !(p.dbg & 1)) {
+                if (owin < nwin) {
                     const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
                     const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
                     const uint32_t eo = (uint32_t)((gy * p.Wo + gx) * COUT + ntile * 32 + 8 * (lane & 3));
@@ -515,13 +509,285 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
                     for (int t = 0; t < BN_T; t++) pooled[t] = pooled4[t][g];
                     tmix4(tm, pooled, o);
                     const int owin = tile * 8 + 2 * g + kh;
-                    if (owin < nwin && (!(p.dbg & 1) || o[0] == (_Float16)12345.f)) {
+                    if (owin < nwin) {
                         const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
                         const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
                         const uint32_t eo = (uint32_t)((gy * p.Wo + gx) * COUT + co);
 #pragma unroll
                         for (int t = 0; t < BN_T; t++)
                             if (t < p.To) reinterpret_cast<_Float16 *>(ob + t * tstride)[eo] = o[t];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ enc levels 0 + 1 fused
+// Level 0's output is 4x the size of its input and level 1 reads it back with a halo: as two
+// kernels the pair moves ~235 MB per 256 frames and both are bound by that traffic.  Here a
+// workgroup takes (frame, band of level-1 pool-window rows), computes the level-0 rows the band
+// needs straight into level 1's LDS image A1 (same swizzled layout enc_mfma stages), and runs level 1
+// from there: HBM sees the u8 input, the T = 0 slice of level 0 (the last decoder block's skip
+// input) and level 1's output.  Level 0 is recomputed for the two halo rows of a band.
+//   LDS: RAW [T][raw_rows][W0] x 4 B    the item's u8 input rows, fetched by LDS-DMA while the previous
+//                                      item's level-1 tiles run (no registers, no exposed HBM latency)
+//        IN  [T][in_rows][TC0] x 8 B   level-0 input sub-band (fp16, as enc0_mfma), converted from RAW;
+//                                      reused as the per-wave output transpose scratch of level 1
+//        A1  [T][NR1][TC1] x 32 B      level-1 input band with halo and zero padding
+//        WL  13 KB                     weight fragments of both levels
+//   per item: wait for RAW, zero A1; for each sub-band of SB A1 rows: RAW -> IN, barrier, level-0
+//   tiles -> A1, barrier; then LDS-DMA of the next item's RAW, T = 0 rows of A1 -> HBM and
+//   level-1 tiles -> HBM.
+struct Enc01Args {
+    const uint8_t *in;   // [B][T][H0][W0][4]
+    __half *skip;        // level-0 output tensor [B][T][H1][W1][16]; only t = 0 is written
+    __half *out;         // level-1 output [B][T][H2][W2][32]
+    const half8 *w0frag, *w1frag;
+    const float *epi0, *epi1;
+    int B, H0, W0, Hp0, Wp0, oy0, ox0;
+    int H1, W1, Hp1, Wp1, oy1, ox1, H2, W2;
+    int nbands, TC0, TC1, NR1, SB, in_rows, a1_off, wl_off, raw_off;
+    uint32_t mNb, mW4, mWp0, mWp1, mW1;
+    const void *zero;   // >= 16 zero bytes in global memory (source of out-of-image rows)
+};
+
+constexpr int WG01 = 1024;   // 16 waves, one workgroup per CU
+template <bool ALLPOS0, bool ALLPOS1>
+__global__ __launch_bounds__(WG01, 4) void enc01_mfma(Enc01Args p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int TC0 = p.TC0, TC1 = p.TC1;
+    const int tsz0 = p.in_rows * TC0 * 8;    // bytes per T slice of IN
+    const int tsz1 = p.NR1 * TC1 * 32;       // bytes per T slice of A1
+    uint8_t *const a1 = smem + p.a1_off;
+
+    // The weight fragments (4 + 9 per lane) and epilogue constants of both levels are parked in LDS
+    // once and pulled into registers at the start of each phase, so that the two sets are never live
+    // together (128 VGPRs per lane at 16 waves per CU, no scratch).
+    half8 *const wl = reinterpret_cast<half8 *>(smem + p.wl_off);
+    float *const cl = reinterpret_cast<float *>(smem + p.wl_off + 13 * 1024);   // epi0[80] | epi1[128]
+    for (int i = tid; i < 13 * 64; i += WG01) wl[i] = i < 256 ? p.w0frag[i] : p.w1frag[i - 256];
+    if (tid < 208) cl[tid] = tid < 80 ? p.epi0[tid] : p.epi1[tid - 80];
+
+    const int W4 = p.W0 >> 2;
+    const size_t tplane0 = (size_t)p.H0 * p.W0 * 4;
+    const half2v clip = {(_Float16)1030.f, (_Float16)1030.f}, off1024 = {(_Float16)1024.f, (_Float16)1024.f};
+
+    uint8_t *const raw = smem + p.raw_off;
+    // input rows an item needs: [y_first, y_first + n_raw); issue their LDS-DMA, linear [t][row][16-byte chunk]
+    auto dma_raw = [&](int item) {
+        const int b = fdiv(item, p.mNb), band = item - b * p.nbands;
+        const int w0 = (band * p.Hp1) / p.nbands, w1 = ((band + 1) * p.Hp1) / p.nbands;
+        const int a_base = 2 * w0 - 1, n2 = 2 * (w1 - w0) + 2;
+        const int r_lo = max(0, p.oy0 - a_base), r_hi = min(n2, p.H1 - a_base);
+        const int y_first = 2 * (a_base + r_lo - p.oy0) - 1, n_raw = 2 * (r_hi - r_lo) + 2;
+        const int per_t = n_raw * W4, total = BN_T * per_t;
+        const uint8_t *fb = p.in + (size_t)b * BN_T * tplane0;
+        for (int s0 = wave * 64; s0 < total; s0 += WG01) {
+            const int i = s0 + lane;
+            if (i < total) {
+                const int t = (i >= per_t) + (i >= 2 * per_t) + (i >= 3 * per_t), rem = i - t * per_t;
+                const int r = fdiv(rem, p.mW4), c4 = rem - r * W4;
+                const int y = y_first + r;
+                const void *src = (y >= 0 && y < p.H0) ? (const void *)(fb + t * tplane0 + ((size_t)y * p.W0 + c4 * 4) * 4) : p.zero;
+                glds16(src, raw + s0 * 16);
+            }
+        }
+    };
+
+    const int n_items = p.B * p.nbands;
+    if ((int)blockIdx.x < n_items) dma_raw(blockIdx.x);
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int b = fdiv(item, p.mNb), band = item - b * p.nbands;
+        const int w0 = (band * p.Hp1) / p.nbands, w1 = ((band + 1) * p.Hp1) / p.nbands;
+        const int rb = w1 - w0, n2 = 2 * rb + 2;
+        const int a_base = 2 * w0 - 1;                        // level-0 output row of A1 row 0
+        const int r_lo = max(0, p.oy0 - a_base), r_hi = min(n2, p.H1 - a_base);   // A1 rows that hold data
+        const int y_first = 2 * (a_base + r_lo - p.oy0) - 1, n_raw = 2 * (r_hi - r_lo) + 2;
+        // Per-lane index math below depends only on the lane; re-deriving it per item from an opaque copy
+        // keeps hipcc from hoisting a few dozen loop-invariant registers out of the item loop (they
+        // would be spilled to scratch, and a kernel with scratch pays ~90 us per launch here).
+        int ll = lane;
+        asm volatile("" : "+v"(ll));
+        const int tv = (wave << 6) | ll;
+        wait_vmem();     // this item's RAW has landed
+        lds_barrier();   // ... for every wave; the previous item's level-1 tiles are done with A1 and the scratch
+        for (int i = tv; i < (BN_T * tsz1) / 16; i += WG01) reinterpret_cast<uint4 *>(a1)[i] = make_uint4(0, 0, 0, 0);
+
+        for (int r0 = r_lo; r0 < r_hi; r0 += p.SB) {
+            const int cnt = min(p.SB, r_hi - r0);             // level-0 pool rows of this sub-band
+            const int pr0 = a_base + r0 - p.oy0;              // first pool row
+            const int yin0 = 2 * pr0 - 1, nin = 2 * cnt + 2;  // input rows [yin0, yin0 + nin)
+            // ---- RAW -> IN: u8 -> fp16 with the clip at 6 (see enc0_mfma)
+            {
+                const int per_t = nin * W4;
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int i = tv + k * WG01;
+                    if (i < per_t) {
+                        const int r = fdiv(i, p.mW4), c4 = i - r * W4;
+                        const int dsto = r * TC0 * 8 + 16 + c4 * 32;
+                        const uint8_t *src = raw + ((yin0 - y_first + r) * W4 + c4) * 16;
+                        uint4 v[BN_T];
+#pragma unroll
+                        for (int t = 0; t < BN_T; t++) v[t] = *reinterpret_cast<const uint4 *>(src + t * n_raw * W4 * 16);
+#pragma unroll
+                        for (int t = 0; t < BN_T; t++) {
+                            const uint32_t px[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
+                            uint32_t o[8];
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const uint32_t c01 = __builtin_amdgcn_perm(0x64646464u, px[q], 0x05010500u);
+                                const uint32_t c23 = __builtin_amdgcn_perm(0x64646464u, px[q], 0x05030502u);
+                                const half2v h01 = __builtin_elementwise_min(__builtin_bit_cast(half2v, c01), clip) - off1024;
+                                const half2v h23 = __builtin_elementwise_min(__builtin_bit_cast(half2v, c23), clip) - off1024;
+                                o[2 * q] = __builtin_bit_cast(uint32_t, h01);
+                                o[2 * q + 1] = __builtin_bit_cast(uint32_t, h23);
+                            }
+                            uint8_t *d = smem + t * tsz0 + dsto;
+                            *reinterpret_cast<uint4 *>(d) = make_uint4(o[0], o[1], o[2], o[3]);
+                            *reinterpret_cast<uint4 *>(d + 16) = make_uint4(o[4], o[5], o[6], o[7]);
+                        }
+                    }
+                }
+                for (int i = tv; i < BN_T * nin * 2; i += WG01) {   // zero halo columns 0,1 and W+2,W+3
+                    const int rr = i >> 1;
+                    const int t = (rr >= nin) + (rr >= 2 * nin) + (rr >= 3 * nin);
+                    const int r = rr - t * nin;
+                    *reinterpret_cast<uint4 *>(smem + t * tsz0 + r * TC0 * 8 + ((i & 1) ? (p.W0 + 2) * 8 : 0)) =
+                        make_uint4(0, 0, 0, 0);
+                }
+            }
+            lds_barrier();
+            // ---- level-0 tiles of 8 pool windows (see enc0_mfma) -> A1
+            {
+                // level-0 weights: even-x / odd-x sets, two K-steps each; epilogue constants of channel lane & 15
+                const half8 be0 = wl[ll], be1 = wl[64 + ll], bo0 = wl[128 + ll], bo1 = wl[192 + ll];
+                const int co0 = ll & 15;
+                const float f0 = cl[co0], f1 = cl[16 + co0], f2 = cl[32 + co0];
+                const TmixW tm0 = load_tmix(cl + 48, ll);
+                const int nwin = cnt * p.Wp0;
+                const int ntiles = (nwin + 7) / 8;
+                const int m = ll & 15, g = ll >> 4;
+                for (int tile = wave; tile < ntiles; tile += WG01 / 64) {
+                    const int win = min(tile * 8 + (m >> 1), nwin - 1);
+                    const int wy = fdiv(win, p.mWp0), wx = win - wy * p.Wp0;
+                    const int yy = 2 * wy + (m & 1), xe = 2 * wx;
+                    const int offe0 = ((yy + (g >> 1)) * TC0 + xe + 2 * (g & 1)) * 8;
+                    const int offe1 = ((yy + 2) * TC0 + xe + 2 * (g & 1)) * 8;
+                    float pooled[2][BN_T];
+#pragma unroll
+                    for (int t = 0; t < BN_T; t++) {
+                        const uint8_t *base = smem + t * tsz0;
+                        const half8 ae0 = *reinterpret_cast<const half8 *>(base + offe0);
+                        const half8 ae1 = *reinterpret_cast<const half8 *>(base + offe1);
+                        const half8 ao0 = *reinterpret_cast<const half8 *>(base + offe0 + 16);
+                        const half8 ao1 = *reinterpret_cast<const half8 *>(base + offe1 + 16);
+                        f32x4 ce = {0.f, 0.f, 0.f, 0.f}, co_ = {0.f, 0.f, 0.f, 0.f};
+                        ce = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae0, be0, ce, 0, 0, 0);
+                        co_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao0, bo0, co_, 0, 0, 0);
+                        ce = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae1, be1, ce, 0, 0, 0);
+                        co_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao1, bo1, co_, 0, 0, 0);
+                        pooled[0][t] = pool4<ALLPOS0>(ce[0], ce[1], co_[0], co_[1], f0, f1, f2);
+                        pooled[1][t] = pool4<ALLPOS0>(ce[2], ce[3], co_[2], co_[3], f0, f1, f2);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        half4 o;
+                        tmix4(tm0, pooled[q], o);
+                        const int owin = tile * 8 + 2 * g + q;
+                        if (owin < nwin) {
+                            const int owy = fdiv(owin, p.mWp0), owx = owin - owy * p.Wp0;
+                            const int r = r0 + owy, c = owx + p.ox0 + 1;          // A1 coordinates
+                            // pixel = two 16-byte chunks, physical chunk = logical ^ (row & 1)  (enc_swz<16>)
+                            uint8_t *d = a1 + (r * TC1 + c) * 32 + (((co0 >> 3) ^ (r & 1)) * 16) + (co0 & 7) * 2;
+#pragma unroll
+                            for (int t = 0; t < BN_T; t++) *reinterpret_cast<_Float16 *>(d + t * tsz1) = o[t];
+                        }
+                    }
+                }
+            }
+            lds_barrier();
+        }
+        // ---- RAW is consumed: fetch the next item's rows behind the level-1 phase
+        if (item + (int)gridDim.x < n_items) dma_raw(item + gridDim.x);
+        // ---- T = 0 rows of the band proper -> level-0 tensor in HBM (skip input of the last decoder block)
+        {
+            const int ra = 2 * w0, rbnd = (band == p.nbands - 1) ? p.H1 : 2 * w1;   // level-0 output rows [ra, rbnd)
+            const int nch = (rbnd - ra) * p.W1 * 2;                                 // 16-byte chunks
+            __half *const sk = p.skip + (size_t)b * BN_T * p.H1 * p.W1 * 16;
+            for (int i = tv; i < nch; i += WG01) {
+                const int pix = i >> 1, ch = i & 1;
+                const int ry = fdiv(pix, p.mW1), x = pix - ry * p.W1;
+                const int r = ra + ry - a_base;                                     // A1 row
+                const uint4 v = *reinterpret_cast<const uint4 *>(a1 + (r * TC1 + x + 1) * 32 + ((ch ^ (r & 1)) * 16));
+                *reinterpret_cast<uint4 *>(sk + ((size_t)(ra + ry) * p.W1 + x) * 16 + ch * 8) = v;
+            }
+        }
+        // ---- level-1 tiles of 8 pool windows (see enc_mfma<16, 32>), one M-group per wave
+        {
+            half8 bf[9];   // one weight fragment per tap (16 input channels); epilogue constants of channel lane & 31
+#pragma unroll
+            for (int ks = 0; ks < 9; ks++) bf[ks] = wl[256 + ks * 64 + ll];
+            const int co1 = ll & 31;
+            const float e0 = cl[80 + co1], e1 = cl[80 + 32 + co1], e2 = cl[80 + 64 + co1];
+            const TmixW tm1 = load_tmix(cl + 80 + 96, ll);
+            const int nwin = rb * p.Wp1;
+            const int ntiles = (nwin + 7) / 8;
+            const int m = ll & 31, kh = ll >> 5;
+            uint8_t *const scr = smem + wave * 2048;
+            const uint32_t tstride = (uint32_t)(p.H2 * p.W2 * 32);
+            __half *const ob = p.out + (size_t)b * BN_T * tstride;
+            for (int tile = wave; tile < ntiles; tile += WG01 / 64) {
+                const int win = min(tile * 8 + (m >> 2), nwin - 1);
+                const int wy = fdiv(win, p.mWp1), wx = win - wy * p.Wp1;
+                const int yy0 = 2 * wy + ((m >> 1) & 1), xx0 = 2 * wx + (m & 1);
+                float pooled4[BN_T][4];
+#pragma unroll
+                for (int t = 0; t < BN_T; t++) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++) {
+                            const int yy = yy0 + ky, xx = xx0 + kx;
+                            const half8 a = *reinterpret_cast<const half8 *>(a1 + t * tsz1 + (yy * TC1 + xx) * 32 + ((kh ^ (yy & 1)) * 16));
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[ky * 3 + kx], acc, 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+                        pooled4[t][g] = pool4<ALLPOS1>(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], e0, e1, e2);
+                }
+#pragma unroll
+                for (int t = 0; t < BN_T; t++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) asm volatile("" : "+v"(pooled4[t][g]));
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    float pooled[BN_T];
+                    half4 o;
+#pragma unroll
+                    for (int t = 0; t < BN_T; t++) pooled[t] = pooled4[t][g];
+                    tmix4(tm1, pooled, o);
+                    _Float16 *sw = reinterpret_cast<_Float16 *>(scr + (2 * g + kh) * 64) + co1;
+#pragma unroll
+                    for (int t = 0; t < BN_T; t++) sw[t * 256] = o[t];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int owin = tile * 8 + ((ll >> 2) & 7);
+                if (owin < nwin) {
+                    const int owy = fdiv(owin, p.mWp1), owx = owin - owy * p.Wp1;
+                    const int gy = w0 + owy + p.oy1, gx = owx + p.ox1;
+                    const uint32_t eo = (uint32_t)((gy * p.W2 + gx) * 32 + 8 * (ll & 3));
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(scr + (j * 64 + ll) * 16);
+                        *reinterpret_cast<uint4 *>(ob + (2 * j + (ll >> 5)) * tstride + eo) = v;
                     }
                 }
             }
@@ -570,7 +836,7 @@ __global__ __launch_bounds__(((FINAL ? 1 : 4 * COUT / 32) > 4 ? 4 * COUT / 32 : 
     }
     const float fbias = FINAL ? p.epi[0] : 0.f;
 
-    const int n_items = (p.dbg & 8) ? 0 : p.B * p.nbands;
+    const int n_items = p.B * p.nbands;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int b = fdiv(item, p.mNb), band = item - b * p.nbands;
         const int u0 = band * GH / p.nbands, u1 = (band + 1) * GH / p.nbands;
@@ -590,7 +856,7 @@ __global__ __launch_bounds__(((FINAL ? 1 : 4 * COUT / 32) > 4 ? 4 * COUT / 32 : 
                     const int cb = (chp ^ dec_swz<C>(c)) * 8;
                     const int y = u0 - 1 + r, x = c - 1;
                     const void *src = p.zero;
-                    if (y >= 0 && y < p.Hi && x >= 0 && x < p.Wi && !(p.dbg & 2)) {
+                    if (y >= 0 && y < p.Hi && x >= 0 && x < p.Wi) {
                         const size_t pix = (size_t)y * p.Wi + x;
                         if constexpr (C1 == 0) {
                             src = ss + pix * C2 + cb;
@@ -612,7 +878,7 @@ __global__ __launch_bounds__(((FINAL ? 1 : 4 * COUT / 32) > 4 ? 4 * COUT / 32 : 
         // ---- compute over the band's flattened (u, v) positions
         const int npos = nu * GW;
         const int ntiles = (npos + 31) / 32;
-        for (int tile = pgroup; tile < ((p.dbg & 4) ? 0 : ntiles); tile += PG) {
+        for (int tile = pgroup; tile < ntiles; tile += PG) {
             const int q = tile * 32 + (lane & 31);
             const int qc = min(q, npos - 1);
             const int ul = fdiv(qc, p.mGW), v = qc - ul * GW;   // ul = u - u0
@@ -632,7 +898,7 @@ __global__ __launch_bounds__(((FINAL ? 1 : 4 * COUT / 32) > 4 ? 4 * COUT / 32 : 
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[(a * 2 + bb) * KC + kc], av, acc, 0, 0, 0);
                     }
                 }
-            if (q >= npos || ((p.dbg & 1) && acc[0] != 12345.f)) continue;
+            if (q >= npos) continue;
             const int u = u0 + ul;
             if constexpr (FINAL) {
                 // rows 0..3 = parities (py,px) = (r>>1, r&1): only the kh == 0 half holds them
@@ -896,7 +1162,57 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
     const int num_cu = ctx->props.multiProcessorCount;
 
     // ---------------- encoder
-    for (int i = 0; i < BN_LEVELS; i++) {
+    int first_level = 0;
+    if (m->fuse01) {
+        // levels 0 + 1 in one kernel when the geometry fits its LDS plan (otherwise: one kernel per level)
+        const int H0 = m->lv[0].H, W0 = m->lv[0].W, H1 = m->lv[1].H, W1 = m->lv[1].W;
+        const int Hp1 = H1 / 2, Wp1 = W1 / 2;
+        const int TC0 = ((W0 + 4 - 16 + 31) / 32) * 32 + 16, TC1 = W1 + 2;
+        const size_t lds_max = 160 * 1024 - 512;
+        // fewest bands (least level-0 halo recomputation) whose A1 + IN fit; a level-1 band is at most 16 tiles
+        // (one per wave) and IN takes half the A1 rows (at most two chunk positions per thread)
+        int nbands = 0, NR1 = 0, SB = 0, in_rows = 0;
+        size_t in_bytes = 0, a1_bytes = 0, raw_bytes = 0;
+        for (int nb = 1; nb <= Hp1 && W0 % 4 == 0; nb++) {
+            const int rb = (Hp1 + nb - 1) / nb, nr1 = 2 * rb + 2;
+            if ((rb * Wp1 + 7) / 8 > WG01 / 64) continue;
+            const int sb = (nr1 + 1) / 2, inr = 2 * sb + 2;
+            const size_t ib = std::max((size_t)BN_T * inr * TC0 * 8, (size_t)(WG01 / 64) * 2048);
+            const size_t ab = (size_t)BN_T * nr1 * TC1 * 32;
+            const size_t rwb = (size_t)BN_T * (2 * nr1 + 2) * W0 * 4;
+            if (ib + ab + rwb + 14 * 1024 > lds_max || inr * (W0 / 4) > 2 * WG01) continue;
+            if ((long long)batch * nb < num_cu && nb < Hp1) continue;   // keep every CU busy
+            nbands = nb; NR1 = nr1; SB = sb; in_rows = inr; in_bytes = (ib + 15) & ~(size_t)15; a1_bytes = ab; raw_bytes = rwb;
+            break;
+        }
+        if (nbands) {
+            Enc01Args a{};
+            a.in = d_stack; a.skip = act[1]; a.out = act[2];
+            a.w0frag = (const half8 *)(prep + pr->enc[0].wfrag); a.epi0 = (const float *)(prep + pr->enc[0].epi);
+            a.w1frag = (const half8 *)(prep + pr->enc[1].wfrag); a.epi1 = (const float *)(prep + pr->enc[1].epi);
+            a.B = batch; a.H0 = H0; a.W0 = W0; a.Hp0 = H0 / 2; a.Wp0 = W0 / 2; a.oy0 = H0 & 1; a.ox0 = W0 & 1;
+            a.H1 = H1; a.W1 = W1; a.Hp1 = Hp1; a.Wp1 = Wp1; a.oy1 = H1 & 1; a.ox1 = W1 & 1;
+            a.H2 = m->lv[2].H; a.W2 = m->lv[2].W;
+            a.nbands = nbands; a.TC0 = TC0; a.TC1 = TC1; a.NR1 = NR1; a.SB = SB; a.in_rows = in_rows;
+            a.a1_off = (int)in_bytes; a.wl_off = (int)(in_bytes + a1_bytes); a.raw_off = (int)(in_bytes + a1_bytes + 14 * 1024);
+            a.zero = prep + pr->zero;
+            a.mNb = magic(nbands); a.mW4 = magic(W0 / 4); a.mWp0 = magic(W0 / 2); a.mWp1 = magic(Wp1); a.mW1 = magic(W1);
+            const size_t lds = in_bytes + a1_bytes + 14 * 1024 + raw_bytes;
+            const int grid = std::min(batch * nbands, num_cu);
+            const bool p0 = pr->allpos[0], p1 = pr->allpos[1];
+            int rc = p0 ? (p1 ? set_lds(ctx, enc01_mfma<true, true>, lds) : set_lds(ctx, enc01_mfma<true, false>, lds))
+                        : (p1 ? set_lds(ctx, enc01_mfma<false, true>, lds) : set_lds(ctx, enc01_mfma<false, false>, lds));
+            if (rc) return rc;
+            ProfScope ps(ctx, "enc01_mfma");
+            if (p0 && p1) hipLaunchKernelGGL((enc01_mfma<true, true>), dim3(grid), dim3(WG01), lds, ctx->stream, a);
+            else if (p0) hipLaunchKernelGGL((enc01_mfma<true, false>), dim3(grid), dim3(WG01), lds, ctx->stream, a);
+            else if (p1) hipLaunchKernelGGL((enc01_mfma<false, true>), dim3(grid), dim3(WG01), lds, ctx->stream, a);
+            else hipLaunchKernelGGL((enc01_mfma<false, false>), dim3(grid), dim3(WG01), lds, ctx->stream, a);
+            COVAHIP_CHECK_HIP(ctx, hipGetLastError());
+            first_level = 2;
+        }
+    }
+    for (int i = first_level; i < BN_LEVELS; i++) {
         const int H = m->lv[i].H, W = m->lv[i].W, Hp = H / 2, Wp = W / 2;
         const int cin = m->enc_c[i];
         const size_t px_bytes = (i == 0) ? 8 : (size_t)cin * 2;
@@ -913,8 +1229,8 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
         static const int enc_waves[BN_LEVELS] = {WG0 / 64, 8, 4, 8};
         static const bool enc_wide[BN_LEVELS] = {true, true, false, true};
         const size_t scr_bytes = (i == 0) ? (size_t)enc_waves[0] * 1024 : (enc_wide[i] ? (size_t)enc_waves[i] * 2048 : 0);
-        const size_t lds_cap = ((i == BN_LEVELS - 1) ? 150 * 1024 : 80 * 1024) - scr_bytes;
         const int wgs_per_cu = (i == BN_LEVELS - 1) ? 1 : 2;
+        const size_t lds_cap = (wgs_per_cu == 1 ? 150 * 1024 : 80 * 1024) - scr_bytes;
         // band planner: bands of whole pool-window rows.  Workgroups are persistent (wgs_per_cu per CU)
         // and take items round-robin, so a launch lasts ceil(items / slots) rounds of one band each;
         // a band costs its window rows plus about one row of halo staging + barriers.  Pick the band
@@ -929,22 +1245,12 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
             const long long cost = rounds * (rb + 1);
             if (best < 0 || cost < best) { best = cost; nbands = nb; RB = 2 * rb; }
         }
-        if (const char *ov = std::getenv("COVAHIP_DEV_ENC_NB")) {   // developer override: "nb0,nb1,nb2,nb3" (0 = planner)
-            int v[BN_LEVELS] = {0, 0, 0, 0};
-            std::sscanf(ov, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
-            if (v[i] > 0 && v[i] <= Hp) { nbands = v[i]; RB = 2 * ((Hp + nbands - 1) / nbands); }
-        }
         if (!nbands) return COVAHIP_ERR_UNSUPPORTED;
         const size_t tile_bytes = (((size_t)BN_T * (RB + 2) * TC * px_bytes) + 15) & ~(size_t)15;
         const size_t lds = tile_bytes + scr_bytes;
         if (lds > 160 * 1024 - 256) return COVAHIP_ERR_UNSUPPORTED;
         const int items = batch * nbands;
-        int grid = std::min(items, (i == BN_LEVELS - 1 ? 1 : 2) * num_cu);
-        if (const char *ov = std::getenv("COVAHIP_DEV_ENC_GRID")) {   // developer override: workgroups per CU per level (0 = keep)
-            int v[BN_LEVELS] = {0, 0, 0, 0};
-            std::sscanf(ov, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
-            if (v[i] > 0) grid = std::min(items, v[i] * num_cu);
-        }
+        const int grid = std::min(items, wgs_per_cu * num_cu);
         if (i == 0) {
             Enc0Args a;
             a.in = d_stack; a.out = act[1];
@@ -952,7 +1258,6 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
             a.B = batch; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.Ho = m->lv[1].H; a.Wo = m->lv[1].W;
             a.oy = H & 1; a.ox = W & 1; a.RB = RB; a.nbands = nbands; a.TR = RB + 2; a.TC = TC;
             a.mWp = magic(Wp); a.mNb = magic(nbands); a.mW4 = magic(W / 4); a.scr_off = (int)tile_bytes;
-            a.dbg = std::getenv("COVAHIP_DEV_DBG") ? std::atoi(std::getenv("COVAHIP_DEV_DBG")) : 0;
             if (W % 4 || (RB + 2) * (W / 4) > 2 * WG0) return COVAHIP_ERR_UNSUPPORTED;
             int rc = pr->allpos[0] ? set_lds(ctx, enc0_mfma<true>, lds) : set_lds(ctx, enc0_mfma<false>, lds);
             if (rc) return rc;
@@ -967,7 +1272,6 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
             a.oy = H & 1; a.ox = W & 1; a.To = (i == BN_LEVELS - 1) ? 1 : BN_T;
             a.RB = RB; a.nbands = nbands; a.TR = RB + 2; a.TC = TC;
             a.mWp = magic(Wp); a.mNb = magic(nbands); a.mRC = magic(TC * (cin / 8)); a.zero = prep + pr->zero; a.scr_off = (int)tile_bytes;
-            a.dbg = std::getenv("COVAHIP_DEV_DBG") ? std::atoi(std::getenv("COVAHIP_DEV_DBG")) : 0;
             int rc = COVAHIP_OK;
             if (i == 1) {
                 rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true, true>, lds) : set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true, false>, lds);
@@ -1019,26 +1323,15 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
             while (nbands < GH && (((size_t)((GH + nbands - 1) / nbands) + 1) * row_bytes > 30 * 1024 ||
                                    (long long)batch * nbands < 2LL * num_cu))
                 nbands++;
-        if (const char *ov = std::getenv("COVAHIP_DEV_DEC_NB")) {   // developer override
-            int v[BN_LEVELS] = {0, 0, 0, 0};
-            std::sscanf(ov, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
-            if (v[j] > 0 && v[j] <= GH) nbands = v[j];
-        }
         a.nbands = nbands; a.mNb = magic(nbands); a.mGW = magic(in.W + 1);
         a.mRC = magic((in.W + 2) * (m->dec_ci[j] / 8)); a.zero = prep + pr->zero;
-        a.dbg = std::getenv("COVAHIP_DEV_DBG") ? std::atoi(std::getenv("COVAHIP_DEV_DBG")) >> 8 : 0;
         const size_t tile_bytes = ((size_t)((GH + nbands - 1) / nbands) + 1) * row_bytes;
         const size_t mask_bytes = last ? ((((size_t)2 * ((GH + nbands - 1) / nbands) * out.W) + 15) & ~(size_t)15) : 0;
         const size_t lds = tile_bytes + mask_bytes;
         a.mask_off = (int)tile_bytes;
         if (lds > 160 * 1024 - 256) return COVAHIP_ERR_UNSUPPORTED;
         const int items = batch * nbands;
-        int grid = std::min(items, (heavy ? 1 : 4) * num_cu);
-        if (const char *ov = std::getenv("COVAHIP_DEV_DEC_GRID")) {
-            int v[BN_LEVELS] = {0, 0, 0, 0};
-            std::sscanf(ov, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
-            if (v[j] > 0) grid = std::min(items, v[j] * num_cu);
-        }
+        const int grid = std::min(items, (heavy ? 1 : 4) * num_cu);
         int rc;
         if (j == 0) {
             rc = set_lds(ctx, dec_mfma<0, 128, 64, false>, lds);

@@ -160,7 +160,7 @@ class BlobNetInfer:
                 "covahip_blobnet_load", ctx.handle)
 
     def set_impl(self, impl: str):
-        L.check(self._lib.covahip_blobnet_set_impl(self.ctx.handle, {"naive": 0, "mfma": 1}[impl]), "set_impl")
+        L.check(self._lib.covahip_blobnet_set_impl(self.ctx.handle, {"naive": 0, "mfma": 1, "mfma_fused01": 2}[impl]), "set_impl")
 
     def set_overlap(self, on: bool):
         L.check(self._lib.covahip_blobnet_set_overlap(self.ctx.handle, int(on)), "set_overlap")

@@ -120,8 +120,9 @@ int covahip_blobnet_forward(covahip_ctx *ctx, const uint8_t *rgba_stack, int bat
 int covahip_set_pipeline(covahip_ctx *ctx, int on);
 /* Algorithmic MACs per frame of the loaded geometry. */
 int covahip_blobnet_macs_per_frame(covahip_ctx *ctx, int64_t *macs);
-/* Debug switch: 1 = MFMA kernels (default), 0 = direct one-thread-per-output kernels
- * (on-GPU bring-up path; also selectable with COVAHIP_BLOBNET_IMPL=naive). */
+/* Implementation switch: 1 = MFMA kernels, one kernel per level (default); 2 = MFMA kernels with encoder
+ * levels 0 and 1 fused into one kernel (less HBM traffic, measured slower on MI355X, kept for study);
+ * 0 = direct one-thread-per-output kernels (on-GPU bring-up path; also COVAHIP_BLOBNET_IMPL=naive). */
 int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl);
 /* 1: batches >= 32 are issued as two half-batches on two HIP streams (frames are independent);
  * 0 (default): one stream.  Per-kernel profiling of all kernels forces 0. */

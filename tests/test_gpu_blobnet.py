@@ -24,8 +24,8 @@ def _check(logits, mask, ref_logits):
     return float(err.max())
 
 
-@pytest.mark.parametrize("impl", ["naive", "mfma"])
-@pytest.mark.parametrize("hw", [(68, 120), (67, 120), (45, 80)])
+@pytest.mark.parametrize("impl", ["naive", "mfma", "mfma_fused01"])
+@pytest.mark.parametrize("hw", [(68, 120), (67, 120), (45, 80), (35, 60)])
 def test_logits_match_oracle(ctx, weights_flat, hw, impl):
     h, w = hw
     stack = synth.stacked_batch(3, h, w, seed=11, streams=3)
@@ -51,7 +51,8 @@ def test_alpha_channel_ignored_and_clip(ctx, weights_flat):
     np.testing.assert_array_equal(l0, l2)
 
 
-def test_negative_bn_gamma(ctx):
+@pytest.mark.parametrize("impl", ["mfma", "mfma_fused01"])
+def test_negative_bn_gamma(ctx, impl):
     """BN runs after ReLU and before max-pool; a negative gamma must not commute with the max."""
     from cova_amd import weights as W
     wts = W.unflatten(W.random_init(77))
@@ -62,6 +63,7 @@ def test_negative_bn_gamma(ctx):
     h, w = 45, 80
     stack = synth.stacked_batch(2, h, w, seed=21)
     net = BlobNetInfer(ctx, flat, h, w, max_batch=2)
+    net.set_impl(impl)
     logits, mask = net.infer(stack)
     ref_logits, _ = ref.blobnet_forward(flat, stack, h, w)
     _check(logits, mask, ref_logits)
@@ -141,3 +143,16 @@ def test_pipelined_device_path_matches_unpipelined(ctx, weights_flat):
     np.testing.assert_array_equal(counts, ref_res[1][0])
     for p in d_stack + [d_boxes, d_counts, d_mask]:
         ctx.free(p)
+
+
+def test_fused_levels_match_per_level_kernels_bitwise(ctx, weights_flat):
+    """Encoder levels 0+1 as one kernel compute the same fp16 tensors as the two per-level kernels
+    (same MFMA tiles, same rounding points), so the logits are identical bit for bit."""
+    h, w = 68, 120
+    stack = synth.stacked_batch(64, h, w, seed=9, streams=4)
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=64)
+    l0, m0 = net.infer(stack)
+    net.set_impl("mfma_fused01")
+    l1, m1 = net.infer(stack)
+    np.testing.assert_array_equal(l0, l1)
+    np.testing.assert_array_equal(m0, m1)

@@ -16,6 +16,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 ctx = Context(0)
 flat = W.random_init(1234)
 net = BlobNetInfer(ctx, flat, H, Wd, max_batch=B)
+if os.environ.get("QB_IMPL"):
+    net.set_impl(os.environ["QB_IMPL"])
 stack = synth.stacked_batch(min(B, 64), H, Wd, seed=1, streams=8)
 stack = np.concatenate([stack] * (B // stack.shape[0] + 1))[:B]
 d_stack = ctx.malloc(stack.nbytes)
