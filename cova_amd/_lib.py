@@ -53,6 +53,11 @@ class GopFilterCfg(C.Structure):
                 ("alpha", C.c_uint32), ("beta", C.c_uint32), ("infer_i", C.c_uint8)]
 
 
+class AssocCfg(C.Structure):
+    _fields_ = [("moving_iou", C.c_float), ("stationary_iou", C.c_float), ("stationary_maxage_s", C.c_uint64),
+                ("scale_factor", C.c_float)]
+
+
 # name -> (restype, argtypes); every symbol include/covahip.h declares
 _P = C.c_void_p
 _SZ = C.c_size_t
@@ -93,6 +98,15 @@ PROTOTYPES = {
     "covahip_tfrecord_example": (_SZ, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _SZ, C.POINTER(C.c_int)]),
     "covahip_bbox_csv": (_SZ, [_P, _SZ, C.c_int, _P, _SZ, C.POINTER(C.c_int)]),
     "covahip_tracks_export": (_SZ, [C.c_uint64, C.c_uint64, _P, _P, _SZ, _P, _SZ, C.POINTER(C.c_int)]),
+    "covahip_assoc_default_cfg": (None, [C.POINTER(AssocCfg)]),
+    "covahip_assoc_new": (C.c_int, [C.POINTER(AssocCfg), _P, _SZ, C.POINTER(_P)]),
+    "covahip_assoc_free": (None, [_P]),
+    "covahip_assoc_push_track": (C.c_int, [_P, C.c_uint64, C.c_uint64, _P, _SZ]),
+    "covahip_assoc_push_track_frame": (C.c_int, [_P, _P, _SZ]),
+    "covahip_assoc_push_dnn": (C.c_int, [_P, _P, _SZ]),
+    "covahip_assoc_push_dnn_text": (C.c_int, [_P, C.c_char_p, _SZ]),
+    "covahip_assoc_terminate": (C.c_int, [_P]),
+    "covahip_assoc_csv": (_SZ, [_P, C.c_int, _P, _SZ, C.POINTER(C.c_int)]),
     "covahip_stack_new": (C.c_int, [_SZ, C.c_uint, C.c_uint, C.POINTER(_P)]),
     "covahip_stack_free": (None, [_P]),
     "covahip_stack_push": (C.c_int, [_P, _P, _SZ, _P, _SZ, C.POINTER(C.c_int)]),

@@ -14,10 +14,12 @@
 //   u64 length prefix, 1-byte Option tag).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <limits>
 #include <list>
+#include <map>
 #include <new>
 #include <vector>
 
@@ -966,24 +968,32 @@ void put_len_field(std::string &s, int field, const std::string &payload) {
     s += payload;
 }
 
-// serde/csv formats f32 with ryu: shortest round-trip digits, always a ".0" on integral values,
-// exponents as "e21" / "e-7"
+// serde/csv formats f32 with ryu (crate ryu, pretty::format32): shortest round-trip decimal digits
+// d1..dn with decimal exponent k (value = d1..dn x 10^k), kk = n + k, then
+//   0 <= k  and kk <= 13 : digits, k zeros, ".0"          1234e7  -> 12340000000.0
+//   0 <  kk and kk <= 13 : decimal point inside            1234e-2 -> 12.34
+//   -6 < kk and kk <= 0  : "0." + (-kk) zeros + digits      1234e-6 -> 0.001234
+//   otherwise            : d1[.d2..dn]e(kk-1)                1e21, 1.234e33, 1e-7
 std::string ryu_like(float v) {
     if (std::isnan(v)) return "NaN";
     if (std::isinf(v)) return v > 0 ? "inf" : "-inf";
+    if (v == 0.f) return std::signbit(v) ? "-0.0" : "0.0";
     char buf[64];
-    auto r = std::to_chars(buf, buf + sizeof(buf), v);
+    auto r = std::to_chars(buf, buf + sizeof(buf), v, std::chars_format::scientific);   // shortest digits
     std::string s(buf, r.ptr);
+    std::string sign;
+    if (s[0] == '-') { sign = "-"; s = s.substr(1); }
     const size_t e = s.find('e');
-    if (e != std::string::npos) {
-        std::string mant = s.substr(0, e), ex = s.substr(e + 1);
-        bool neg = false;
-        if (!ex.empty() && (ex[0] == '+' || ex[0] == '-')) { neg = ex[0] == '-'; ex = ex.substr(1); }
-        while (ex.size() > 1 && ex[0] == '0') ex = ex.substr(1);
-        return mant + "e" + (neg ? "-" : "") + ex;
-    }
-    if (s.find('.') == std::string::npos) s += ".0";
-    return s;
+    std::string digits;
+    for (char c : s.substr(0, e)) if (c != '.') digits += c;
+    const int sci = std::atoi(s.c_str() + e + 1);
+    const int n = (int)digits.size(), kk = sci + 1, k = kk - n;
+    std::string out;
+    if (k >= 0 && kk <= 13) out = digits + std::string(k, '0') + ".0";
+    else if (kk > 0 && kk <= 13) out = digits.substr(0, kk) + "." + digits.substr(kk);
+    else if (kk > -6 && kk <= 0) out = "0." + std::string(-kk, '0') + digits;
+    else out = digits.substr(0, 1) + (n > 1 ? "." + digits.substr(1) : "") + "e" + std::to_string(kk - 1);
+    return sign + out;
 }
 
 }  // namespace
@@ -1079,6 +1089,283 @@ size_t covahip_tracks_export(uint64_t range_start, uint64_t oldest, const covahi
     }
     if (status) *status = (out && need <= cap) ? COVAHIP_OK : COVAHIP_ERR_OVERFLOW;
     return need;
+}
+
+}  // extern "C"
+
+// ===================================================================== analysis-aggregator join
+// Association of tracker output with DNN detections, restating
+// cova-rs/analysis-aggregator/src/server/assoc.rs (Associator :63-441, message loop :443-507),
+// track.rs:59-66 and dnn.rs:57-86.  The reference visits three HashMaps; the orders are fixed
+// here: classes in ascending id, the LAST of equally frequent classes is "the most frequent" (what
+// max_by_key returns over an ascending visit), ranges ascending at terminate.  Quirks kept: `>` vs `>=` moving_iou for a
+// new vs an existing track, the always-true "two detections" filter, tracks still pending at
+// terminate never reach assoc.csv.
+namespace {
+
+struct StationaryObj {   // assoc.rs:11-58
+    uint64_t range_start, range_end, start, end;
+    covahip_bbox bbox;
+    uint32_t class_id;
+};
+
+void bbox_scale(covahip_bbox &b, float s) {   // bbox.rs:69-82: the centroid stays
+    if (s == 1.f) return;
+    const float x = b.left + b.width / 2.f, y = b.top + b.height / 2.f;
+    b.width *= s;
+    b.height *= s;
+    b.left = x - b.width / 2.f;
+    b.top = y - b.height / 2.f;
+    b.area *= s * s;
+}
+void bbox_scale_dim(covahip_bbox &b, float s) {   // bbox.rs:58-67
+    if (s == 1.f) return;
+    b.left *= s; b.top *= s; b.width *= s; b.height *= s;
+    b.area *= s * s;
+}
+
+std::string csv_rows(const std::vector<covahip_bbox> &rows) {
+    if (rows.empty()) return std::string();   // csv::Writer emits the header with the first record
+    const size_t n = covahip_bbox_csv(rows.data(), rows.size(), 1, nullptr, 0, nullptr);
+    std::string out(n, '\0');
+    int st = 0;
+    covahip_bbox_csv(rows.data(), rows.size(), 1, &out[0], n, &st);
+    return out;
+}
+
+}  // namespace
+
+struct covahip_assoc {
+    struct Track { uint64_t range_start, range_end; std::vector<covahip_bbox> boxes; };
+    struct Dnn { bool matched; covahip_bbox box; };
+    std::map<uint64_t, uint64_t> tracker_range;
+    std::vector<covahip_bbox> rows[4];   // track, dnn, assoc, stationary
+    std::list<Track> tracks;
+    std::list<Dnn> dnns;
+    std::list<StationaryObj> stationary, finalized;
+    std::map<uint64_t, std::vector<uint32_t>> track2class;
+    float moving_iou = 0.15f, stationary_iou = 0.3f, scale_factor = 1.3f;
+    uint64_t stationary_maxage = 120ull * 1000000000ull, max_track_id = 0;
+    std::string dnn_text;                // unparsed tail of the detection text stream
+    bool terminated = false;
+
+    void finalize_trk(uint64_t ts) {     // assoc.rs:127-215
+        for (auto it = tracks.begin(); it != tracks.end();) {
+            if (!(it->range_start <= ts && ts < it->range_end && it->boxes.back().timestamp < ts)) { ++it; continue; }
+            std::vector<uint32_t> class_ids;
+            auto f = track2class.find(it->boxes.front().track_id);
+            if (f != track2class.end() && !f->second.empty()) {
+                std::map<uint32_t, int> count;
+                for (uint32_t c : f->second) count[c]++;
+                uint32_t best = 0;
+                int freq = -1;
+                for (auto &kv : count) if (kv.second >= freq) { best = kv.first; freq = kv.second; }
+                count.erase(best);
+                class_ids.push_back(best);
+                for (auto &kv : count) if (freq == 1 || kv.second >= 2) class_ids.push_back(kv.first);
+            }
+            if (f != track2class.end()) track2class.erase(f);
+            for (uint32_t c : class_ids)
+                for (auto &b : it->boxes) { b.class_id = c; b.has_class_id = 1; rows[2].push_back(b); }
+            it = tracks.erase(it);
+        }
+    }
+    void finalize_dnn(uint64_t rs, uint64_t re, uint64_t ts) {   // assoc.rs:220-267
+        for (auto it = dnns.begin(); it != dnns.end();) {
+            const uint64_t dt = it->box.timestamp;
+            if (!(rs <= dt && dt < re && dt < ts)) { ++it; continue; }
+            if (!it->matched) {
+                StationaryObj *best = nullptr;
+                float best_iou = 0.f;
+                for (auto &so : stationary) {
+                    if (so.range_start != rs || so.class_id != it->box.class_id) continue;
+                    const float iou = bbox_iou(so.bbox, it->box);
+                    if (iou >= stationary_iou && (!best || iou >= best_iou)) { best = &so; best_iou = iou; }
+                }
+                if (best) best->end = dt;
+                else stationary.push_back(StationaryObj{rs, re, dt, dt, it->box, it->box.class_id});
+            }
+            it = dnns.erase(it);
+        }
+    }
+    void finalize_stationary(uint64_t ts) {   // assoc.rs:271-287
+        for (auto it = stationary.begin(); it != stationary.end();) {
+            if (it->range_start <= ts && ts < it->range_end && stationary_maxage + it->end < ts) {
+                if (it->range_start != it->range_end) finalized.push_back(*it);   // the reference's filter, always true
+                it = stationary.erase(it);
+            } else ++it;
+        }
+    }
+    // the track's box at `ts`, scaled about its centre (assoc.rs:326-334, 396-404); false = the reference unwraps None
+    bool match_box(const std::vector<covahip_bbox> &trk, uint64_t ts, covahip_bbox &out) const {
+        for (auto &b : trk)
+            if (b.timestamp == ts) { out = b; bbox_scale(out, scale_factor); return true; }
+        return false;
+    }
+    int update_dnn(const covahip_bbox *boxes, size_t n) {   // assoc.rs:296-367
+        std::vector<uint64_t> seen;
+        for (size_t i = 0; i < n; i++) {
+            if (!boxes[i].has_timestamp || !boxes[i].has_class_id) return COVAHIP_ERR_BAD_DATA;
+            if (std::find(seen.begin(), seen.end(), boxes[i].timestamp) == seen.end()) seen.push_back(boxes[i].timestamp);
+        }
+        for (uint64_t ts : seen) { finalize_stationary(ts); finalize_trk(ts); }
+        for (size_t i = 0; i < n; i++) {
+            const covahip_bbox &d = boxes[i];
+            rows[1].push_back(d);
+            bool matched = false;
+            for (auto &t : tracks) {
+                if (!(t.range_start <= d.timestamp && d.timestamp < t.range_end && t.boxes.front().timestamp <= d.timestamp)) continue;
+                covahip_bbox tb;
+                if (!match_box(t.boxes, d.timestamp, tb)) return COVAHIP_ERR_BAD_DATA;
+                if (bbox_iou(tb, d) >= moving_iou) { track2class[tb.track_id].push_back(d.class_id); matched = true; }
+            }
+            dnns.push_back(Dnn{matched, d});
+        }
+        return COVAHIP_OK;
+    }
+    int update_track(uint64_t rs, uint64_t oldest, const covahip_bbox *boxes, size_t n) {   // assoc.rs:370-431
+        auto r = tracker_range.find(rs);
+        if (r == tracker_range.end() || n == 0) return COVAHIP_ERR_BAD_DATA;
+        for (size_t i = 0; i < n; i++) if (!boxes[i].has_timestamp || !boxes[i].has_track_id) return COVAHIP_ERR_BAD_DATA;
+        Track t{rs, r->second, std::vector<covahip_bbox>(boxes, boxes + n)};
+        for (auto &b : t.boxes) rows[0].push_back(b);
+        max_track_id = std::max(max_track_id, t.boxes.front().track_id);
+        const uint64_t t0 = t.boxes.front().timestamp, t1 = t.boxes.back().timestamp;
+        for (auto &d : dnns) {
+            if (!(t0 <= d.box.timestamp && d.box.timestamp <= t1)) continue;
+            covahip_bbox tb;
+            if (!match_box(t.boxes, d.box.timestamp, tb)) return COVAHIP_ERR_BAD_DATA;
+            if (bbox_iou(tb, d.box) > moving_iou) { track2class[tb.track_id].push_back(d.box.class_id); d.matched = true; }
+        }
+        tracks.push_back(std::move(t));
+        finalize_dnn(rs, r->second, oldest);
+        return COVAHIP_OK;
+    }
+    void terminate() {   // assoc.rs:434-467
+        if (terminated) return;
+        terminated = true;
+        for (auto &kv : tracker_range) {
+            finalize_trk(kv.second);
+            finalize_dnn(kv.first, kv.second, kv.second);
+            finalize_stationary(kv.second);
+        }
+        uint64_t tid = max_track_id + 1;
+        for (auto &so : finalized) {
+            for (uint64_t ts = so.start; ts < so.end; ts += 100000000ull)   // Stationary::to_vec, assoc.rs:41-57
+                for (uint64_t i = 0; i < 2; i++) {
+                    covahip_bbox b = so.bbox;
+                    b.timestamp = ts + i * 33333333ull; b.has_timestamp = 1;
+                    b.track_id = tid; b.has_track_id = 1;
+                    rows[3].push_back(b);
+                }
+            tid++;
+        }
+    }
+};
+
+extern "C" {
+
+void covahip_assoc_default_cfg(covahip_assoc_cfg *cfg) {   // main.rs:32-39
+    if (!cfg) return;
+    cfg->moving_iou = 0.15f;
+    cfg->stationary_iou = 0.3f;
+    cfg->stationary_maxage_s = 120;
+    cfg->scale_factor = 1.3f;
+}
+
+int covahip_assoc_new(const covahip_assoc_cfg *cfg, const uint64_t *range_starts, size_t n_trackers, covahip_assoc **out) {
+    if (!cfg || !range_starts || !n_trackers || !out) return COVAHIP_ERR_INVALID_ARG;
+    covahip_assoc *a = new covahip_assoc();
+    a->moving_iou = cfg->moving_iou;
+    a->stationary_iou = cfg->stationary_iou;
+    a->stationary_maxage = cfg->stationary_maxage_s * 1000000000ull;
+    a->scale_factor = cfg->scale_factor;
+    std::vector<uint64_t> rs(range_starts, range_starts + n_trackers);   // assoc.rs:473-489
+    std::sort(rs.begin(), rs.end());
+    rs.push_back(UINT64_MAX);
+    for (size_t i = 0; i < n_trackers; i++) a->tracker_range[rs[i]] = rs[i + 1];
+    *out = a;
+    return COVAHIP_OK;
+}
+void covahip_assoc_free(covahip_assoc *a) { delete a; }
+
+int covahip_assoc_push_track(covahip_assoc *a, uint64_t range_start, uint64_t oldest, const covahip_bbox *boxes, size_t n) {
+    if (!a || (!boxes && n) || a->terminated) return COVAHIP_ERR_INVALID_ARG;
+    return a->update_track(range_start, oldest, boxes, n);
+}
+
+// One LengthDelimitedCodec payload as a tracker connection receives it (track.rs:47-66): bincode Frame,
+// boxes scaled from macroblocks to pixels (x16), track ids re-based by range_start.
+int covahip_assoc_push_track_frame(covahip_assoc *a, const uint8_t *payload, size_t len) {
+    if (!a || !payload || a->terminated) return COVAHIP_ERR_INVALID_ARG;
+    Reader r{payload, len};
+    const uint64_t rs = r.val<uint64_t>(), oldest = r.val<uint64_t>(), cnt = r.val<uint64_t>();
+    if (!r.ok || cnt > len) return COVAHIP_ERR_BAD_DATA;
+    std::vector<covahip_bbox> boxes((size_t)cnt);
+    for (auto &b : boxes) {
+        if (!read_bbox(r, b) || !b.has_track_id) return COVAHIP_ERR_BAD_DATA;
+        bbox_scale_dim(b, 16.f);
+        b.track_id += rs;
+    }
+    if (r.n != len) return COVAHIP_ERR_BAD_DATA;
+    return a->update_track(rs, oldest, boxes.data(), boxes.size());
+}
+
+int covahip_assoc_push_dnn(covahip_assoc *a, const covahip_bbox *boxes, size_t n) {
+    if (!a || (!boxes && n) || a->terminated) return COVAHIP_ERR_INVALID_ARG;
+    return a->update_dnn(boxes, n);
+}
+
+// Detection text as it arrives on a DNN connection (dnn.rs:57-86): rows "timestamp,left,top,width,height,class_id\n";
+// an incomplete last row is kept for the next call; the complete rows of one call form one update.
+int covahip_assoc_push_dnn_text(covahip_assoc *a, const char *text, size_t len) {
+    if (!a || (!text && len) || a->terminated) return COVAHIP_ERR_INVALID_ARG;
+    a->dnn_text.append(text, len);
+    std::vector<covahip_bbox> boxes;
+    size_t pos = 0;
+    while (true) {
+        const size_t nl = a->dnn_text.find('\n', pos);
+        if (nl == std::string::npos) break;
+        const std::string line = a->dnn_text.substr(pos, nl - pos);
+        pos = nl + 1;
+        if (line.empty()) continue;
+        std::vector<std::string> f;
+        size_t p = 0;
+        while (true) {
+            const size_t c = line.find(',', p);
+            f.push_back(line.substr(p, c == std::string::npos ? std::string::npos : c - p));
+            if (c == std::string::npos) break;
+            p = c + 1;
+        }
+        if (f.size() != 6 || f[5].empty()) return COVAHIP_ERR_BAD_DATA;
+        char *end = nullptr;
+        covahip_bbox b = bbox_new(std::strtof(f[1].c_str(), nullptr), std::strtof(f[2].c_str(), nullptr),
+                                  std::strtof(f[3].c_str(), nullptr), std::strtof(f[4].c_str(), nullptr));
+        b.timestamp = std::strtoull(f[0].c_str(), &end, 10);
+        if (*end) return COVAHIP_ERR_BAD_DATA;
+        const long long cls = std::strtoll(f[5].c_str(), &end, 10);
+        if (*end || cls < 0) return COVAHIP_ERR_BAD_DATA;   // dnn.rs:78: u32::try_from(i32)
+        b.class_id = (uint32_t)cls;
+        b.has_timestamp = b.has_class_id = 1;
+        boxes.push_back(b);
+    }
+    a->dnn_text.erase(0, pos);
+    return boxes.empty() ? COVAHIP_OK : a->update_dnn(boxes.data(), boxes.size());
+}
+
+int covahip_assoc_terminate(covahip_assoc *a) {
+    if (!a) return COVAHIP_ERR_INVALID_ARG;
+    a->terminate();
+    return COVAHIP_OK;
+}
+
+// CSV text of one of the four output files (0 track.csv, 1 dnn.csv, 2 assoc.csv, 3 stationary.csv) as written so far.
+size_t covahip_assoc_csv(covahip_assoc *a, int which, char *out, size_t cap, int *status) {
+    if (!a || which < 0 || which > 3) { if (status) *status = COVAHIP_ERR_INVALID_ARG; return 0; }
+    const std::string s = csv_rows(a->rows[which]);
+    if (status) *status = (out && s.size() <= cap) ? COVAHIP_OK : COVAHIP_ERR_OVERFLOW;
+    if (out && s.size() <= cap) std::memcpy(out, s.data(), s.size());
+    return s.size();
 }
 
 }  // extern "C"

@@ -468,3 +468,50 @@ class Cova:
     dropped = property(lambda s: s._counters()[0])
     decoded_dependency = property(lambda s: s._counters()[1])
     decoded_inference = property(lambda s: s._counters()[2])
+
+
+# ---------------------------------------------------------------------------------------- analysis-aggregator join
+class Associator:
+    """The association rules of CoVA's analysis-aggregator (assoc.rs:63-507) without its sockets: tracker frames
+    and DNN detections are pushed in arrival order, `csv(name)` returns the text of track / dnn / assoc /
+    stationary .csv.  Defaults as main.rs:32-39."""
+
+    FILES = {"track": 0, "dnn": 1, "assoc": 2, "stationary": 3}
+
+    def __init__(self, range_starts, moving_iou: float = 0.15, stationary_iou: float = 0.3, stationary_maxage: int = 120,
+                 scale_factor: float = 1.3):
+        self._lib = L.lib()
+        cfg = L.AssocCfg(moving_iou, stationary_iou, stationary_maxage, scale_factor)
+        rs = np.ascontiguousarray(range_starts, dtype=np.uint64)
+        h = C.c_void_p()
+        L.check(self._lib.covahip_assoc_new(C.byref(cfg), _ptr(rs), rs.shape[0], C.byref(h)), "assoc_new")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.covahip_assoc_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def push_track(self, range_start: int, oldest: int, boxes: np.ndarray):
+        b = np.ascontiguousarray(boxes, dtype=L.BBOX_DTYPE)
+        L.check(self._lib.covahip_assoc_push_track(self._h, range_start, oldest, _ptr(b), b.shape[0]), "assoc_push_track")
+
+    def push_track_frame(self, payload: bytes):
+        buf = np.frombuffer(payload, dtype=np.uint8)
+        L.check(self._lib.covahip_assoc_push_track_frame(self._h, _ptr(buf), buf.shape[0]), "assoc_push_track_frame")
+
+    def push_dnn(self, boxes: np.ndarray):
+        b = np.ascontiguousarray(boxes, dtype=L.BBOX_DTYPE)
+        L.check(self._lib.covahip_assoc_push_dnn(self._h, _ptr(b), b.shape[0]), "assoc_push_dnn")
+
+    def push_dnn_text(self, text: bytes):
+        L.check(self._lib.covahip_assoc_push_dnn_text(self._h, text, len(text)), "assoc_push_dnn_text")
+
+    def terminate(self):
+        L.check(self._lib.covahip_assoc_terminate(self._h), "assoc_terminate")
+
+    def csv(self, name: str) -> str:
+        which = self.FILES[name]
+        return _sized_call(lambda o, c, st: self._lib.covahip_assoc_csv(self._h, which, o, c, st), "assoc_csv").decode()

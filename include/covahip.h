@@ -189,6 +189,35 @@ size_t covahip_bbox_csv(const covahip_bbox *boxes, size_t n, int with_header, ch
 size_t covahip_tracks_export(uint64_t range_start, uint64_t oldest, const covahip_bbox *boxes, const uint32_t *track_lens,
                              size_t n_tracks, uint8_t *out, size_t cap, int *status);
 
+/* ------------------------------------------------ analysis-aggregator join
+ * Association of tracker output with DNN detections (cova-rs/analysis-aggregator/src/server/
+ * assoc.rs:63-507, track.rs:47-66, dnn.rs:57-86): what the aggregator
+ * does with the messages of its tracker and DNN connections, without the sockets.  Messages are
+ * pushed in arrival order; the four CSV files (track, dnn, assoc, stationary) are read back as text. */
+typedef struct covahip_assoc covahip_assoc;
+typedef struct covahip_assoc_cfg {   /* main.rs:32-39 */
+    float moving_iou;                /* 0.15 */
+    float stationary_iou;            /* 0.3  */
+    uint64_t stationary_maxage_s;    /* 120  */
+    float scale_factor;              /* 1.3  */
+} covahip_assoc_cfg;
+void covahip_assoc_default_cfg(covahip_assoc_cfg *cfg);
+/* range_starts: the range_start every tracker announces with its first frame (assoc.rs:473-489). */
+int covahip_assoc_new(const covahip_assoc_cfg *cfg, const uint64_t *range_starts, size_t n_trackers, covahip_assoc **out);
+void covahip_assoc_free(covahip_assoc *a);
+/* Recieved::Track: boxes already in pixels with re-based ids (assoc.rs:370-431). */
+int covahip_assoc_push_track(covahip_assoc *a, uint64_t range_start, uint64_t oldest, const covahip_bbox *boxes, size_t n);
+/* One length-delimited payload of covahip_tracks_export as track.rs:47-66 handles it: bincode Frame,
+ * scale_dim(16), track_id += range_start, then push_track. */
+int covahip_assoc_push_track_frame(covahip_assoc *a, const uint8_t *payload, size_t len);
+/* Recieved::Dnn (assoc.rs:296-367); boxes need timestamp and class_id. */
+int covahip_assoc_push_dnn(covahip_assoc *a, const covahip_bbox *boxes, size_t n);
+/* Detection rows "timestamp,left,top,width,height,class_id\n" as read from a DNN connection (dnn.rs:57-86). */
+int covahip_assoc_push_dnn_text(covahip_assoc *a, const char *text, size_t len);
+int covahip_assoc_terminate(covahip_assoc *a);   /* assoc.rs:434-467 */
+/* which: 0 track.csv, 1 dnn.csv, 2 assoc.csv, 3 stationary.csv; returns the size, copies if it fits. */
+size_t covahip_assoc_csv(covahip_assoc *a, int which, char *out, size_t cap, int *status);
+
 /* ------------------------------------------------- metapreprocess stacking
  * Host state of the `metapreprocess` element (cova-rs/gst-plugins/src/metapreprocess/
  * imp.rs:204-332): keeps the last timestep-1 inputs, emits one stacked frame every
