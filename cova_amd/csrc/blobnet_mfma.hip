@@ -386,6 +386,10 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
         const int y0 = 2 * ((band * p.Hp) / p.nbands);
         const int rows = 2 * (((band + 1) * p.Hp) / p.nbands) - y0;
         const int n2 = rows + 2;
+        // opaque per-item copy of the lane id: keeps hipcc from hoisting (and, at level 3, spilling) the
+        // lane-only index math out of the item loop -- see enc01_mfma
+        int ll = lane;
+        asm volatile("" : "+v"(ll));
         lds_barrier();
         // ---- stage the band with LDS-DMA: the tile is swept linearly in 16-byte chunks (64 per
         // wave-instruction); chunk -> (row, col, physical chunk) -> swizzled source chunk; halo
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
             const size_t tplane = (size_t)p.H * p.W * CIN * 2;   // bytes
             const uint8_t *fbase = reinterpret_cast<const uint8_t *>(p.in) + (size_t)b * BN_T * tplane;
             for (int s0 = wave * 64; s0 < nchunk; s0 += WGS) {
-                const int sidx = s0 + lane;
+                const int sidx = s0 + ll;
                 if (sidx < nchunk) {
                     const int r = fdiv(sidx, p.mRC), within = sidx - r * RC;
                     const int c = within / CPP, chp = within % CPP;
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
         // ---- compute
         const int nwin = (rows / 2) * p.Wp;
         const int ntiles = (nwin + 7) / 8;
-        const int m = lane & 31, kh = lane >> 5;
+        const int m = ll & 31, kh = ll >> 5;
         for (int tile = mgroup; tile < ntiles; tile += MG) {
             const int win = min(tile * 8 + (m >> 2), nwin - 1);
             const int wy = fdiv(win, p.mWp), wx = win - wy * p.Wp;
@@ -479,23 +483,23 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
 #pragma unroll
                     for (int t = 0; t < BN_T; t++) pooled[t] = pooled4[t][g];
                     tmix4(tm, pooled, o);
-                    _Float16 *sw = reinterpret_cast<_Float16 *>(scr + (2 * g + kh) * 64) + (lane & 31);
+                    _Float16 *sw = reinterpret_cast<_Float16 *>(scr + (2 * g + kh) * 64) + (ll & 31);
 #pragma unroll
                     for (int t = 0; t < BN_T; t++) sw[t * 256] = o[t];
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int owin = tile * 8 + ((lane >> 2) & 7);
+                const int owin = tile * 8 + ((ll >> 2) & 7);
                 if (owin < nwin) {
                     const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
                     const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
-                    const uint32_t eo = (uint32_t)((gy * p.Wo + gx) * COUT + ntile * 32 + 8 * (lane & 3));
+                    const uint32_t eo = (uint32_t)((gy * p.Wo + gx) * COUT + ntile * 32 + 8 * (ll & 3));
 #pragma unroll
                     for (int j = 0; j < 2; j++) {
-                        const int t = 2 * j + (lane >> 5);
+                        const int t = 2 * j + (ll >> 5);
                         if (t < p.To) {
-                            const uint4 v = *reinterpret_cast<const uint4 *>(scr + (j * 64 + lane) * 16);
+                            const uint4 v = *reinterpret_cast<const uint4 *>(scr + (j * 64 + ll) * 16);
                             *reinterpret_cast<uint4 *>(ob + t * tstride + eo) = v;
                         }
                     }
