@@ -12,6 +12,10 @@
 //     8-byte-per-lane coalesced loads; each work item then derives, for the 4 blocks
 //     under one packed byte, the foreground nibble and the four "prior neighbour"
 //     connections (left, up-left, up, up-right) with shifts/ands on 3x3 bytes.
+//   * Horizontal runs need no union at all: the "connected to my left neighbour" bits of a block
+//     row form a bit mask, and the first block of the run a block sits in is the highest zero of
+//     that mask at or below it (one clz).  Every block starts with the id of its run's first block
+//     as label, so only the vertical connections (up-left, up, up-right) go through the union-find.
 //   * Blocks are merged with a lock-free min-root union-find (atomicMin on LDS), then
 //     flattened.  The root of a component is therefore its SMALLEST block id, i.e. the
 //     first block of the component in block-raster order -- exactly the block at which
@@ -60,6 +64,7 @@ struct CcGeom {
     int H, W, BH, BW, NB;
     int RS;     // packed-row stride in bytes (1 pad byte left, >=1 right)
     int NXB;    // packed bytes per row = ceil(W/8)
+    int rowl_off;  // byte offset of the per-block-row "joined to the left" masks in LDS
 };
 
 __global__ __launch_bounds__(CC_THREADS) void bboxcc_kernel(const uint8_t *__restrict__ masks, CcGeom g,
@@ -80,10 +85,12 @@ __global__ __launch_bounds__(CC_THREADS) void bboxcc_kernel(const uint8_t *__res
     uint32_t *s_miny = s_maxx + NB;
     uint32_t *s_maxy = s_miny + NB;
     uint8_t *binfo = (uint8_t *)(s_maxy + NB);            // [NB] fg nibble | conn nibble << 4
+    uint32_t *rowL = (uint32_t *)(smem + g.rowl_off);     // [BH][4]: bit bx = block bx is joined to block bx-1 (BW <= 128)
     __shared__ uint32_t wave_tot[CC_THREADS / 64];
 
     // ---- phase 0: clear packed rows (pads must be zero)
     for (int i = tid; i < rb_bytes / 4; i += CC_THREADS) ((uint32_t *)rb)[i] = 0;
+    for (int i = tid; i < g.BH * 4; i += CC_THREADS) rowL[i] = 0;
     __syncthreads();
 
     // ---- phase 1: stream the mask in, 8 pixels per work item, and bit-pack it
@@ -124,6 +131,7 @@ __global__ __launch_bounds__(CC_THREADS) void bboxcc_kernel(const uint8_t *__res
         const uint32_t up = p0[0] | (p0[1] << 8) | (p0[2] << 16);
         const uint32_t ra = p1[0] | (p1[1] << 8) | (p1[2] << 16);
         const uint32_t rc = p2[0] | (p2[1] << 8) | (p2[2] << 16);
+        uint32_t lbits = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int bx = xc * 4 + j;
@@ -148,23 +156,49 @@ __global__ __launch_bounds__(CC_THREADS) void bboxcc_kernel(const uint8_t *__res
                 s_miny[blk] = 0x7FFFFFFF;
                 s_maxy[blk] = 0;
                 binfo[blk] = (uint8_t)(fg | (conn << 4));
+                lbits |= cL << j;
             }
         }
+        if (lbits) atomicOr(&rowL[by * 4 + (xc >> 3)], lbits << ((xc & 7) * 4));   // 4 blocks per unit, 8 units per word
     }
     __syncthreads();
 
-    // ---- phase 3: unions with the four prior neighbours
+    // ---- phase 2b: label of a foreground block = id of the first block of its horizontal run
     for (int blk = tid; blk < NB; blk += CC_THREADS) {
-        const uint32_t conn = binfo[blk] >> 4;
+        if (!(binfo[blk] & 0xF)) continue;
+        const int by = blk / BW, bx = blk - by * BW;
+        // highest zero of the "joined to the left" mask at or below bx (bit 0 of a row is always zero)
+        int w = bx >> 5;
+        uint32_t z = ~rowL[by * 4 + w] & (0xFFFFFFFFu >> (31 - (bx & 31)));
+        while (!z) z = ~rowL[by * 4 + --w];
+        lab[blk] = by * BW + w * 32 + (31 - __clz(z));
+    }
+    __syncthreads();
+
+    // ---- phase 3: unions with the three neighbours in the block row above.  A union is skipped when
+    // it is implied by one that is made anyway: by this block (the up neighbour is joined to the
+    // up-left / up-right one inside the upper row) or by the left neighbour of the same run (it
+    // reaches the same upper block, or one joined to it).
+    for (int blk = tid; blk < NB; blk += CC_THREADS) {
+        const uint32_t me = binfo[blk];
+        const uint32_t conn = me >> 5 << 1;
         if (!conn) continue;
-        if (conn & 1) uf_union(lab, blk, blk - 1);
-        if (conn & 4) uf_union(lab, blk, blk - BW);
-        if (conn & 2) uf_union(lab, blk, blk - BW - 1);
-        if (conn & 8) uf_union(lab, blk, blk - BW + 1);
+        const int by = blk / BW, bx = blk - by * BW;
+        const uint32_t *upL = rowL + (by - 1) * 4;                       // conn != 0 implies by >= 1
+        const bool up_j0 = (upL[bx >> 5] >> (bx & 31)) & 1;              // upper bx joined to upper bx-1
+        const bool up_j1 = bx + 1 < BW && ((upL[(bx + 1) >> 5] >> ((bx + 1) & 31)) & 1);   // upper bx+1 joined to upper bx
+        const uint32_t left = (me >> 4) & 1 ? binfo[blk - 1] >> 4 : 0;   // connections of the left block when it is in my run
+        const bool cUL = conn & 2, cU = conn & 4, cUR = conn & 8;
+        const bool lU = left & 4, lUR = left & 8;
+        if (cU && !(lUR || (lU && up_j0))) uf_union(lab, blk, blk - BW);
+        if (cUL && !(cU && up_j0) && !lU) uf_union(lab, blk, blk - BW - 1);
+        if (cUR && !(cU && up_j1)) uf_union(lab, blk, blk - BW + 1);
     }
     __syncthreads();
 
     // ---- phase 4+5: flatten and accumulate statistics on the root
+    // (one set of atomics per horizontal run instead of per block was measured: 25 % faster on
+    //  half-full masks, 10 % slower on sparse blobs because the run's first block walks it serially)
     for (int blk = tid; blk < NB; blk += CC_THREADS) {
         const uint32_t fg = binfo[blk] & 0xF;
         if (!fg) continue;
@@ -239,9 +273,11 @@ int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, in
     g.NXB = (w + 7) / 8;
     g.RS = g.NXB + 2;
     const size_t rb_bytes = (((size_t)(h + 3) * g.RS) + 15) & ~(size_t)15;
-    const size_t lds = rb_bytes + (size_t)g.NB * 4 * 6 + (((size_t)g.NB + 15) & ~(size_t)15);
+    const size_t rowl_off = rb_bytes + (size_t)g.NB * 4 * 6 + (((size_t)g.NB + 15) & ~(size_t)15);
+    const size_t lds = rowl_off + (size_t)g.BH * 16;
+    g.rowl_off = (int)rowl_off;
     // Shapes the kernel assumes (checked on the host before any launch).
-    if (lds + 64 > 160 * 1024) return COVAHIP_ERR_UNSUPPORTED;
+    if (lds + 64 > 160 * 1024 || g.BW > 128) return COVAHIP_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
