@@ -37,6 +37,7 @@ struct covahip_blobnet {
     size_t prepared_bytes = 0;
     struct Prepared *prep = nullptr;
     int impl = 1;  // 0 = naive direct kernels, 1 = MFMA kernels
+    int fuse_tail = 1;  // MFMA path, with bboxcc requested: last decoder block + bboxcc in one launch
     int fuse01 = 0;  // MFMA path: encoder levels 0 and 1 as one kernel (default off: measured slower)
     int overlap = 0;  // split a batch in two halves on two HIP streams (off by default: no gain measured at b=256)
     int64_t macs_per_frame = 0;
@@ -50,5 +51,11 @@ int blobnet_prepare_mfma(covahip_ctx *ctx, covahip_blobnet *m, const float *h_we
 void blobnet_release_mfma(covahip_ctx *ctx, covahip_blobnet *m);
 // frame0: index of the first workspace frame slot to use (two half-batches can be in flight on
 // two streams, each in its own slice of the activation workspace)
+// cc != nullptr: bboxcc is wanted on the mask; *cc_done tells whether the forward already ran it (fused tail)
+struct BnCcTail {
+    int area_thresh, max_boxes;
+    covahip_box *boxes;   // [batch of the whole call][max_boxes]; the forward offsets by frame0
+    int32_t *counts;
+};
 int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_stack, int batch, float *d_logits,
-                         uint8_t *d_mask, int frame0);
+                         uint8_t *d_mask, int frame0, const BnCcTail *cc = nullptr, bool *cc_done = nullptr);

@@ -90,14 +90,18 @@ static int filter_dev(covahip_ctx *ctx, const uint8_t *d_stack, int batch, float
         float *lg = d_logits ? d_logits + (size_t)f0 * hw : nullptr;
         uint8_t *mk = d_mask ? d_mask + (size_t)f0 * hw : nullptr;
         int rc;
+        bool cc_done = false;
         if (m->impl == 0) {
             if (f0 != 0) return COVAHIP_ERR_INVALID_ARG;
             rc = blobnet_forward_naive(ctx, m, st, n, lg, mk);
         } else {
-            rc = blobnet_forward_mfma(ctx, m, st, n, lg, mk, f0);
+            // the fused tail needs no mask buffer of its own; the separate bboxcc kernel does (pipelined or fallback)
+            const bool pipe_cc = ctx->pipeline_cc && ctx->stream2 && f0 == 0 && n == batch && !ctx->profile_all();
+            BnCcTail tail{area_thresh, max_boxes, d_boxes, d_counts};
+            rc = blobnet_forward_mfma(ctx, m, st, n, lg, mk, f0, (with_cc && !pipe_cc) ? &tail : nullptr, &cc_done);
         }
         if (rc) return rc;
-        if (with_cc) {
+        if (with_cc && !cc_done) {
             const bool pipe = ctx->pipeline_cc && m->impl == 1 && ctx->stream2 && f0 == 0 && n == batch &&
                               !ctx->profile_all();
             if (pipe) {

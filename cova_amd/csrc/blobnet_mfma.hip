@@ -28,6 +28,7 @@
 #include <cstring>
 #include <vector>
 
+#include "bboxcc_body.h"
 #include "blobnet.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -949,6 +950,120 @@ __global__ __launch_bounds__(((FINAL ? 1 : 4 * COUT / 32) > 4 ? 4 * COUT / 32 : 
     }
 }
 
+// ------------------------------------------------------------------ last decoder block + bboxcc fused
+// One 16-wave workgroup per frame: the last block runs band by band (double-buffered LDS-DMA of the
+// next band behind the tiles of the current one), its threshold output is assembled as the frame's
+// H x W mask bytes in LDS, and bboxcc (bboxcc_body.h) runs on that LDS image in the same launch: no
+// second kernel, no trip of the mask through HBM (it is still written out when the caller asks for
+// it).  bboxcc's LDS region reuses the two band buffers.
+struct Dec3ccArgs {
+    DecArgs d;                 // the last block's arguments (up, skip, logits, mask, weights, geometry, nbands)
+    ccbody::CcGeom g;
+    covahip_box *boxes;        // [B][max_boxes]
+    int32_t *counts;           // [B]
+    int area_thresh, max_boxes;
+    int tile_bytes;            // one band buffer; two of them at LDS offsets 0 and tile_bytes
+    int mfull_off, cc_off;     // LDS offsets of the frame's mask bytes and of bboxcc's region
+};
+
+__global__ __launch_bounds__(ccbody::CC_THREADS) void dec3cc_mfma(Dec3ccArgs q) {
+    constexpr int C1 = 16, C2 = 16, C = 32, NW = ccbody::CC_THREADS / 64;
+    constexpr int KC = C / 16, KSTEPS = 4 * KC, CPP = C / 8, PS = C * 2;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const DecArgs &p = q.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int TC = p.Wi + 2;
+    const int GW = p.Wi + 1, GH = p.Hi + 1;
+    const int kh = lane >> 5;
+    half8 wf[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++) wf[ks] = p.wfrag[ks * 64 + lane];
+    const float fbias = p.epi[0];
+    uint8_t *const mfull = smem + q.mfull_off;
+
+    for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+        auto stage = [&](int band, uint8_t *buf) {   // LDS-DMA of concat(up, skip[t=0]) rows u0-1 .. u1-1
+            const int u0 = band * GH / p.nbands, u1 = (band + 1) * GH / p.nbands;
+            const int RC = TC * CPP;
+            const int nchunk = (u1 - u0 + 1) * RC;
+            const __half *su = p.up + ((size_t)b) * p.Hi * p.Wi * C1;
+            const __half *ss = p.skip + ((size_t)b * p.Ts) * p.Hi * p.Wi * C2;
+            for (int s0 = wave * 64; s0 < nchunk; s0 += NW * 64) {
+                const int sidx = s0 + lane;
+                if (sidx < nchunk) {
+                    const int r = fdiv(sidx, p.mRC), within = sidx - r * RC;
+                    const int c = within / CPP, chp = within % CPP;
+                    const int cb = (chp ^ dec_swz<C>(c)) * 8;
+                    const int y = u0 - 1 + r, x = c - 1;
+                    const void *src = p.zero;
+                    if (y >= 0 && y < p.Hi && x >= 0 && x < p.Wi) {
+                        const size_t pix = (size_t)y * p.Wi + x;
+                        src = cb < C1 ? (const void *)(su + pix * C1 + cb) : (const void *)(ss + pix * C2 + (cb - C1));
+                    }
+                    glds16(src, buf + s0 * 16);
+                }
+            }
+        };
+        lds_barrier();   // the previous frame's bboxcc is done with the band buffers it reuses
+        stage(0, smem);
+        for (int band = 0; band < p.nbands; band++) {
+            uint8_t *const cur = smem + (band & 1) * q.tile_bytes;
+            wait_vmem();
+            lds_barrier();   // this band has landed; every wave is done with the other buffer
+            if (band + 1 < p.nbands) stage(band + 1, smem + ((band + 1) & 1) * q.tile_bytes);
+            const int u0 = band * GH / p.nbands, u1 = (band + 1) * GH / p.nbands;
+            const int npos = (u1 - u0) * GW;
+            const int ntiles = (npos + 31) / 32;
+            for (int tile = wave; tile < ntiles; tile += NW) {
+                const int qi = tile * 32 + (lane & 31);
+                const int qc = min(qi, npos - 1);
+                const int ul = fdiv(qc, p.mGW), v = qc - ul * GW;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int bb = 0; bb < 2; bb++) {
+                        const int yy = ul + 1 - a, xx = v + 1 - bb;
+                        const int pbase = (yy * TC + xx) * PS;
+                        const int s = dec_swz<C>(xx);
+#pragma unroll
+                        for (int kc = 0; kc < KC; kc++) {
+                            const half8 av = *reinterpret_cast<const half8 *>(cur + pbase + (((kc * 2 + kh) ^ s) * 16));
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[(a * 2 + bb) * KC + kc], av, acc, 0, 0, 0);
+                        }
+                    }
+                if (qi < npos && kh == 0) {   // rows 0..3 = the four output parities of position (u, v)
+                    const int u = u0 + ul;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int Y = 2 * u + (r >> 1) - p.cy, X = 2 * v + (r & 1) - p.cx;
+                        if (Y >= 0 && Y < p.Hd && X >= 0 && X < p.Wd) {
+                            const float l = acc[r] + fbias;
+                            if (p.logits) p.logits[((size_t)b * p.Hd + Y) * p.Wd + X] = l;
+                            mfull[Y * p.Wd + X] = l > 0.f ? 1 : 0;
+                        }
+                    }
+                }
+            }
+        }
+        lds_barrier();   // the frame's mask is complete; the band buffers are free
+        if (p.mask) {
+            uint8_t *dst = p.mask + (size_t)b * p.Hd * p.Wd;
+            const int nbytes = p.Hd * p.Wd;
+            if ((nbytes & 3) == 0 && (reinterpret_cast<uintptr_t>(p.mask) & 3) == 0) {
+                for (int i = tid; i < nbytes / 4; i += NW * 64)
+                    reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(mfull)[i];
+            } else {
+                for (int i = tid; i < nbytes; i += NW * 64) dst[i] = mfull[i];
+            }
+        }
+        ccbody::bboxcc_frame(mfull, smem + q.cc_off, q.g, q.area_thresh, q.boxes + (size_t)b * q.max_boxes, q.counts + b,
+                             q.max_boxes, tid);
+    }
+}
+
 // ------------------------------------------------------------------ host-side weight preparation
 // Epilogue constants of an encoder level (see pool4): BN folded into the weights when every scale is >= 0.
 void enc_epilogue(int cout, bool allpos, const float *bias, const float *gamma, const float *beta, const float *mean,
@@ -1149,7 +1264,8 @@ void blobnet_release_mfma(covahip_ctx *, covahip_blobnet *m) {
 }
 
 int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_stack, int batch, float *d_logits,
-                         uint8_t *d_mask, int frame0) {
+                         uint8_t *d_mask, int frame0, const BnCcTail *cc, bool *cc_done) {
+    if (cc_done) *cc_done = false;
     // workspace slices of this call
     __half *act[BN_LEVELS + 1] = {};
     __half *dact[BN_LEVELS] = {};
@@ -1352,6 +1468,43 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
             if (rc) return rc;
             ProfScope ps(ctx, "dec2_mfma");
             hipLaunchKernelGGL((dec_mfma<32, 32, 16, false>), dim3(grid), dim3(256), lds, ctx->stream, a);
+        } else if (cc && m->fuse_tail && [&]() -> bool {
+                       // last block + bboxcc in one launch when the frame's LDS plan fits: two band buffers (which
+                       // bboxcc's region reuses) + the frame's mask bytes
+                       Dec3ccArgs t;
+                       const size_t cc_bytes = ccbody::cc_plan(out.H, out.W, t.g);
+                       if (!cc_bytes) return false;
+                       const size_t mfull = ((size_t)out.H * out.W + 15) & ~(size_t)15;
+                       int best_nb = 0;
+                       long long best_cost = -1;
+                       for (int nb = 1; nb <= GH; nb++) {
+                           const size_t tb = (((size_t)((GH + nb - 1) / nb) + 1) * row_bytes + 15) & ~(size_t)15;
+                           const size_t nbuf = nb == 1 ? 1 : 2;   // the whole frame in one buffer when it fits
+                           if (std::max(nbuf * tb, cc_bytes) + mfull > 160 * 1024 - 512) continue;
+                           long long rounds = 0;   // tiles of 32 positions over 16 waves, band by band
+                           for (int k = 0; k < nb; k++) {
+                               const int nu = (k + 1) * GH / nb - k * GH / nb;
+                               rounds += ((nu * (in.W + 1) + 31) / 32 + 15) / 16;
+                           }
+                           const long long cost = rounds * 8 + nb;   // a band costs a barrier + DMA issue on top of its tiles
+                           if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_nb = nb; }
+                       }
+                       if (!best_nb) return false;
+                       const size_t tb = (((size_t)((GH + best_nb - 1) / best_nb) + 1) * row_bytes + 15) & ~(size_t)15;
+                       t.d = a;
+                       t.d.nbands = best_nb; t.d.mNb = magic(best_nb);
+                       t.boxes = cc->boxes + (size_t)frame0 * cc->max_boxes; t.counts = cc->counts + frame0;
+                       t.area_thresh = cc->area_thresh; t.max_boxes = cc->max_boxes;
+                       t.tile_bytes = (int)tb; t.cc_off = 0;
+                       t.mfull_off = (int)std::max((best_nb == 1 ? 1 : 2) * tb, cc_bytes);
+                       const size_t tl = (size_t)t.mfull_off + mfull;
+                       if (set_lds(ctx, dec3cc_mfma, tl)) return false;
+                       if (ctx->cc_pending && hipStreamWaitEvent(ctx->stream, ctx->ev_cc_done, 0) != hipSuccess) return false;
+                       ProfScope ps(ctx, "dec3_bboxcc_fused");
+                       hipLaunchKernelGGL(dec3cc_mfma, dim3(std::min(batch, 2 * num_cu)), dim3(ccbody::CC_THREADS), tl, ctx->stream, t);
+                       return true;
+                   }()) {
+            if (cc_done) *cc_done = true;
         } else {
             rc = set_lds(ctx, dec_mfma<16, 16, 16, true>, lds);
             if (rc) return rc;

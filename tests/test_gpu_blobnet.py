@@ -156,3 +156,23 @@ def test_fused_levels_match_per_level_kernels_bitwise(ctx, weights_flat):
     l1, m1 = net.infer(stack)
     np.testing.assert_array_equal(l0, l1)
     np.testing.assert_array_equal(m0, m1)
+
+
+@pytest.mark.parametrize("hw", [(68, 120), (67, 120), (45, 80), (35, 60)])
+@pytest.mark.parametrize("want_mask", [False, True])
+def test_fused_tail_matches_separate_kernels(ctx, weights_flat, hw, want_mask):
+    """covahip_filter_forward runs the last decoder block and bboxcc in ONE launch (mask in LDS); its boxes, counts
+    and (when asked for) mask equal covahip_blobnet_forward followed by covahip_bboxcc on the mask."""
+    from cova_amd.elements import BboxCc
+    h, w = hw
+    stack = synth.stacked_batch(5, h, w, seed=17, streams=2)
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=8)
+    boxes, counts, mask = net.filter(stack, cc_threshold=2, max_boxes=2048, want_mask=want_mask)
+    _, mask_sep = net.infer(stack)
+    boxes_sep, counts_sep = BboxCc(ctx, 2, 2048).regionprops(mask_sep)
+    np.testing.assert_array_equal(counts, counts_sep)
+    for i in range(len(counts)):
+        np.testing.assert_array_equal(boxes[i, :counts[i]], boxes_sep[i, :counts[i]])
+    if want_mask:
+        np.testing.assert_array_equal(mask, mask_sep)
+    assert counts.sum() > 0
