@@ -71,7 +71,8 @@ def kernel_bytes_per_frame():
 
 PMC_KERNEL_KEYS = {"enc0_mfma": "enc0_mfma", "enc1_mfma": "enc_mfma<16, 32", "enc2_mfma": "enc_mfma<32, 64",
                    "enc3_mfma": "enc_mfma<64, 128", "dec0_mfma": "dec_mfma<0, 128", "dec1_mfma": "dec_mfma<64, 64",
-                   "dec2_mfma": "dec_mfma<32, 32", "dec3_final_mfma": "dec_mfma<16, 16", "bboxcc_kernel": "bboxcc_kernel"}
+                   "dec2_mfma": "dec_mfma<32, 32", "dec3_final_mfma": "dec_mfma<16, 16", "dec3_bboxcc_fused": "dec3cc_mfma",
+                   "bboxcc_kernel": "bboxcc_kernel"}
 
 
 def committed_traffic(kernel):
