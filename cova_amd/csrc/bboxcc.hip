@@ -24,7 +24,10 @@
 //     == OpenCV label order.
 //   * Area / min-max extents are accumulated per root with LDS atomics, and surviving
 //     roots are compacted in ascending id order with a workgroup prefix sum.
+#include <algorithm>
 #include <cstdint>
+#include <mutex>
+#include <vector>
 
 #include "bboxcc_body.h"
 #include "internal.h"
@@ -50,12 +53,14 @@ int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, in
     CcGeom g;
     const size_t lds = cc_plan(h, w, g);   // shapes the kernel assumes, checked on the host before any launch
     if (!lds) return COVAHIP_ERR_UNSUPPORTED;
-    if (lds > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
+    if (lds > 64 * 1024) {   // the attribute is per device and sticky: set it once per device
+        static std::mutex mu;
+        static std::vector<int> opened;
+        std::lock_guard<std::mutex> lock(mu);
+        if (std::find(opened.begin(), opened.end(), ctx->device) == opened.end()) {
             COVAHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bboxcc_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-            attr_set = true;
+            opened.push_back(ctx->device);
         }
     }
     ProfScope ps(ctx, "bboxcc_kernel");

@@ -26,6 +26,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "bboxcc_body.h"
@@ -1240,10 +1242,12 @@ long long model_dec(int C, int Wi, int nu, const Swz &w) {
                 }
     return tot;
 }
+std::mutex g_swz_mutex;
 // enc = true: (C = cin, W, Wp, rows = rb); enc = false: (C, W = Wi, rows = nu).  Results are cached per key.
 Swz choose_swz(bool enc, int C, int W, int Wp, int rows) {
     struct Key { bool enc; int C, W, Wp, rows; Swz s; };
     static std::vector<Key> cache;
+    std::lock_guard<std::mutex> lock(g_swz_mutex);
     for (auto &k : cache)
         if (k.enc == enc && k.C == C && k.W == W && k.Wp == Wp && k.rows == rows) return k.s;
     const int cpp = C / 8, TC = W + 2;
@@ -1268,11 +1272,20 @@ Swz choose_swz(bool enc, int C, int W, int Wp, int rows) {
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Raises a kernel's dynamic-LDS limit once per (device, kernel): the attribute is sticky, so every kernel
+// is opened up to the 160 KB a CU has (minus the 256 B the runtime keeps) the first time it needs more
+// than the default 64 KB.
+std::mutex g_host_mutex;   // guards the cache below
 template <typename K>
 int set_lds(covahip_ctx *ctx, K kernel, size_t lds) {
-    if (lds > 64 * 1024)
-        COVAHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds <= 64 * 1024) return COVAHIP_OK;
+    static std::vector<std::pair<int, const void *>> opened;
+    const void *fn = reinterpret_cast<const void *>(kernel);
+    std::lock_guard<std::mutex> lock(g_host_mutex);
+    for (auto &o : opened)
+        if (o.first == ctx->device && o.second == fn) return COVAHIP_OK;
+    COVAHIP_CHECK_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    opened.emplace_back(ctx->device, fn);
     return COVAHIP_OK;
 }
 
