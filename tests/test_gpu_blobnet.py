@@ -176,3 +176,21 @@ def test_fused_tail_matches_separate_kernels(ctx, weights_flat, hw, want_mask):
     if want_mask:
         np.testing.assert_array_equal(mask, mask_sep)
     assert counts.sum() > 0
+
+
+def test_batch_size_sequence_on_one_context(ctx, weights_flat):
+    """The band planners, swizzle choice and item order depend on the batch size; one model must serve any
+    sequence of batch sizes with identical per-frame results (frames are independent)."""
+    h, w = 68, 120
+    stack = synth.stacked_batch(40, h, w, seed=23, streams=4)
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=64)
+    ref_l, ref_m = net.infer(stack)
+    ref_boxes, ref_counts, _ = net.filter(stack, cc_threshold=1, max_boxes=2048)
+    for n in (1, 3, 17, 40, 2, 33, 8):
+        l, m = net.infer(stack[:n])
+        np.testing.assert_array_equal(l, ref_l[:n])
+        np.testing.assert_array_equal(m, ref_m[:n])
+        boxes, counts, _ = net.filter(stack[:n], cc_threshold=1, max_boxes=2048)
+        np.testing.assert_array_equal(counts, ref_counts[:n])
+        for i in range(n):
+            np.testing.assert_array_equal(boxes[i, :counts[i]], ref_boxes[i, :counts[i]])
