@@ -74,6 +74,31 @@ static int run_harness(const char *launch, const char *srccaps, const char *in_p
     return 0;
 }
 
+/* ---- sink elements (bboxsink, tfrecordsink): push 'B' records (flags bit 0 = DELTA_UNIT), EOS, tear down ---- */
+static int run_sink(const char *launch, const char *srccaps, const char *in_path) {
+    GstElement *e = gst_parse_launch(launch, NULL);
+    GstHarness *h = e ? gst_harness_new_with_element(e, "sink", NULL) : NULL;
+    FILE *fi = fopen(in_path, "rb");
+    rec_t r;
+    int pushed = 0;
+    if (!h || !fi) { fprintf(stderr, "setup failed\n"); return 2; }
+    gst_harness_set_src_caps_str(h, srccaps);
+    while (read_rec(fi, &r)) {
+        if (r.kind == 'B') {
+            GstFlowReturn fr = gst_harness_push(h, buffer_from(&r));
+            if (fr != GST_FLOW_OK) { fprintf(stderr, "push failed: %s\n", gst_flow_get_name(fr)); return 3; }
+            pushed++;
+        }
+        free(r.data);
+    }
+    gst_harness_push_event(h, gst_event_new_eos());
+    printf("{\"pushed\": %d}\n", pushed);
+    fclose(fi);
+    gst_harness_teardown(h);
+    gst_object_unref(e);
+    return 0;
+}
+
 /* ---- cova: two sink pads driven by hand ---- */
 static FILE *cova_out;
 static GstFlowReturn cova_chain_list(GstPad *pad, GstObject *parent, GstBufferList *list) {
@@ -147,6 +172,7 @@ int main(int argc, char **argv) {
     gst_init(&argc, &argv);
     if (argc >= 6 && !strcmp(argv[1], "harness")) return run_harness(argv[2], argv[3], argv[4], argv[5]);
     if (argc >= 5 && !strcmp(argv[1], "cova")) return run_cova(argv[2], argv[3], argv[4]);
-    fprintf(stderr, "usage: %s harness '<launch line>' '<src caps>' in.rec out.rec | cova '<props>' in.rec out.rec\n", argv[0]);
+    if (argc >= 5 && !strcmp(argv[1], "sink")) return run_sink(argv[2], argv[3], argv[4]);
+    fprintf(stderr, "usage: %s harness '<launch line>' '<src caps>' in.rec out.rec | cova '<props>' in.rec out.rec | sink '<launch line>' '<src caps>' in.rec\n", argv[0]);
     return 1;
 }

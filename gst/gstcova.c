@@ -9,11 +9,15 @@
  *   bboxcc          <- cova-rs/gst-plugins/src/bboxcc/imp.rs           (BaseTransform, AlwaysInPlace)
  *   sorttracker     <- cova-rs/gst-plugins/src/sorttracker/imp.rs      (BaseTransform, NeverInPlace)
  *   cova            <- cova-rs/gst-plugins/src/cova/imp.rs             (Element, 2 sink pads + src)
+ *   bboxsink        <- cova-rs/gst-plugins/src/bboxsink/imp.rs         (BaseSink: bincode boxes -> CSV file)
+ *   tfrecordsink    <- cova-rs/gst-plugins/src/tfrecordsink/imp.rs     (BaseSink: RGBA metadata frames + ground
+ *                      truth file -> TFRecord file of tf.train.Example, one per frame or per GoP)
  *
  * The reference elements are Rust (gstreamer-rs); Rust is not available in this build image, so
  * the elements are written in C against the same GStreamer base classes.  All arithmetic and all
  * stream state live behind covahip_* calls; nothing is computed here.
  */
+#include <gst/base/gstbasesink.h>
 #include <gst/base/gstbasetransform.h>
 #include <gst/gst.h>
 #include <gst/video/video.h>
@@ -735,6 +739,230 @@ static void gst_cova_class_init(GstCovaClass *k) {
     gst_element_class_add_pad_template(e, gst_pad_template_new("sink_enc", GST_PAD_SINK, GST_PAD_ALWAYS, gst_caps_new_any()));
 }
 
+/* ===================================================================== bboxsink */
+typedef struct {
+    GstBaseSink parent;
+    gchar *location;
+    FILE *f;
+    gboolean header_done;
+    covahip_bbox *boxes;
+} GstBboxSink;
+typedef struct { GstBaseSinkClass parent_class; } GstBboxSinkClass;
+G_DEFINE_TYPE(GstBboxSink, gst_bboxsink, GST_TYPE_BASE_SINK)
+enum { BS_PROP_0, BS_PROP_LOCATION };
+
+static void bs_set_property(GObject *o, guint id, const GValue *v, GParamSpec *ps) {
+    GstBboxSink *s = (GstBboxSink *)o;
+    if (id == BS_PROP_LOCATION) {
+        if (s->f) { g_warning("Changing the `location` property on a started `bboxsink` is not supported"); return; }   /* imp.rs:39-46 */
+        g_free(s->location);
+        s->location = g_value_dup_string(v);
+    } else G_OBJECT_WARN_INVALID_PROPERTY_ID(o, id, ps);
+}
+static void bs_get_property(GObject *o, guint id, GValue *v, GParamSpec *ps) {
+    GstBboxSink *s = (GstBboxSink *)o;
+    if (id == BS_PROP_LOCATION) g_value_set_string(v, s->location);
+    else G_OBJECT_WARN_INVALID_PROPERTY_ID(o, id, ps);
+}
+static gboolean bs_start(GstBaseSink *bs) {   /* imp.rs:199-233 */
+    GstBboxSink *s = (GstBboxSink *)bs;
+    if (!s->location) { GST_ELEMENT_ERROR(s, RESOURCE, SETTINGS, ("File location is not defined"), (NULL)); return FALSE; }
+    s->f = fopen(s->location, "wb");
+    if (!s->f) { GST_ELEMENT_ERROR(s, RESOURCE, OPEN_WRITE, ("Could not open file %s for writing", s->location), (NULL)); return FALSE; }
+    setvbuf(s->f, NULL, _IOFBF, 2 * 1024 * 1024);
+    s->header_done = FALSE;
+    return TRUE;
+}
+static gboolean bs_stop(GstBaseSink *bs) {
+    GstBboxSink *s = (GstBboxSink *)bs;
+    if (s->f) { fclose(s->f); s->f = NULL; }
+    return TRUE;
+}
+static GstFlowReturn bs_render(GstBaseSink *bs, GstBuffer *buf) {   /* imp.rs:252-270 */
+    GstBboxSink *s = (GstBboxSink *)bs;
+    GstMapInfo m;
+    size_t n = 0;
+    if (!gst_buffer_map(buf, &m, GST_MAP_READ)) return GST_FLOW_ERROR;
+    int rc = covahip_bbox_deserialize_vec(m.data, m.size, s->boxes, MAX_BOXES, &n);
+    gst_buffer_unmap(buf, &m);
+    if (rc != COVAHIP_OK) { GST_ELEMENT_ERROR(s, STREAM, DECODE, ("bad bbox buffer: %s", covahip_strerror(rc)), (NULL)); return GST_FLOW_ERROR; }
+    if (n == 0) return GST_FLOW_OK;   /* csv::Writer emits the header with the first record */
+    int st = 0;
+    const size_t need = covahip_bbox_csv(s->boxes, n, !s->header_done, NULL, 0, NULL);
+    char *text = g_malloc(need);
+    covahip_bbox_csv(s->boxes, n, !s->header_done, text, need, &st);
+    const gboolean ok = st == COVAHIP_OK && fwrite(text, 1, need, s->f) == need;
+    g_free(text);
+    s->header_done = TRUE;
+    return ok ? GST_FLOW_OK : GST_FLOW_ERROR;
+}
+static void bs_finalize(GObject *o) {
+    GstBboxSink *s = (GstBboxSink *)o;
+    g_free(s->location);
+    g_free(s->boxes);
+    G_OBJECT_CLASS(gst_bboxsink_parent_class)->finalize(o);
+}
+static void gst_bboxsink_init(GstBboxSink *s) { s->boxes = g_new0(covahip_bbox, MAX_BOXES); gst_base_sink_set_sync(GST_BASE_SINK(s), FALSE); }
+static void gst_bboxsink_class_init(GstBboxSinkClass *k) {
+    GObjectClass *g = G_OBJECT_CLASS(k);
+    GstElementClass *e = GST_ELEMENT_CLASS(k);
+    GstBaseSinkClass *b = GST_BASE_SINK_CLASS(k);
+    g->set_property = bs_set_property;
+    g->get_property = bs_get_property;
+    g->finalize = bs_finalize;
+    g_object_class_install_property(g, BS_PROP_LOCATION,
+        g_param_spec_string("location", "File Location", "Location of the file to write", NULL, G_PARAM_READWRITE));
+    gst_element_class_set_static_metadata(e, "Bounding box sink", "Sink/Video", "Writes bounding boxes as CSV (covahip)", "covahip");
+    gst_element_class_add_pad_template(e, gst_pad_template_new("sink", GST_PAD_SINK, GST_PAD_ALWAYS, gst_caps_from_string(BBOX_CAPS)));
+    b->start = bs_start;
+    b->stop = bs_stop;
+    b->render = bs_render;
+}
+
+/* ===================================================================== tfrecordsink */
+typedef struct {
+    GstBaseSink parent;
+    gchar *location, *gt;
+    guint gop;               /* 0: one Example per frame; else frames are stacked until the next key frame */
+    FILE *f, *fgt;
+    gint width, height;
+    guint8 *frames, *gts;    /* the open Example: batch_count frames of w*h*4 / w*h bytes */
+    guint batch_count, cap_frames;
+    GMutex lock;
+} GstTfRecordSink;
+typedef struct { GstBaseSinkClass parent_class; } GstTfRecordSinkClass;
+G_DEFINE_TYPE(GstTfRecordSink, gst_tfrecordsink, GST_TYPE_BASE_SINK)
+enum { TF_PROP_0, TF_PROP_LOCATION, TF_PROP_GT, TF_PROP_GOP };
+
+static void tf_set_property(GObject *o, guint id, const GValue *v, GParamSpec *ps) {
+    GstTfRecordSink *s = (GstTfRecordSink *)o;
+    g_mutex_lock(&s->lock);
+    switch (id) {
+    case TF_PROP_LOCATION:
+        if (s->f) g_warning("Changing the `location` property on a started `tfrecordsink` is not supported");   /* imp.rs:207-214 */
+        else { g_free(s->location); s->location = g_value_dup_string(v); }
+        break;
+    case TF_PROP_GT:
+        if (s->f) g_warning("Changing the `gt` property on a started `tfrecordsink` is not supported");
+        else { g_free(s->gt); s->gt = g_value_dup_string(v); }
+        break;
+    case TF_PROP_GOP: s->gop = g_value_get_uint(v); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID(o, id, ps);
+    }
+    g_mutex_unlock(&s->lock);
+}
+static void tf_get_property(GObject *o, guint id, GValue *v, GParamSpec *ps) {
+    GstTfRecordSink *s = (GstTfRecordSink *)o;
+    switch (id) {
+    case TF_PROP_LOCATION: g_value_set_string(v, s->location); break;
+    case TF_PROP_GT: g_value_set_string(v, s->gt); break;
+    case TF_PROP_GOP: g_value_set_uint(v, s->gop); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID(o, id, ps);
+    }
+}
+static gboolean tf_set_caps(GstBaseSink *bs, GstCaps *caps) {   /* imp.rs:439-447 */
+    GstTfRecordSink *s = (GstTfRecordSink *)bs;
+    GstVideoInfo vi;
+    if (!gst_video_info_from_caps(&vi, caps)) return FALSE;
+    s->width = GST_VIDEO_INFO_WIDTH(&vi);
+    s->height = GST_VIDEO_INFO_HEIGHT(&vi);
+    return TRUE;
+}
+static gboolean tf_start(GstBaseSink *bs) {   /* imp.rs:449-512 */
+    GstTfRecordSink *s = (GstTfRecordSink *)bs;
+    if (!s->location) { GST_ELEMENT_ERROR(s, RESOURCE, SETTINGS, ("File location is not defined"), (NULL)); return FALSE; }
+    if (!s->gt) { GST_ELEMENT_ERROR(s, RESOURCE, SETTINGS, ("Ground truth file is not defined"), (NULL)); return FALSE; }
+    s->f = fopen(s->location, "wb");
+    if (!s->f) { GST_ELEMENT_ERROR(s, RESOURCE, OPEN_WRITE, ("Could not open file %s for writing", s->location), (NULL)); return FALSE; }
+    setvbuf(s->f, NULL, _IOFBF, 2000000);
+    s->fgt = fopen(s->gt, "rb");
+    if (!s->fgt) {
+        GST_ELEMENT_ERROR(s, RESOURCE, OPEN_READ, ("Could not open ground truth file %s", s->gt), (NULL));
+        fclose(s->f); s->f = NULL;
+        return FALSE;
+    }
+    s->batch_count = 0;
+    return TRUE;
+}
+static gboolean tf_stop(GstBaseSink *bs) {   /* imp.rs:514-532: flush only -- an open, partly filled GoP is not written */
+    GstTfRecordSink *s = (GstTfRecordSink *)bs;
+    if (s->f) { fclose(s->f); s->f = NULL; }
+    if (s->fgt) { fclose(s->fgt); s->fgt = NULL; }
+    s->batch_count = 0;
+    return TRUE;
+}
+static gboolean tf_write(GstTfRecordSink *s, guint gop) {   /* imp.rs:137-178 */
+    int st = 0;
+    const int pad = (int)gop;
+    const size_t need = covahip_tfrecord_example(s->frames, s->gts, (int)s->batch_count, pad, s->width, s->height, NULL, 0, NULL);
+    guint8 *rec = g_malloc(need);
+    covahip_tfrecord_example(s->frames, s->gts, (int)s->batch_count, pad, s->width, s->height, rec, need, &st);
+    const gboolean ok = st == COVAHIP_OK && fwrite(rec, 1, need, s->f) == need;
+    g_free(rec);
+    s->batch_count = 0;
+    return ok;
+}
+static GstFlowReturn tf_render(GstBaseSink *bs, GstBuffer *buf) {   /* imp.rs:534-606 */
+    GstTfRecordSink *s = (GstTfRecordSink *)bs;
+    g_mutex_lock(&s->lock);
+    const guint gop = s->gop;
+    g_mutex_unlock(&s->lock);
+    const size_t hw = (size_t)s->width * s->height;
+    /* GoP stacking: a key frame closes the previous Example */
+    if (gop != 0 && !GST_BUFFER_FLAG_IS_SET(buf, GST_BUFFER_FLAG_DELTA_UNIT) && s->batch_count != 0)
+        if (!tf_write(s, gop)) { GST_ELEMENT_ERROR(s, CORE, FAILED, ("Failed to write TFRecord"), (NULL)); return GST_FLOW_ERROR; }
+    if (gop != 0 && s->batch_count >= gop) {   /* the reference underflows `gop - batch_count` here */
+        GST_ELEMENT_ERROR(s, CORE, FAILED, ("more than `gop` frames without a key frame"), (NULL));
+        return GST_FLOW_ERROR;
+    }
+    if (s->batch_count + 1 > s->cap_frames) {
+        s->cap_frames = s->cap_frames ? 2 * s->cap_frames : 8;
+        s->frames = g_realloc(s->frames, (gsize)s->cap_frames * hw * 4);
+        s->gts = g_realloc(s->gts, (gsize)s->cap_frames * hw);
+    }
+    GstMapInfo m;
+    if (!gst_buffer_map(buf, &m, GST_MAP_READ)) return GST_FLOW_ERROR;
+    if (m.size < hw * 4) { gst_buffer_unmap(buf, &m); GST_ELEMENT_ERROR(s, CORE, FAILED, ("Failed to map input buffer readable"), (NULL)); return GST_FLOW_ERROR; }
+    memcpy(s->frames + (gsize)s->batch_count * hw * 4, m.data, hw * 4);   /* RGBA rows are tightly packed (stride = 4 * width) */
+    gst_buffer_unmap(buf, &m);
+    if (fread(s->gts + (gsize)s->batch_count * hw, 1, hw, s->fgt) != hw) {
+        GST_ELEMENT_ERROR(s, RESOURCE, READ, ("Could not read file from ground truth file"), (NULL));
+        return GST_FLOW_ERROR;
+    }
+    s->batch_count++;
+    if (gop == 0 && !tf_write(s, 0)) { GST_ELEMENT_ERROR(s, CORE, FAILED, ("Failed to write TFRecord"), (NULL)); return GST_FLOW_ERROR; }
+    return GST_FLOW_OK;
+}
+static void tf_finalize(GObject *o) {
+    GstTfRecordSink *s = (GstTfRecordSink *)o;
+    g_free(s->location); g_free(s->gt); g_free(s->frames); g_free(s->gts);
+    g_mutex_clear(&s->lock);
+    G_OBJECT_CLASS(gst_tfrecordsink_parent_class)->finalize(o);
+}
+static void gst_tfrecordsink_init(GstTfRecordSink *s) { g_mutex_init(&s->lock); gst_base_sink_set_sync(GST_BASE_SINK(s), FALSE); }
+static void gst_tfrecordsink_class_init(GstTfRecordSinkClass *k) {
+    GObjectClass *g = G_OBJECT_CLASS(k);
+    GstElementClass *e = GST_ELEMENT_CLASS(k);
+    GstBaseSinkClass *b = GST_BASE_SINK_CLASS(k);
+    g->set_property = tf_set_property;
+    g->get_property = tf_get_property;
+    g->finalize = tf_finalize;
+    g_object_class_install_property(g, TF_PROP_LOCATION,
+        g_param_spec_string("location", "File Location", "Location of the file to write", NULL, G_PARAM_READWRITE));
+    g_object_class_install_property(g, TF_PROP_GT,
+        g_param_spec_string("gt", "Ground truth location", "Location of the ground truth file to read", NULL, G_PARAM_READWRITE));
+    g_object_class_install_property(g, TF_PROP_GOP,
+        g_param_spec_uint("gop", "GoP", "Number of frames to stack per Example (0: one Example per frame)", 0, G_MAXUINT, 0,
+                          G_PARAM_READWRITE | GST_PARAM_MUTABLE_PLAYING));
+    gst_element_class_set_static_metadata(e, "TFRecord Sink", "Sink/Video", "Pack metadatas extracted from avdec into TFRecord (covahip)", "covahip");
+    gst_element_class_add_pad_template(e, gst_pad_template_new("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
+        gst_caps_from_string("video/x-raw, format=(string)RGBA, width=(int)[0,2147483647], height=(int)[0,2147483647]")));
+    b->set_caps = tf_set_caps;
+    b->start = tf_start;
+    b->stop = tf_stop;
+    b->render = tf_render;
+}
+
 /* ===================================================================== plugin */
 static gboolean plugin_init(GstPlugin *plugin) {
     GST_DEBUG_CATEGORY_INIT(cova_debug, "cova", 0, "CoVA compressed-domain elements on covahip");
@@ -743,7 +971,9 @@ static gboolean plugin_init(GstPlugin *plugin) {
            gst_element_register(plugin, "blobnetinfer", GST_RANK_NONE, gst_blobnetinfer_get_type()) &&
            gst_element_register(plugin, "bboxcc", GST_RANK_NONE, gst_bboxcc_get_type()) &&
            gst_element_register(plugin, "sorttracker", GST_RANK_NONE, gst_sorttracker_get_type()) &&
-           gst_element_register(plugin, "cova", GST_RANK_NONE, gst_cova_get_type());
+           gst_element_register(plugin, "cova", GST_RANK_NONE, gst_cova_get_type()) &&
+           gst_element_register(plugin, "bboxsink", GST_RANK_NONE, gst_bboxsink_get_type()) &&
+           gst_element_register(plugin, "tfrecordsink", GST_RANK_NONE, gst_tfrecordsink_get_type());
 }
 #define PACKAGE "covahip"
 GST_PLUGIN_DEFINE(GST_VERSION_MAJOR, GST_VERSION_MINOR, cova, "CoVA compressed-domain filter elements (MI355X / covahip)",

@@ -66,7 +66,8 @@ def test_inspect_lists_reference_elements_and_properties(tmp_path):
             "sorttracker": ["iou-threshold", "maxage", "minhits"],
             "cova": ["sort-iou", "sort-maxage", "sort-minhits", "port", "infer-i", "debug", "alpha", "beta", "dropped",
                      "decoded-dependency", "decoded-inference"],
-            "blobnetinfer": ["model-weights-file", "gpu-id"]}
+            "blobnetinfer": ["model-weights-file", "gpu-id"], "bboxsink": ["location"],
+            "tfrecordsink": ["location", "gt", "gop"]}
     for el, props in want.items():
         r = subprocess.run([insp, el], env=_env(tmp_path), capture_output=True, text=True, timeout=60)
         assert r.returncode == 0, r.stdout + r.stderr
@@ -187,3 +188,54 @@ def test_blobnet_bboxcc_pipeline(tmp_path, weights_flat):
         exp = E.serialize_vec(E.boxes_to_bbox(boxes[i, :counts[i]]))
         assert outs[i][3] == exp and outs[i][1] == i * CLK
     ctx.close()
+
+
+def test_bboxsink_element(tmp_path):
+    """bboxsink (bboxsink/imp.rs:199-270): bincode Vec<Bbox> buffers -> one CSV file, header with the first record."""
+    frames = [_bb([(1.5, 2.0, 3.0, 4.0), (10.0, 20.0, 5.0, 6.0)]), _bb([]), _bb([(0.25, 0.5, 100000.0, 2.0)])]
+    frames[0]["track_id"], frames[0]["has_track_id"] = [7, 8], 1
+    frames[0]["timestamp"], frames[0]["has_timestamp"] = 33333333, 1
+    _write(tmp_path / "in.rec", [("B", i * CLK, 0, E.serialize_vec(f)) for i, f in enumerate(frames)])
+    out = tmp_path / "boxes.csv"
+    info = _run(["sink", f"bboxsink location={out}", "bbox,width=120,height=68", str(tmp_path / "in.rec")], tmp_path)
+    assert info["pushed"] == 3
+    exp = E.bbox_csv(frames[0], with_header=True) + E.bbox_csv(frames[2], with_header=False)
+    assert out.read_text() == exp
+    assert exp.splitlines()[1] == "1.5,2.0,3.0,4.0,12.0,7,33333333,,"
+
+
+@pytest.mark.parametrize("gop", [0, 3])
+def test_tfrecordsink_element(tmp_path, gop):
+    """tfrecordsink (tfrecordsink/imp.rs:69-198,534-606): one Example per frame, or per GoP (closed by the next key
+    frame, zero filled to `gop`; an open GoP at EOS is not written)."""
+    from tests.test_host_formats import _parse_example, _masked
+    w, h, n = 20, 15, 8
+    rng = np.random.default_rng(gop)
+    frames = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)
+    gt = rng.integers(0, 2, (n, h * w), dtype=np.uint8)
+    (tmp_path / "gt.bin").write_bytes(gt.tobytes())
+    key = [0, 2, 5]                                                     # key frames (not DELTA_UNIT)
+    _write(tmp_path / "in.rec", [("B", i * CLK, 0 if i in key else 1, frames[i].tobytes()) for i in range(n)])
+    out = tmp_path / "out.tfrecord"
+    _run(["sink", f"tfrecordsink location={out} gt={tmp_path / 'gt.bin'} gop={gop}",
+          f"video/x-raw,format=RGBA,width={w},height={h},framerate=30/1", str(tmp_path / "in.rec")], tmp_path)
+    raw, off, recs = out.read_bytes(), 0, []
+    while off < len(raw):
+        (length,) = struct.unpack_from("<Q", raw, off)
+        assert struct.unpack_from("<I", raw, off + 8)[0] == _masked(raw[off:off + 8])
+        data = raw[off + 12:off + 12 + length]
+        assert struct.unpack_from("<I", raw, off + 12 + length)[0] == _masked(data)
+        recs.append(_parse_example(data))
+        off += 16 + length
+    groups = [[i] for i in range(n)] if gop == 0 else [[0, 1], [2, 3, 4]]   # frames 5..7 stay in the open GoP
+    assert len(recs) == len(groups)
+    for ex, g in zip(recs, groups):
+        total = max(len(g), gop)
+        for ch, name in enumerate(("mb_type", "mv_x", "mv_y")):
+            assert len(ex[name]) == total
+            for k, i in enumerate(g):
+                assert ex[name][k] == frames[i, :, :, ch].tobytes()
+            for k in range(len(g), total):
+                assert ex[name][k] == bytes(w * h)
+        for k, i in enumerate(g):
+            assert ex["gt"][k] == gt[i].tobytes()
