@@ -249,6 +249,7 @@ struct DecArgs {
     uint32_t mNb, mGW, mRC;
     const void *zero;
     Swz swz;             // LDS pixel swizzle of this launch (choose_swz)
+    int scr_off;         // blocks 0..2: byte offset of the per-wave store transpose scratch (2 KB per wave)
     int mask_off;        // last block: byte offset of the band's mask rows in LDS
 };
 
@@ -948,9 +949,9 @@ __global__ __launch_bounds__(((FINAL ? 1 : 4 * COUT / 32) > 4 ? 4 * COUT / 32 : 
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[(a * 2 + bb) * KC + kc], av, acc, 0, 0, 0);
                     }
                 }
-            if (q >= npos) continue;
-            const int u = u0 + ul;
             if constexpr (FINAL) {
+                if (q >= npos) continue;
+                const int u = u0 + ul;
                 // rows 0..3 = parities (py,px) = (r>>1, r&1): only the kh == 0 half holds them
                 if (kh == 0) {
 #pragma unroll
@@ -964,19 +965,41 @@ __global__ __launch_bounds__(((FINAL ? 1 : 4 * COUT / 32) > 4 ? 4 * COUT / 32 : 
                     }
                 }
             } else {
+                // 16-byte stores through a wave-private LDS transpose: the wave's 32 rows (parity, channel) x 32
+                // positions are 64 contiguous bytes per position in the output tensor; lanes drop their 8-byte
+                // pieces at position * 64 + (chunk ^ ((position >> 2) & 3)) * 16 (+8 for the kh half) and every
+                // lane then moves two 16-byte pieces.
+                uint8_t *const scr = smem + p.scr_off + wave * 2048;
+                const int pos = lane & 31;
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    const int n0 = mtile * 32 + 8 * g + 4 * kh;
-                    const int phase = n0 / COUT, co0 = n0 % COUT;
-                    const int Y = 2 * u + (phase >> 1) - p.cy, X = 2 * v + (phase & 1) - p.cx;
-                    if (Y >= 0 && Y < p.Hd && X >= 0 && X < p.Wd) {
-                        half4 o;
+                    half4 o;
 #pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            o[j] = (_Float16)fmaxf(acc[4 * g + j] * es[4 * g + j] + eb[4 * g + j], 0.f);
-                        *reinterpret_cast<half4 *>(p.out + (((size_t)b * p.Hd + Y) * p.Wd + X) * COUT + co0) = o;
+                    for (int j = 0; j < 4; j++)
+                        o[j] = (_Float16)fmaxf(acc[4 * g + j] * es[4 * g + j] + eb[4 * g + j], 0.f);
+                    *reinterpret_cast<half4 *>(scr + pos * 64 + ((g ^ ((pos >> 2) & 3)) * 16) + kh * 8) = o;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int c = j * 64 + lane;                 // 16-byte piece of the wave's 2 KB
+                    const int rp = c >> 2;                       // position of the tile
+                    const int g = (c & 3) ^ ((rp >> 2) & 3);     // logical 16-byte chunk = 8 rows n0 .. n0+7
+                    const int rq = tile * 32 + rp;
+                    if (rq < npos) {
+                        const int rul = fdiv(rq, p.mGW), rv = rq - rul * GW;
+                        const int n0 = mtile * 32 + 8 * g;
+                        const int phase = n0 / COUT, co0 = n0 % COUT;
+                        const int Y = 2 * (u0 + rul) + (phase >> 1) - p.cy, X = 2 * rv + (phase & 1) - p.cx;
+                        if (Y >= 0 && Y < p.Hd && X >= 0 && X < p.Wd)
+                            *reinterpret_cast<uint4 *>(p.out + (((size_t)b * p.Hd + Y) * p.Wd + X) * COUT + co0) =
+                                *reinterpret_cast<const uint4 *>(scr + c * 16);
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next tile's pieces stay behind these reads
+                __builtin_amdgcn_wave_barrier();
             }
         }
         if constexpr (FINAL) {
@@ -1614,10 +1637,12 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
         a.nbands = nbands; a.mNb = magic(nbands); a.mGW = magic(in.W + 1);
         a.mRC = magic((in.W + 2) * (m->dec_ci[j] / 8)); a.zero = prep + pr->zero;
         a.swz = choose_swz(false, m->dec_ci[j], in.W, 0, (GH + nbands - 1) / nbands);
-        const size_t tile_bytes = ((size_t)((GH + nbands - 1) / nbands) + 1) * row_bytes;
+        const size_t tile_bytes = (((size_t)((GH + nbands - 1) / nbands) + 1) * row_bytes + 15) & ~(size_t)15;
         const size_t mask_bytes = last ? ((((size_t)2 * ((GH + nbands - 1) / nbands) * out.W) + 15) & ~(size_t)15) : 0;
-        const size_t lds = tile_bytes + mask_bytes;
+        const size_t scr_bytes = last ? 0 : (size_t)std::max(4, 4 * m->dec_co[j] / 32) * 2048;   // one 2 KB transpose scratch per wave
+        const size_t lds = tile_bytes + mask_bytes + scr_bytes;
         a.mask_off = (int)tile_bytes;
+        a.scr_off = (int)tile_bytes;
         if (lds > 160 * 1024 - 256) return COVAHIP_ERR_UNSUPPORTED;
         const int items = batch * nbands;
         const int grid = std::min(items, (heavy ? 1 : 4) * num_cu);
