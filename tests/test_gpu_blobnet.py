@@ -194,3 +194,25 @@ def test_batch_size_sequence_on_one_context(ctx, weights_flat):
         np.testing.assert_array_equal(counts, ref_counts[:n])
         for i in range(n):
             np.testing.assert_array_equal(boxes[i, :counts[i]], ref_boxes[i, :counts[i]])
+
+
+def test_host_buffer_call_equals_device_pointer_call(ctx, weights_flat):
+    """covahip_filter_forward on host buffers (staged H2D, results copied back) gives the boxes, counts and masks of
+    the device-pointer call on the same batch."""
+    h, w, b = 68, 120, 200
+    stack = synth.stacked_batch(b, h, w, seed=29, streams=8)
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=256)
+    boxes, counts, mask = net.filter(stack, cc_threshold=1, max_boxes=1024, want_mask=True)
+    d_stack = ctx.malloc(stack.nbytes)
+    ctx.h2d(d_stack, stack)
+    d_boxes, d_counts, d_mask = ctx.malloc(b * 1024 * 20), ctx.malloc(b * 4), ctx.malloc(b * h * w)
+    net.filter_device(d_stack, b, 1, d_boxes, d_counts, 1024, d_mask)
+    from cova_amd import _lib as L
+    boxes2 = np.zeros((b, 1024), dtype=L.BOX_DTYPE)
+    counts2 = np.zeros(b, dtype=np.int32)
+    mask2 = np.zeros((b, h, w), dtype=np.uint8)
+    ctx.d2h(boxes2, d_boxes); ctx.d2h(counts2, d_counts); ctx.d2h(mask2, d_mask)
+    np.testing.assert_array_equal(counts, counts2)
+    np.testing.assert_array_equal(mask, mask2)
+    for i in range(b):
+        np.testing.assert_array_equal(boxes[i, :counts[i]], boxes2[i, :counts[i]])
