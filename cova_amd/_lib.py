@@ -85,9 +85,6 @@ PROTOTYPES = {
     "covahip_blobnet_load": (C.c_int, [_P, _P, _SZ, C.c_int, C.c_int, C.c_int, C.c_int]),
     "covahip_blobnet_forward": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int]),
     "covahip_blobnet_macs_per_frame": (C.c_int, [_P, C.POINTER(C.c_int64)]),
-    "covahip_set_pipeline": (C.c_int, [_P, C.c_int]),
-    "covahip_blobnet_set_impl": (C.c_int, [_P, C.c_int]),
-    "covahip_blobnet_set_overlap": (C.c_int, [_P, C.c_int]),
     "covahip_bboxcc": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int]),
     "covahip_filter_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int]),
     "covahip_boxes_to_bbox": (None, [_P, C.c_int, _P]),
@@ -126,8 +123,15 @@ PROTOTYPES = {
     "covahip_gopfilter_push_enc": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32]),
     "covahip_gopfilter_push_boxes": (C.c_int, [_P, _P, _SZ, C.c_uint64, _P, _SZ, C.POINTER(_SZ)]),
     "covahip_gopfilter_eos": (C.c_int, [_P, _P, _SZ, C.POINTER(_SZ)]),
+    "covahip_gopfilter_take_dropped": (C.c_int, [_P, _P, _SZ, C.POINTER(_SZ)]),
+    "covahip_gopfilter_take_track_export": (_SZ, [_P, _P, _SZ, C.POINTER(C.c_int)]),
     "covahip_gopfilter_counters": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                              C.POINTER(C.c_uint64)]),
+}
+
+# developer switches (include/covahip_dev.h): bound for tools/ and tests/, not part of the drop-in boundary
+DEV_PROTOTYPES = {
+    "covahip_blobnet_set_impl": (C.c_int, [_P, C.c_int]),
 }
 
 _lib = None
@@ -142,7 +146,7 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C cova_amd/csrc` -- cova_amd has no CPU fallback")
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in PROTOTYPES.items():
+        for name, (res, args) in list(PROTOTYPES.items()) + list(DEV_PROTOTYPES.items()):
             fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args

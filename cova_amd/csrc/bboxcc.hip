@@ -76,7 +76,6 @@ extern "C" int covahip_bboxcc(covahip_ctx *ctx, const uint8_t *mask, int batch, 
     if (batch == 0) return COVAHIP_OK;
     if (!mask || !counts || (!boxes && max_boxes > 0)) return COVAHIP_ERR_INVALID_ARG;
     COVAHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    { int rcj = covahip_join_aux(ctx); if (rcj) return rcj; }
     if (mem_kind == COVAHIP_MEM_DEVICE)
         return covahip_bboxcc_launch(ctx, mask, batch, h, w, area_thresh, boxes, counts, max_boxes);
     if (mem_kind != COVAHIP_MEM_HOST) return COVAHIP_ERR_INVALID_ARG;

@@ -11,13 +11,6 @@ struct BnLevelGeom {
     int H, W;  // spatial size of the tensor at this level (level 0 = network input)
 };
 
-struct EncParams {        // device pointers into the fp32 weight blob
-    const float *k, *b, *gamma, *beta, *mean, *var, *w1, *w2;
-};
-struct DecParams {
-    const float *k, *b, *gamma, *beta, *mean, *var;
-};
-
 struct covahip_blobnet {
     int H = 0, W = 0, max_batch = 0;
     BnLevelGeom lv[BN_LEVELS + 1];
@@ -25,10 +18,6 @@ struct covahip_blobnet {
     int dec_ci[BN_LEVELS] = {128, 128, 64, 32};
     int dec_co[BN_LEVELS] = {64, 32, 16, 16};
     int dec_cy[BN_LEVELS], dec_cx[BN_LEVELS];  // crop offsets (top/left) per decoder block
-    float *d_weights = nullptr;  // raw fp32 blob payload
-    EncParams enc[BN_LEVELS];
-    DecParams dec[BN_LEVELS];
-    const float *final_k = nullptr, *final_b = nullptr;
     // activations (fp16, channels-last)
     __half *act[BN_LEVELS + 1] = {};  // act[i], i=1..3: [B][T][H_i][W_i][C_i]; act[4]: [B][H_4][W_4][128] (t=0)
     __half *dact[BN_LEVELS] = {};     // dact[j], j=0..2: [B][Hd][Wd][Cout_j]
@@ -36,26 +25,20 @@ struct covahip_blobnet {
     void *d_prepared = nullptr;
     size_t prepared_bytes = 0;
     struct Prepared *prep = nullptr;
-    int impl = 1;  // 0 = naive direct kernels, 1 = MFMA kernels
     int fuse_tail = 1;  // MFMA path, with bboxcc requested: last decoder block + bboxcc in one launch
     int fuse01 = 0;  // MFMA path: encoder levels 0 and 1 as one kernel (default off: measured slower)
-    int overlap = 0;  // split a batch in two halves on two HIP streams (off by default: no gain measured at b=256)
     int64_t macs_per_frame = 0;
 };
 
-// blobnet_naive.hip
-int blobnet_forward_naive(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_stack, int batch, float *d_logits,
-                          uint8_t *d_mask);
 // blobnet_mfma.hip
 int blobnet_prepare_mfma(covahip_ctx *ctx, covahip_blobnet *m, const float *h_weights);
 void blobnet_release_mfma(covahip_ctx *ctx, covahip_blobnet *m);
-// frame0: index of the first workspace frame slot to use (two half-batches can be in flight on
-// two streams, each in its own slice of the activation workspace)
 // cc != nullptr: bboxcc is wanted on the mask; *cc_done tells whether the forward already ran it (fused tail)
 struct BnCcTail {
     int area_thresh, max_boxes;
-    covahip_box *boxes;   // [batch of the whole call][max_boxes]; the forward offsets by frame0
+    covahip_box *boxes;   // [batch][max_boxes]
     int32_t *counts;
 };
+// d_stack == nullptr: planning only (every geometry / LDS check of the launch sequence, no kernel is launched)
 int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_stack, int batch, float *d_logits,
-                         uint8_t *d_mask, int frame0, const BnCcTail *cc = nullptr, bool *cc_done = nullptr);
+                         uint8_t *d_mask, const BnCcTail *cc = nullptr, bool *cc_done = nullptr);

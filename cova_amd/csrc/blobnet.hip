@@ -8,59 +8,30 @@
 #include <cstring>
 
 #include "blobnet.h"
+#include "covahip_dev.h"
 
 namespace {
 
 constexpr uint32_t W_MAGIC = 0x57485643;  // "CVHW"
 constexpr size_t N_PARAMS = 320305;
 
-size_t bind_params(covahip_blobnet *m, const float *base) {
-    const float *p = base;
-    for (int i = 0; i < BN_LEVELS; i++) {
-        const int ci = m->enc_c[i], co = m->enc_c[i + 1];
-        EncParams &e = m->enc[i];
-        e.k = p; p += 9 * ci * co;
-        e.b = p; p += co;
-        e.gamma = p; p += co;
-        e.beta = p; p += co;
-        e.mean = p; p += co;
-        e.var = p; p += co;
-        e.w1 = p; p += 16;
-        e.w2 = p; p += 16;
-    }
-    for (int j = 0; j < BN_LEVELS; j++) {
-        const int ci = m->dec_ci[j], co = m->dec_co[j];
-        DecParams &d = m->dec[j];
-        d.k = p; p += 16 * ci * co;
-        d.b = p; p += co;
-        if (j < BN_LEVELS - 1) {
-            d.gamma = p; p += co;
-            d.beta = p; p += co;
-            d.mean = p; p += co;
-            d.var = p; p += co;
-        } else {
-            d.gamma = d.beta = d.mean = d.var = nullptr;
-        }
-    }
-    m->final_k = p; p += 16;
-    m->final_b = p; p += 1;
-    return (size_t)(p - base);
-}
-
 }  // namespace
 
-void covahip_blobnet_destroy(covahip_ctx *ctx) {
-    covahip_blobnet *m = ctx->blobnet;
+static void free_model(covahip_ctx *ctx, covahip_blobnet *m) {
     if (!m) return;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
     blobnet_release_mfma(ctx, m);
-    if (m->d_weights) hipFree(m->d_weights);
     for (int i = 0; i <= BN_LEVELS; i++)
         if (m->act[i]) hipFree(m->act[i]);
     for (int j = 0; j < BN_LEVELS; j++)
         if (m->dact[j]) hipFree(m->dact[j]);
     delete m;
+}
+
+void covahip_blobnet_destroy(covahip_ctx *ctx) {
+    if (!ctx->blobnet) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    free_model(ctx, ctx->blobnet);
     ctx->blobnet = nullptr;
 }
 
@@ -71,74 +42,22 @@ int covahip_blobnet_geometry(covahip_ctx *ctx, int *h, int *w) {
     return COVAHIP_OK;
 }
 
-// BlobNet forward (+ optionally bboxcc) on device pointers.  With the MFMA path and a large enough
-// batch the work is split in two halves issued on two HIP streams: frames are independent, so the
-// launch gaps, fill/drain tails and latency-bound phases of one half overlap with the other half.
+// BlobNet forward (+ optionally bboxcc) on device pointers, asynchronous on the ctx stream.
 static int filter_dev(covahip_ctx *ctx, const uint8_t *d_stack, int batch, float *d_logits, uint8_t *d_mask,
                       bool with_cc, int area_thresh, covahip_box *d_boxes, int32_t *d_counts, int max_boxes) {
     covahip_blobnet *m = ctx->blobnet;
     if (!m) return COVAHIP_ERR_NOT_LOADED;
     if (batch > m->max_batch) return COVAHIP_ERR_INVALID_ARG;
     if (batch == 0) return COVAHIP_OK;
-    const size_t hw = (size_t)m->H * m->W;
-    if (!(with_cc && ctx->pipeline_cc && m->impl == 1)) {
-        int rcj = covahip_join_aux(ctx);
-        if (rcj) return rcj;
-    }
-    auto run = [&](int f0, int n) -> int {
-        const uint8_t *st = d_stack + (size_t)f0 * BN_T * hw * 4;
-        float *lg = d_logits ? d_logits + (size_t)f0 * hw : nullptr;
-        uint8_t *mk = d_mask ? d_mask + (size_t)f0 * hw : nullptr;
-        int rc;
-        bool cc_done = false;
-        if (m->impl == 0) {
-            if (f0 != 0) return COVAHIP_ERR_INVALID_ARG;
-            rc = blobnet_forward_naive(ctx, m, st, n, lg, mk);
-        } else {
-            // the fused tail needs no mask buffer of its own; the separate bboxcc kernel does (pipelined or fallback)
-            const bool pipe_cc = ctx->pipeline_cc && ctx->stream2 && f0 == 0 && n == batch && !ctx->profile_all();
-            BnCcTail tail{area_thresh, max_boxes, d_boxes, d_counts};
-            rc = blobnet_forward_mfma(ctx, m, st, n, lg, mk, f0, (with_cc && !pipe_cc) ? &tail : nullptr, &cc_done);
-        }
-        if (rc) return rc;
-        if (with_cc && !cc_done) {
-            const bool pipe = ctx->pipeline_cc && m->impl == 1 && ctx->stream2 && f0 == 0 && n == batch &&
-                              !ctx->profile_all();
-            if (pipe) {
-                // bboxcc of this batch goes to stream2 and overlaps the next batch's BlobNet; the next
-                // batch's mask-writing kernel waits for ev_cc_done (blobnet_forward_mfma), every
-                // consumer of the boxes joins through covahip_join_aux.
-                hipStream_t main_stream = ctx->stream;
-                COVAHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_mask_ready, main_stream));
-                COVAHIP_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_mask_ready, 0));
-                ctx->stream = ctx->stream2;
-                rc = covahip_bboxcc_launch(ctx, mk, n, m->H, m->W, area_thresh, d_boxes, d_counts, max_boxes);
-                ctx->stream = main_stream;
-                if (rc) return rc;
-                COVAHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_cc_done, ctx->stream2));
-                ctx->cc_pending = true;
-            } else {
-                rc = covahip_bboxcc_launch(ctx, mk, n, m->H, m->W, area_thresh, d_boxes + (size_t)f0 * max_boxes,
-                                           d_counts + f0, max_boxes);
-            }
-        }
-        return rc;
-    };
-    const bool split = m->impl == 1 && m->overlap && batch >= 32 && ctx->stream2 && !ctx->profile_all();
-    if (!split) return run(0, batch);
-    const int h0 = (batch + 1) / 2;
-    hipStream_t main_stream = ctx->stream;
-    COVAHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_fork, main_stream));
-    COVAHIP_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-    int rc = run(0, h0);
+    BnCcTail tail{area_thresh, max_boxes, d_boxes, d_counts};
+    bool cc_done = false;
+    int rc = blobnet_forward_mfma(ctx, m, d_stack, batch, d_logits, d_mask, with_cc ? &tail : nullptr, &cc_done);
     if (rc) return rc;
-    ctx->stream = ctx->stream2;  // launches of the second half go to the second stream
-    rc = run(h0, batch - h0);
-    ctx->stream = main_stream;
-    if (rc) return rc;
-    COVAHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
-    COVAHIP_CHECK_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
-    return COVAHIP_OK;
+    // the fused decoder tail normally runs bboxcc itself; the separate kernel is the fallback for
+    // geometries whose frame does not fit its LDS plan
+    if (with_cc && !cc_done)
+        rc = covahip_bboxcc_launch(ctx, d_mask, batch, m->H, m->W, area_thresh, d_boxes, d_counts, max_boxes);
+    return rc;
 }
 
 int covahip_blobnet_forward_dev(covahip_ctx *ctx, const uint8_t *d_stack, int batch, float *d_logits,
@@ -146,26 +65,9 @@ int covahip_blobnet_forward_dev(covahip_ctx *ctx, const uint8_t *d_stack, int ba
     return filter_dev(ctx, d_stack, batch, d_logits, d_mask, false, 0, nullptr, nullptr, 0);
 }
 
-extern "C" {
-
-int covahip_blobnet_load(covahip_ctx *ctx, const void *weights, size_t weights_bytes, int h_mb, int w_mb, int t,
-                         int max_batch) {
-    if (!ctx || !weights || h_mb <= 0 || w_mb <= 0 || max_batch <= 0) return COVAHIP_ERR_INVALID_ARG;
-    if (t != BN_T) return COVAHIP_ERR_UNSUPPORTED;
-    if (h_mb < 16 || w_mb < 16 || h_mb > 1024 || w_mb > 1024) return COVAHIP_ERR_UNSUPPORTED;
-    if (weights_bytes < 64) return COVAHIP_ERR_BAD_WEIGHTS;
-    uint32_t hdr[16];
-    std::memcpy(hdr, weights, 64);
-    static const uint32_t want[] = {W_MAGIC, 1, 4, 3, 16, 32, 64, 128, 64, 32, 16, 16, (uint32_t)N_PARAMS};
-    for (int i = 0; i < 13; i++)
-        if (hdr[i] != want[i]) return COVAHIP_ERR_BAD_WEIGHTS;
-    if (weights_bytes != 64 + N_PARAMS * sizeof(float)) return COVAHIP_ERR_BAD_WEIGHTS;
-    const float *h_w = reinterpret_cast<const float *>(static_cast<const uint8_t *>(weights) + 64);
-
-    COVAHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    covahip_blobnet_destroy(ctx);
-    covahip_blobnet *m = new covahip_blobnet();
-    ctx->blobnet = m;
+// Geometry, HBM workspace and prepared weights of a model.  Every limit of the kernels is checked here (a
+// planning-only pass of the forward for batch 1 and max_batch), so an unsupported grid fails at load time.
+static int build_model(covahip_ctx *ctx, covahip_blobnet *m, const float *h_w, int h_mb, int w_mb, int max_batch) {
     m->H = h_mb;
     m->W = w_mb;
     m->max_batch = max_batch;
@@ -191,11 +93,6 @@ int covahip_blobnet_load(covahip_ctx *ctx, const void *weights, size_t weights_b
     macs += (int64_t)h_mb * w_mb * 16;
     m->macs_per_frame = macs;
 
-    COVAHIP_CHECK_HIP(ctx, hipMalloc((void **)&m->d_weights, N_PARAMS * sizeof(float)));
-    COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(m->d_weights, h_w, N_PARAMS * sizeof(float), hipMemcpyHostToDevice,
-                                          ctx->stream));
-    if (bind_params(m, m->d_weights) != N_PARAMS) return COVAHIP_ERR_BAD_WEIGHTS;
-
     // HBM workspace: activations stay resident; pad rows/columns are zeroed once here and
     // never written afterwards.
     for (int i = 1; i <= BN_LEVELS; i++) {
@@ -211,9 +108,41 @@ int covahip_blobnet_load(covahip_ctx *ctx, const void *weights, size_t weights_b
     }
     int rc = blobnet_prepare_mfma(ctx, m, h_w);
     if (rc) return rc;
-    const char *env = std::getenv("COVAHIP_BLOBNET_IMPL");
-    m->impl = (env && std::strcmp(env, "naive") == 0) ? 0 : 1;
-    COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rc = blobnet_forward_mfma(ctx, m, nullptr, 1, nullptr, nullptr, nullptr, nullptr);   // planning only
+    if (rc) return rc;
+    return blobnet_forward_mfma(ctx, m, nullptr, max_batch, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" {
+
+int covahip_blobnet_load(covahip_ctx *ctx, const void *weights, size_t weights_bytes, int h_mb, int w_mb, int t,
+                         int max_batch) {
+    if (!ctx || !weights || h_mb <= 0 || w_mb <= 0 || max_batch <= 0) return COVAHIP_ERR_INVALID_ARG;
+    if (t != BN_T) return COVAHIP_ERR_UNSUPPORTED;
+    if (h_mb < 16 || w_mb < 16 || h_mb > 1024 || w_mb > 1024) return COVAHIP_ERR_UNSUPPORTED;
+    if (weights_bytes < 64) return COVAHIP_ERR_BAD_WEIGHTS;
+    uint32_t hdr[16];
+    std::memcpy(hdr, weights, 64);
+    static const uint32_t want[] = {W_MAGIC, 1, 4, 3, 16, 32, 64, 128, 64, 32, 16, 16, (uint32_t)N_PARAMS};
+    for (int i = 0; i < 13; i++)
+        if (hdr[i] != want[i]) return COVAHIP_ERR_BAD_WEIGHTS;
+    if (weights_bytes != 64 + N_PARAMS * sizeof(float)) return COVAHIP_ERR_BAD_WEIGHTS;
+    const float *h_w = reinterpret_cast<const float *>(static_cast<const uint8_t *>(weights) + 64);
+
+    COVAHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    covahip_blobnet_destroy(ctx);
+    // The model is built on the side and attached to the ctx only when every step succeeded: a failed
+    // load leaves the ctx without a model (COVAHIP_ERR_NOT_LOADED afterwards), never with half of one.
+    covahip_blobnet *m = new covahip_blobnet();
+    int rc = build_model(ctx, m, h_w, h_mb, w_mb, max_batch);
+    if (rc == COVAHIP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = COVAHIP_ERR_HIP;
+    if (rc) {
+        hipStreamSynchronize(ctx->stream);
+        (void)hipGetLastError();
+        free_model(ctx, m);
+        return rc;
+    }
+    ctx->blobnet = m;
     return COVAHIP_OK;
 }
 
@@ -224,24 +153,9 @@ int covahip_blobnet_macs_per_frame(covahip_ctx *ctx, int64_t *macs) {
     return COVAHIP_OK;
 }
 
-int covahip_set_pipeline(covahip_ctx *ctx, int on) {
-    if (!ctx) return COVAHIP_ERR_INVALID_ARG;
-    int rc = covahip_join_aux(ctx);
-    if (rc) return rc;
-    ctx->pipeline_cc = on != 0;
-    return COVAHIP_OK;
-}
-
-int covahip_blobnet_set_overlap(covahip_ctx *ctx, int on) {
-    if (!ctx || !ctx->blobnet) return COVAHIP_ERR_NOT_LOADED;
-    ctx->blobnet->overlap = on != 0;
-    return COVAHIP_OK;
-}
-
 int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl) {
     if (!ctx || !ctx->blobnet) return COVAHIP_ERR_NOT_LOADED;
-    if (impl < 0 || impl > 2) return COVAHIP_ERR_INVALID_ARG;
-    ctx->blobnet->impl = impl ? 1 : 0;
+    if (impl < 1 || impl > 2) return COVAHIP_ERR_INVALID_ARG;
     ctx->blobnet->fuse01 = impl == 2;
     return COVAHIP_OK;
 }
@@ -286,8 +200,6 @@ int covahip_filter_forward(covahip_ctx *ctx, const uint8_t *rgba_stack, int batc
     COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(ctx->stage_in, rgba_stack, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     rc = filter_dev(ctx, (const uint8_t *)ctx->stage_in, batch, logits ? d_logits : nullptr, d_mask, true, area_thresh,
                     d_boxes, d_counts, max_boxes);
-    if (rc) return rc;
-    rc = covahip_join_aux(ctx);
     if (rc) return rc;
     if (logits) COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(logits, d_logits, logit_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (mask) COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(mask, d_mask, mask_bytes, hipMemcpyDeviceToHost, ctx->stream));

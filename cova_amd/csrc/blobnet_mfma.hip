@@ -1373,6 +1373,12 @@ int set_lds(covahip_ctx *ctx, K kernel, size_t lds) {
 
 }  // namespace
 
+// planning-only passes (blobnet_forward_mfma with d_stack == nullptr) go through every check and launch nothing
+#define LAUNCH(...)                                  \
+    do {                                             \
+        if (!dry) hipLaunchKernelGGL(__VA_ARGS__);   \
+    } while (0)
+
 int blobnet_prepare_mfma(covahip_ctx *ctx, covahip_blobnet *m, const float *w) {
     // host view of the parameter blob (same order as bind_params in blobnet.hip)
     struct HE { const float *k, *b, *gamma, *beta, *mean, *var, *w1, *w2; } he[BN_LEVELS];
@@ -1452,19 +1458,11 @@ void blobnet_release_mfma(covahip_ctx *, covahip_blobnet *m) {
 }
 
 int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_stack, int batch, float *d_logits,
-                         uint8_t *d_mask, int frame0, const BnCcTail *cc, bool *cc_done) {
+                         uint8_t *d_mask, const BnCcTail *cc, bool *cc_done) {
     if (cc_done) *cc_done = false;
-    // workspace slices of this call
-    __half *act[BN_LEVELS + 1] = {};
-    __half *dact[BN_LEVELS] = {};
-    for (int i = 1; i <= BN_LEVELS; i++) {
-        const size_t tt = (i == BN_LEVELS) ? 1 : BN_T;
-        act[i] = m->act[i] + (size_t)frame0 * tt * m->lv[i].H * m->lv[i].W * m->enc_c[i];
-    }
-    for (int j = 0; j < BN_LEVELS - 1; j++) {
-        const BnLevelGeom o = m->lv[BN_LEVELS - 1 - j];
-        dact[j] = m->dact[j] + (size_t)frame0 * o.H * o.W * m->dec_co[j];
-    }
+    const bool dry = d_stack == nullptr;   // planning only: every check below runs, no kernel is launched
+    __half *const *act = m->act;
+    __half *const *dact = m->dact;
     const uint8_t *prep = (const uint8_t *)m->d_prepared;
     const Prepared *pr = m->prep;
     const int num_cu = ctx->props.multiProcessorCount;
@@ -1512,10 +1510,10 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
                         : (p1 ? set_lds(ctx, enc01_mfma<false, true>, lds) : set_lds(ctx, enc01_mfma<false, false>, lds));
             if (rc) return rc;
             ProfScope ps(ctx, "enc01_mfma");
-            if (p0 && p1) hipLaunchKernelGGL((enc01_mfma<true, true>), dim3(grid), dim3(WG01), lds, ctx->stream, a);
-            else if (p0) hipLaunchKernelGGL((enc01_mfma<true, false>), dim3(grid), dim3(WG01), lds, ctx->stream, a);
-            else if (p1) hipLaunchKernelGGL((enc01_mfma<false, true>), dim3(grid), dim3(WG01), lds, ctx->stream, a);
-            else hipLaunchKernelGGL((enc01_mfma<false, false>), dim3(grid), dim3(WG01), lds, ctx->stream, a);
+            if (p0 && p1) LAUNCH((enc01_mfma<true, true>), dim3(grid), dim3(WG01), lds, ctx->stream, a);
+            else if (p0) LAUNCH((enc01_mfma<true, false>), dim3(grid), dim3(WG01), lds, ctx->stream, a);
+            else if (p1) LAUNCH((enc01_mfma<false, true>), dim3(grid), dim3(WG01), lds, ctx->stream, a);
+            else LAUNCH((enc01_mfma<false, false>), dim3(grid), dim3(WG01), lds, ctx->stream, a);
             COVAHIP_CHECK_HIP(ctx, hipGetLastError());
             first_level = 2;
         }
@@ -1571,8 +1569,8 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
             int rc = pr->allpos[0] ? set_lds(ctx, enc0_mfma<true>, lds) : set_lds(ctx, enc0_mfma<false>, lds);
             if (rc) return rc;
             ProfScope ps(ctx, "enc0_mfma");
-            if (pr->allpos[0]) hipLaunchKernelGGL(enc0_mfma<true>, dim3(grid), dim3(WG0), lds, ctx->stream, a);
-            else hipLaunchKernelGGL(enc0_mfma<false>, dim3(grid), dim3(WG0), lds, ctx->stream, a);
+            if (pr->allpos[0]) LAUNCH(enc0_mfma<true>, dim3(grid), dim3(WG0), lds, ctx->stream, a);
+            else LAUNCH(enc0_mfma<false>, dim3(grid), dim3(WG0), lds, ctx->stream, a);
         } else {
             EncArgs a;
             a.in = act[i]; a.out = act[i + 1];
@@ -1588,20 +1586,20 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
                 rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true, true>, lds) : set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true, false>, lds);
                 if (rc) return rc;
                 ProfScope ps(ctx, "enc1_mfma");
-                if (pr->allpos[i]) hipLaunchKernelGGL((enc_mfma<16, 32, 2, 4, 8, true, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
-                else hipLaunchKernelGGL((enc_mfma<16, 32, 2, 4, 8, true, false>), dim3(grid), dim3(512), lds, ctx->stream, a);
+                if (pr->allpos[i]) LAUNCH((enc_mfma<16, 32, 2, 4, 8, true, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
+                else LAUNCH((enc_mfma<16, 32, 2, 4, 8, true, false>), dim3(grid), dim3(512), lds, ctx->stream, a);
             } else if (i == 2) {
                 rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<32, 64, 4, 2, 4, false, true>, lds) : set_lds(ctx, enc_mfma<32, 64, 4, 2, 4, false, false>, lds);
                 if (rc) return rc;
                 ProfScope ps(ctx, "enc2_mfma");
-                if (pr->allpos[i]) hipLaunchKernelGGL((enc_mfma<32, 64, 4, 2, 4, false, true>), dim3(grid), dim3(WG), lds, ctx->stream, a);
-                else hipLaunchKernelGGL((enc_mfma<32, 64, 4, 2, 4, false, false>), dim3(grid), dim3(WG), lds, ctx->stream, a);
+                if (pr->allpos[i]) LAUNCH((enc_mfma<32, 64, 4, 2, 4, false, true>), dim3(grid), dim3(WG), lds, ctx->stream, a);
+                else LAUNCH((enc_mfma<32, 64, 4, 2, 4, false, false>), dim3(grid), dim3(WG), lds, ctx->stream, a);
             } else {
                 rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<64, 128, 2, 2, 8, true, true>, lds) : set_lds(ctx, enc_mfma<64, 128, 2, 2, 8, true, false>, lds);
                 if (rc) return rc;
                 ProfScope ps(ctx, "enc3_mfma");
-                if (pr->allpos[i]) hipLaunchKernelGGL((enc_mfma<64, 128, 2, 2, 8, true, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
-                else hipLaunchKernelGGL((enc_mfma<64, 128, 2, 2, 8, true, false>), dim3(grid), dim3(512), lds, ctx->stream, a);
+                if (pr->allpos[i]) LAUNCH((enc_mfma<64, 128, 2, 2, 8, true, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
+                else LAUNCH((enc_mfma<64, 128, 2, 2, 8, true, false>), dim3(grid), dim3(512), lds, ctx->stream, a);
             }
         }
         COVAHIP_CHECK_HIP(ctx, hipGetLastError());
@@ -1651,17 +1649,17 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
             rc = set_lds(ctx, dec_mfma<0, 128, 64, false>, lds);
             if (rc) return rc;
             ProfScope ps(ctx, "dec0_mfma");
-            hipLaunchKernelGGL((dec_mfma<0, 128, 64, false>), dim3(grid), dim3(512), lds, ctx->stream, a);
+            LAUNCH((dec_mfma<0, 128, 64, false>), dim3(grid), dim3(512), lds, ctx->stream, a);
         } else if (j == 1) {
             rc = set_lds(ctx, dec_mfma<64, 64, 32, false>, lds);
             if (rc) return rc;
             ProfScope ps(ctx, "dec1_mfma");
-            hipLaunchKernelGGL((dec_mfma<64, 64, 32, false>), dim3(grid), dim3(256), lds, ctx->stream, a);
+            LAUNCH((dec_mfma<64, 64, 32, false>), dim3(grid), dim3(256), lds, ctx->stream, a);
         } else if (j == 2) {
             rc = set_lds(ctx, dec_mfma<32, 32, 16, false>, lds);
             if (rc) return rc;
             ProfScope ps(ctx, "dec2_mfma");
-            hipLaunchKernelGGL((dec_mfma<32, 32, 16, false>), dim3(grid), dim3(256), lds, ctx->stream, a);
+            LAUNCH((dec_mfma<32, 32, 16, false>), dim3(grid), dim3(256), lds, ctx->stream, a);
         } else if (cc && m->fuse_tail && [&]() -> bool {
                        // last block + bboxcc in one launch when the frame's LDS plan fits: two band buffers (which
                        // bboxcc's region reuses) + the frame's mask bytes
@@ -1688,25 +1686,22 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
                        t.d = a;
                        t.d.nbands = best_nb; t.d.mNb = magic(best_nb);
                        t.d.swz = choose_swz(false, m->dec_ci[j], in.W, 0, (GH + best_nb - 1) / best_nb);
-                       t.boxes = cc->boxes + (size_t)frame0 * cc->max_boxes; t.counts = cc->counts + frame0;
+                       t.boxes = cc->boxes; t.counts = cc->counts;
                        t.area_thresh = cc->area_thresh; t.max_boxes = cc->max_boxes;
                        t.tile_bytes = (int)tb; t.cc_off = 0;
                        t.mfull_off = (int)std::max((best_nb == 1 ? 1 : 2) * tb, cc_bytes);
                        const size_t tl = (size_t)t.mfull_off + mfull;
                        if (set_lds(ctx, dec3cc_mfma, tl)) return false;
-                       if (ctx->cc_pending && hipStreamWaitEvent(ctx->stream, ctx->ev_cc_done, 0) != hipSuccess) return false;
                        ProfScope ps(ctx, "dec3_bboxcc_fused");
-                       hipLaunchKernelGGL(dec3cc_mfma, dim3(std::min(batch, 2 * num_cu)), dim3(ccbody::CC_THREADS), tl, ctx->stream, t);
+                       LAUNCH(dec3cc_mfma, dim3(std::min(batch, 2 * num_cu)), dim3(ccbody::CC_THREADS), tl, ctx->stream, t);
                        return true;
                    }()) {
             if (cc_done) *cc_done = true;
         } else {
             rc = set_lds(ctx, dec_mfma<16, 16, 16, true>, lds);
             if (rc) return rc;
-            // the previous batch's pipelined bboxcc may still be reading the mask this kernel rewrites
-            if (ctx->cc_pending) COVAHIP_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cc_done, 0));
             ProfScope ps(ctx, "dec3_final_mfma");
-            hipLaunchKernelGGL((dec_mfma<16, 16, 16, true>), dim3(grid), dim3(256), lds, ctx->stream, a);
+            LAUNCH((dec_mfma<16, 16, 16, true>), dim3(grid), dim3(256), lds, ctx->stream, a);
         }
         COVAHIP_CHECK_HIP(ctx, hipGetLastError());
     }

@@ -53,11 +53,6 @@ int covahip_ctx_create(int device_id, covahip_ctx **out) {
         hipEventCreate(&ctx->t_start[i]);
         hipEventCreate(&ctx->t_stop[i]);
     }
-    hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
-    hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
-    hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
-    hipEventCreateWithFlags(&ctx->ev_mask_ready, hipEventDisableTiming);
-    hipEventCreateWithFlags(&ctx->ev_cc_done, hipEventDisableTiming);
     *out = ctx;
     return COVAHIP_OK;
 }
@@ -66,7 +61,6 @@ void covahip_ctx_destroy(covahip_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
     covahip_blobnet_destroy(ctx);
     for (int i = 0; i < 16; i++) {
         hipEventDestroy(ctx->t_start[i]);
@@ -84,19 +78,12 @@ void covahip_ctx_destroy(covahip_ctx *ctx) {
     if (ctx->stage_out) hipFree(ctx->stage_out);
     if (ctx->cc_scratch) hipFree(ctx->cc_scratch);
     if (ctx->pinned) hipHostFree(ctx->pinned);
-    if (ctx->stream2) hipStreamDestroy(ctx->stream2);
-    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
-    if (ctx->ev_mask_ready) hipEventDestroy(ctx->ev_mask_ready);
-    if (ctx->ev_cc_done) hipEventDestroy(ctx->ev_cc_done);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
 int covahip_ctx_sync(covahip_ctx *ctx) {
     if (!ctx) return COVAHIP_ERR_INVALID_ARG;
-    int rc = covahip_join_aux(ctx);
-    if (rc) return rc;
     COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return COVAHIP_OK;
 }
@@ -137,7 +124,6 @@ int covahip_memcpy_h2d(covahip_ctx *ctx, void *dev_dst, const void *host_src, si
 
 int covahip_memcpy_d2h(covahip_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
     if (!ctx || (!host_dst && bytes) || (!dev_src && bytes)) return COVAHIP_ERR_INVALID_ARG;
-    { int rc = covahip_join_aux(ctx); if (rc) return rc; }
     COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return COVAHIP_OK;
@@ -157,7 +143,6 @@ int covahip_timer_start(covahip_ctx *ctx, int slot) {
 
 int covahip_timer_stop(covahip_ctx *ctx, int slot) {
     if (!ctx || slot < 0 || slot >= 16) return COVAHIP_ERR_INVALID_ARG;
-    { int rc = covahip_join_aux(ctx); if (rc) return rc; }  // the timed region includes the pipelined bboxcc
     COVAHIP_CHECK_HIP(ctx, hipEventRecord(ctx->t_stop[slot], ctx->stream));
     return COVAHIP_OK;
 }
@@ -255,13 +240,6 @@ ProfScope::~ProfScope() {
         }
         ctx->prof_pending.clear();
     }
-}
-
-int covahip_join_aux(covahip_ctx *ctx) {
-    if (!ctx->cc_pending) return COVAHIP_OK;
-    COVAHIP_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cc_done, 0));
-    ctx->cc_pending = false;
-    return COVAHIP_OK;
 }
 
 int covahip_ensure_buffer(covahip_ctx *ctx, void **buf, size_t *cur, size_t need) {

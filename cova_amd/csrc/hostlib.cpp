@@ -705,6 +705,8 @@ struct covahip_gopfilter {
     uint64_t range_start = 0;
     uint64_t dropped = 0, decoded_dependency = 0, decoded_inference = 0;
     uint32_t next_list = 0;
+    std::vector<uint64_t> dropped_ids;   // ids of access units discarded since the last take_dropped
+    std::vector<uint8_t> track_wire;     // length-delimited bincode Frames of finished tracks (cova/tracker.rs:59-83)
     ~covahip_gopfilter() { delete sort; }
 };
 
@@ -728,6 +730,24 @@ struct OutSink {
         lst.clear();
     }
 };
+
+// cova/tracker.rs:59-83 / :91-118: every finished track goes out as one length-delimited bincode Frame
+// {range_start, oldest = smallest start among the live trackers, history}.  (The reference re-sends the
+// frames already in its buffer for every further track of the same call -- not reproduced.)
+void export_tracks(covahip_gopfilter *g, const std::vector<Tracker> &tracks) {
+    if (tracks.empty()) return;
+    uint64_t oldest = UINT64_MAX;
+    for (const Tracker &t : g->sort->trackers) oldest = std::min(oldest, t.start);
+    for (const Tracker &t : tracks) {
+        const size_t fl = covahip_frame_serialize(g->range_start, oldest, t.history.data(), t.history.size(), nullptr, 0, nullptr);
+        const size_t at = g->track_wire.size();
+        g->track_wire.resize(at + 4 + fl);
+        uint8_t *o = g->track_wire.data() + at;
+        o[0] = (uint8_t)(fl >> 24); o[1] = (uint8_t)(fl >> 16); o[2] = (uint8_t)(fl >> 8); o[3] = (uint8_t)fl;
+        int st = 0;
+        covahip_frame_serialize(g->range_start, oldest, t.history.data(), t.history.size(), o + 4, fl, &st);
+    }
+}
 
 }  // namespace
 
@@ -790,6 +810,7 @@ int covahip_gopfilter_push_boxes(covahip_gopfilter *g, const covahip_bbox *boxes
     }
     std::vector<Tracker> dead;
     if (!g->sort->update(std::vector<covahip_bbox>(boxes, boxes + n), pts, dead)) return COVAHIP_ERR_BAD_DATA;
+    export_tracks(g, dead);
     bool have_min = !dead.empty();
     uint64_t min_track_pts = 0;
     for (const Tracker &t : dead)
@@ -816,7 +837,10 @@ int covahip_gopfilter_push_boxes(covahip_gopfilter *g, const covahip_bbox *boxes
             while (!gop.in.empty()) {
                 Au buf = gop.in.front();
                 gop.in.pop_front();
-                if (track_inferenced > 0) break;  // NB: the popped AU is discarded (reference behaviour)
+                if (track_inferenced > 0) {  // NB: the popped AU is discarded (reference behaviour)
+                    g->dropped_ids.push_back(buf.id);
+                    break;
+                }
                 if (min_track_pts <= buf.pts) {
                     g->sort->mark_seen(buf.pts);
                     di += 1;
@@ -890,10 +914,12 @@ int covahip_gopfilter_push_boxes(covahip_gopfilter *g, const covahip_bbox *boxes
                 gop.out.push_back(b);
             } else {
                 dropped += 1;
+                g->dropped_ids.push_back(b.id);
             }
         }
         if (!gop.out.empty()) sink.push_list(g, gop.out);
         dropped += gop.in.size();
+        for (const Au &a : gop.in) g->dropped_ids.push_back(a.id);
         it = g->bufs.erase(it);
     }
     g->decoded_inference += di2;
@@ -908,14 +934,41 @@ int covahip_gopfilter_eos(covahip_gopfilter *g, covahip_au_out *out, size_t cap,
     uint64_t dropped = 0;
     for (Gop &gop : g->bufs) {  // imp.rs:371-387
         dropped += gop.in.size();
+        for (const Au &a : gop.in) g->dropped_ids.push_back(a.id);
         sink.push_list(g, gop.out);
     }
     g->bufs.clear();
     g->dropped += dropped;
-    delete g->sort;  // tracker.take(); flush() only writes to the optional TCP socket
+    if (g->sort) export_tracks(g, g->sort->finalize());  // tracker.take().flush(): cova/tracker.rs:91-118
+    delete g->sort;
     g->sort = nullptr;
     if (n_out) *n_out = sink.n;
     return (out && sink.n > cap) ? COVAHIP_ERR_OVERFLOW : COVAHIP_OK;
+}
+
+int covahip_gopfilter_take_dropped(covahip_gopfilter *g, uint64_t *ids, size_t cap, size_t *n) {
+    if (!g || !n || (!ids && cap)) return COVAHIP_ERR_INVALID_ARG;
+    const size_t k = std::min(cap, g->dropped_ids.size());
+    std::copy(g->dropped_ids.begin(), g->dropped_ids.begin() + k, ids);
+    g->dropped_ids.erase(g->dropped_ids.begin(), g->dropped_ids.begin() + k);
+    *n = k;
+    return COVAHIP_OK;
+}
+
+size_t covahip_gopfilter_take_track_export(covahip_gopfilter *g, uint8_t *out, size_t cap, int *status) {
+    if (!g) {
+        if (status) *status = COVAHIP_ERR_INVALID_ARG;
+        return 0;
+    }
+    const size_t need = g->track_wire.size();
+    if (out && need <= cap) {
+        std::copy(g->track_wire.begin(), g->track_wire.end(), out);
+        g->track_wire.clear();
+        if (status) *status = COVAHIP_OK;
+    } else if (status) {
+        *status = COVAHIP_ERR_OVERFLOW;
+    }
+    return need;
 }
 
 int covahip_gopfilter_counters(const covahip_gopfilter *g, uint64_t *dropped, uint64_t *decoded_dependency,

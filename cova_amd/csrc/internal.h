@@ -14,14 +14,6 @@ struct covahip_blobnet;  // blobnet.hip
 struct covahip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;      // second stream for the half-batch overlap
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // cross-batch pipelining of the fused path: bboxcc of batch k runs on stream2 while BlobNet of
-    // batch k+1 runs on the main stream
-    hipEvent_t ev_mask_ready = nullptr, ev_cc_done = nullptr;
-    bool cc_pending = false;   // a bboxcc launch on stream2 has not been joined into the main stream yet
-    bool pipeline_cc = false;  // off by default: on MI355X at b=256 the co-running bboxcc takes LDS/CU slots
-                               // from the next batch's enc0 and the step gets slower (224 vs 204 us)
     std::string last_hip_error;
     hipDeviceProp_t props{};
     // timers
@@ -48,8 +40,6 @@ struct covahip_ctx {
     void *cc_scratch = nullptr;
     size_t cc_scratch_bytes = 0;
     covahip_blobnet *blobnet = nullptr;
-    // per-kernel timing of EVERY kernel is only meaningful without cross-stream overlap
-    bool profile_all() const { return profile && profile_filter.empty(); }
 };
 
 #define COVAHIP_CHECK_HIP(ctx, expr)                                                        \
@@ -70,8 +60,6 @@ struct ProfScope {
 };
 
 int covahip_ensure_buffer(covahip_ctx *ctx, void **buf, size_t *cur, size_t need);
-// Makes the main stream wait for an outstanding pipelined bboxcc (no-op when none is pending).
-int covahip_join_aux(covahip_ctx *ctx);
 
 // bboxcc.hip
 int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, int h, int w, int area_thresh,

@@ -48,9 +48,6 @@ class Context:
 
     __del__ = close
 
-    def set_pipeline(self, on: bool):
-        L.check(self._lib.covahip_set_pipeline(self.handle, int(on)), "covahip_set_pipeline", self.handle)
-
     def sync(self):
         L.check(self._lib.covahip_ctx_sync(self.handle), "covahip_ctx_sync", self.handle)
 
@@ -160,10 +157,8 @@ class BlobNetInfer:
                 "covahip_blobnet_load", ctx.handle)
 
     def set_impl(self, impl: str):
-        L.check(self._lib.covahip_blobnet_set_impl(self.ctx.handle, {"naive": 0, "mfma": 1, "mfma_fused01": 2}[impl]), "set_impl")
-
-    def set_overlap(self, on: bool):
-        L.check(self._lib.covahip_blobnet_set_overlap(self.ctx.handle, int(on)), "set_overlap")
+        """Developer switch (include/covahip_dev.h): encoder levels 0/1 as two kernels or as one."""
+        L.check(self._lib.covahip_blobnet_set_impl(self.ctx.handle, {"mfma": 1, "mfma_fused01": 2}[impl]), "set_impl")
 
     @property
     def macs_per_frame(self) -> int:
@@ -421,9 +416,8 @@ class Cova:
 
     def __init__(self, sort_iou: float = 0.1, sort_maxage: int = 30, sort_minhits: int = 30, port: int = 0,
                  infer_i: bool = False, debug: bool = False, alpha: int = 0, beta: int = 0):
-        if port != 0:
-            raise NotImplementedError("TCP track export (analysis-aggregator link) is out of scope of the hot path")
-        self._lib = L.lib()
+        self.port = port           # the socket itself belongs to the GStreamer element (gst/gstcova.c); here the bytes
+        self._lib = L.lib()        # it would carry are read with take_track_export()
         cfg = L.GopFilterCfg(sort_iou, sort_maxage, sort_minhits, alpha, beta, int(infer_i))
         h = C.c_void_p()
         L.check(self._lib.covahip_gopfilter_new(C.byref(cfg), C.byref(h)), "gopfilter_new")
@@ -459,6 +453,22 @@ class Cova:
         if all(self._eos):
             return self._out(lambda o, c, n: self._lib.covahip_gopfilter_eos(self._h, o, c, n))
         return None
+
+    def take_dropped(self) -> list:
+        """Ids of the access units discarded for good since the last call (their buffers can be released)."""
+        ids = []
+        buf = np.zeros(4096, dtype=np.uint64)
+        while True:
+            n = C.c_size_t()
+            L.check(self._lib.covahip_gopfilter_take_dropped(self._h, _ptr(buf), buf.size, C.byref(n)), "take_dropped")
+            ids.extend(int(x) for x in buf[:n.value])
+            if n.value < buf.size:
+                return ids
+
+    def take_track_export(self) -> bytes:
+        """Length-delimited bincode Frames of the tracks finished since the last call (cova/tracker.rs:59-83)."""
+        return _sized_call(lambda o, c, st: self._lib.covahip_gopfilter_take_track_export(self._h, o, c, st),
+                           "take_track_export")
 
     def _counters(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -134,7 +134,7 @@ static int run_cova(const char *props, const char *in_path, const char *out_path
     GstElement *e = gst_parse_launch(desc, &err);
     FILE *fi = fopen(in_path, "rb");
     rec_t r;
-    guint64 d = 0, dd = 0, di = 0;
+    guint64 d = 0, dd = 0, di = 0, held = 0, held_max = 0;
     if (!e || !fi) { fprintf(stderr, "cova setup failed: %s\n", err ? err->message : "?"); return 2; }
     cova_out = fopen(out_path, "wb");
     GstPad *enc = gst_pad_new("enc_src", GST_PAD_SRC), *mask = gst_pad_new("mask_src", GST_PAD_SRC);
@@ -158,11 +158,15 @@ static int run_cova(const char *props, const char *in_path, const char *out_path
         else if (r.kind == 'e') gst_pad_push_event(enc, gst_event_new_eos());
         else if (r.kind == 'm') gst_pad_push_event(mask, gst_event_new_eos());
         free(r.data);
+        g_object_get(e, "held-buffers", &held, NULL);
+        if (held > held_max) held_max = held;
         if (fr != GST_FLOW_OK) { fprintf(stderr, "flow %s at kind %c pts %llu\n", gst_flow_get_name(fr), r.kind, (unsigned long long)r.pts); rc = 3; break; }
     }
     g_object_get(e, "dropped", &d, "decoded-dependency", &dd, "decoded-inference", &di, NULL);
-    printf("{\"dropped\": %llu, \"decoded_dependency\": %llu, \"decoded_inference\": %llu, \"eos\": %d}\n",
-           (unsigned long long)d, (unsigned long long)dd, (unsigned long long)di, cova_got_eos);
+    g_object_get(e, "held-buffers", &held, NULL);
+    printf("{\"dropped\": %llu, \"decoded_dependency\": %llu, \"decoded_inference\": %llu, \"eos\": %d, \"held_max\": %llu, \"held_end\": %llu}\n",
+           (unsigned long long)d, (unsigned long long)dd, (unsigned long long)di, cova_got_eos, (unsigned long long)held_max,
+           (unsigned long long)held);
     fclose(fi); fclose(cova_out);
     gst_element_set_state(e, GST_STATE_NULL);
     return rc;

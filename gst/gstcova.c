@@ -21,9 +21,13 @@
 #include <gst/base/gstbasetransform.h>
 #include <gst/gst.h>
 #include <gst/video/video.h>
+#include <arpa/inet.h>
+#include <netinet/in.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/socket.h>
+#include <unistd.h>
 
 #include "covahip.h"
 
@@ -150,20 +154,15 @@ static void gst_metapreprocess_class_init(GstMetaPreprocessClass *k) {
     b->passthrough_on_same_caps = FALSE;
 }
 
-/* ===================================================================== shared GPU context */
-static covahip_ctx *ctx_for_gpu(guint gpu_id) {
-    /* one context per GPU per process, shared by the elements (calls are serialised by ctx_lock) */
-    static covahip_ctx *ctxs[16];
-    static GMutex init_lock;
+/* ===================================================================== GPU contexts
+ * Every GPU element instance owns its covahip_ctx (HIP stream + model + staging buffers), like an nvinfer
+ * instance owns its engine context: two instances with different caps or weights never share state and never
+ * serialise on each other.  The element's streaming thread is the only caller of its ctx. */
+static covahip_ctx *ctx_new_for_gpu(guint gpu_id) {
     covahip_ctx *c = NULL;
-    if (gpu_id >= 16) return NULL;
-    g_mutex_lock(&init_lock);
-    if (!ctxs[gpu_id] && covahip_ctx_create((int)gpu_id, &ctxs[gpu_id]) != COVAHIP_OK) ctxs[gpu_id] = NULL;
-    c = ctxs[gpu_id];
-    g_mutex_unlock(&init_lock);
+    if (gpu_id >= 16 || covahip_ctx_create((int)gpu_id, &c) != COVAHIP_OK) return NULL;
     return c;
 }
-static GMutex ctx_lock;
 
 /* ===================================================================== blobnetinfer */
 typedef struct {
@@ -223,11 +222,9 @@ static gboolean bn_set_caps(GstBaseTransform *bt, GstCaps *in, GstCaps *out) {
         GST_ERROR_OBJECT(s, "cannot read weights file '%s'", s->weights ? s->weights : "(unset)");
         return FALSE;
     }
-    s->ctx = ctx_for_gpu(s->gpu_id);
+    if (!s->ctx) s->ctx = ctx_new_for_gpu(s->gpu_id);
     if (!s->ctx) { g_free(blob); GST_ERROR_OBJECT(s, "no HIP device %u", s->gpu_id); return FALSE; }
-    g_mutex_lock(&ctx_lock);
     rc = covahip_blobnet_load(s->ctx, blob, len, s->h, s->w, (int)s->timestep, 1);
-    g_mutex_unlock(&ctx_lock);
     g_free(blob);
     if (rc != COVAHIP_OK) { GST_ERROR_OBJECT(s, "covahip_blobnet_load: %s", covahip_strerror(rc)); return FALSE; }
     s->loaded = TRUE;
@@ -241,14 +238,18 @@ static GstFlowReturn bn_transform(GstBaseTransform *bt, GstBuffer *in, GstBuffer
     if (!gst_buffer_map(out, &mo, GST_MAP_WRITE)) { gst_buffer_unmap(in, &mi); return GST_FLOW_ERROR; }
     if (mi.size < (gsize)s->w * s->h * s->timestep * 4 || mo.size < (gsize)s->w * s->h) rc = COVAHIP_ERR_OVERFLOW;
     else {
-        g_mutex_lock(&ctx_lock);
         rc = covahip_blobnet_forward(s->ctx, mi.data, 1, NULL, mo.data, COVAHIP_MEM_HOST);
-        g_mutex_unlock(&ctx_lock);
     }
     gst_buffer_unmap(out, &mo);
     gst_buffer_unmap(in, &mi);
     if (rc != COVAHIP_OK) { GST_ERROR_OBJECT(s, "covahip_blobnet_forward: %s", covahip_strerror(rc)); return GST_FLOW_ERROR; }
     return GST_FLOW_OK;
+}
+static void bn_finalize(GObject *o) {
+    GstBlobNetInfer *s = (GstBlobNetInfer *)o;
+    if (s->ctx) covahip_ctx_destroy(s->ctx);
+    g_free(s->weights);
+    G_OBJECT_CLASS(gst_blobnetinfer_parent_class)->finalize(o);
 }
 static void gst_blobnetinfer_init(GstBlobNetInfer *s) { s->timestep = 4; }
 static void gst_blobnetinfer_class_init(GstBlobNetInferClass *k) {
@@ -257,6 +258,7 @@ static void gst_blobnetinfer_class_init(GstBlobNetInferClass *k) {
     GstBaseTransformClass *b = GST_BASE_TRANSFORM_CLASS(k);
     g->set_property = bn_set_property;
     g->get_property = bn_get_property;
+    g->finalize = bn_finalize;
     g_object_class_install_property(g, BN_PROP_WEIGHTS,
         g_param_spec_string("model-weights-file", "Weights", "BlobNet weight blob (cova_amd/weights.py format)", NULL,
                             G_PARAM_READWRITE | GST_PARAM_MUTABLE_READY));
@@ -332,7 +334,7 @@ static gboolean cc_set_caps(GstBaseTransform *bt, GstCaps *in, GstCaps *out) {
     if (!gst_video_info_from_caps(&ii, in)) return FALSE;
     s->w = GST_VIDEO_INFO_WIDTH(&ii);
     s->h = GST_VIDEO_INFO_HEIGHT(&ii);
-    s->ctx = ctx_for_gpu(s->gpu_id);
+    if (!s->ctx) s->ctx = ctx_new_for_gpu(s->gpu_id);
     if (!s->ctx) { GST_ERROR_OBJECT(s, "no HIP device %u", s->gpu_id); return FALSE; }
     return TRUE;
 }
@@ -349,9 +351,7 @@ static GstFlowReturn cc_transform_ip(GstBaseTransform *bt, GstBuffer *buf) {
     gsize len;
     if (!gst_buffer_map(buf, &m, GST_MAP_READ)) return GST_FLOW_ERROR;
     if (m.size < (gsize)s->w * s->h) { gst_buffer_unmap(buf, &m); return GST_FLOW_ERROR; }
-    g_mutex_lock(&ctx_lock);
     rc = covahip_bboxcc(s->ctx, m.data, 1, s->h, s->w, (int)s->cc_threshold, s->boxes, &count, MAX_BOXES, COVAHIP_MEM_HOST);
-    g_mutex_unlock(&ctx_lock);
     gst_buffer_unmap(buf, &m);
     if (rc != COVAHIP_OK || count > MAX_BOXES) { GST_ERROR_OBJECT(s, "covahip_bboxcc failed (%d, %d boxes)", rc, count); return GST_FLOW_ERROR; }
     covahip_boxes_to_bbox(s->boxes, count, s->bboxes);
@@ -369,6 +369,7 @@ static GstFlowReturn cc_transform_ip(GstBaseTransform *bt, GstBuffer *buf) {
 }
 static void cc_finalize(GObject *o) {
     GstBboxCc *s = (GstBboxCc *)o;
+    if (s->ctx) covahip_ctx_destroy(s->ctx);
     g_free(s->boxes);
     g_free(s->bboxes);
     G_OBJECT_CLASS(gst_bboxcc_parent_class)->finalize(o);
@@ -546,12 +547,13 @@ typedef struct {
     gboolean eos[2];
     covahip_bbox *boxes;
     covahip_au_out *out;
+    int sock;          /* aggregator connection (`port` != 0; cova/tracker.rs:24-30), -1 when closed */
     GMutex lock;
 } GstCova;
 typedef struct { GstElementClass parent_class; } GstCovaClass;
 G_DEFINE_TYPE(GstCova, gst_cova, GST_TYPE_ELEMENT)
 enum { CV_PROP_0, CV_PROP_IOU, CV_PROP_MAXAGE, CV_PROP_MINHITS, CV_PROP_PORT, CV_PROP_INFER_I, CV_PROP_DEBUG, CV_PROP_ALPHA,
-       CV_PROP_BETA, CV_PROP_DROPPED, CV_PROP_DEC_DEP, CV_PROP_DEC_INF };
+       CV_PROP_BETA, CV_PROP_DROPPED, CV_PROP_DEC_DEP, CV_PROP_DEC_INF, CV_PROP_HELD };
 #define CV_CAP_OUT 65536
 
 static void cv_ensure_filter(GstCova *s) {
@@ -590,9 +592,47 @@ static void cv_get_property(GObject *o, guint id, GValue *v, GParamSpec *ps) {
         case CV_PROP_DROPPED: g_value_set_uint64(v, d); break;
         case CV_PROP_DEC_DEP: g_value_set_uint64(v, dd); break;
         case CV_PROP_DEC_INF: g_value_set_uint64(v, di); break;
+        case CV_PROP_HELD: g_value_set_uint64(v, g_hash_table_size(s->bufs)); break;
         default: G_OBJECT_WARN_INVALID_PROPERTY_ID(o, id, ps);
     }
     g_mutex_unlock(&s->lock);
+}
+/* Access units the filter has discarded are released here: the reference frees a GoP's buffers when it drops
+ * the GoP (imp.rs:268-305); without this the element would hold nearly the whole bitstream until EOS. */
+static void cv_release_dropped(GstCova *s) {
+    uint64_t ids[1024];
+    size_t n;
+    do {
+        n = 0;
+        if (covahip_gopfilter_take_dropped(s->filter, ids, 1024, &n) != COVAHIP_OK) return;
+        for (size_t i = 0; i < n; i++) g_hash_table_remove(s->bufs, GSIZE_TO_POINTER((gsize)ids[i]));
+    } while (n == 1024);
+}
+/* Finished tracks go to the aggregator as length-delimited bincode Frames (cova/tracker.rs:59-83,91-118). */
+static void cv_send_tracks(GstCova *s) {
+    int st = 0;
+    const size_t need = covahip_gopfilter_take_track_export(s->filter, NULL, 0, NULL);
+    if (!need) return;
+    guint8 *wire = g_malloc(need);
+    covahip_gopfilter_take_track_export(s->filter, wire, need, &st);
+    if (st == COVAHIP_OK && s->port != 0) {
+        if (s->sock < 0) {   /* Tracker::new connects to 127.0.0.1:port (tracker.rs:24-30) */
+            struct sockaddr_in a;
+            memset(&a, 0, sizeof a);
+            a.sin_family = AF_INET;
+            a.sin_port = htons((guint16)s->port);
+            a.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+            s->sock = socket(AF_INET, SOCK_STREAM, 0);
+            if (s->sock >= 0 && connect(s->sock, (struct sockaddr *)&a, sizeof a) != 0) { close(s->sock); s->sock = -1; }
+            if (s->sock < 0) GST_ELEMENT_WARNING(s, RESOURCE, OPEN_WRITE, ("Socket Creation Failed (port %u)", s->port), (NULL));
+        }
+        for (size_t off = 0; s->sock >= 0 && off < need;) {
+            const ssize_t w = send(s->sock, wire + off, need - off, MSG_NOSIGNAL);
+            if (w <= 0) { close(s->sock); s->sock = -1; break; }
+            off += (size_t)w;
+        }
+    }
+    g_free(wire);
 }
 /* Turns the access units the filter released into BufferLists and pushes them (imp.rs:293-303). */
 static GstFlowReturn cv_push_out(GstCova *s, size_t n) {
@@ -644,6 +684,8 @@ static GstFlowReturn cv_sink_mask_chain(GstPad *pad, GstObject *parent, GstBuffe
         g_mutex_lock(&s->lock);
         cv_ensure_filter(s);
         rc = covahip_gopfilter_push_boxes(s->filter, s->boxes, n, GST_BUFFER_PTS(buf), s->out, CV_CAP_OUT, &nout);
+        cv_release_dropped(s);
+        cv_send_tracks(s);
         ret = rc == COVAHIP_OK ? cv_push_out(s, nout) : GST_FLOW_ERROR;
         g_mutex_unlock(&s->lock);
     }
@@ -656,8 +698,11 @@ static gboolean cv_both_eos(GstCova *s, GstEvent *ev) {
     g_mutex_lock(&s->lock);
     cv_ensure_filter(s);
     covahip_gopfilter_eos(s->filter, s->out, CV_CAP_OUT, &nout);
+    cv_release_dropped(s);
+    cv_send_tracks(s);
+    if (s->sock >= 0) { shutdown(s->sock, SHUT_RDWR); close(s->sock); s->sock = -1; }   /* tracker.rs:120-124 */
     cv_push_out(s, nout);
-    g_hash_table_remove_all(s->bufs);  /* everything still held is "dropped" */
+    g_hash_table_remove_all(s->bufs);
     g_mutex_unlock(&s->lock);
     return gst_pad_push_event(s->src, ev);
 }
@@ -688,6 +733,7 @@ static gboolean cv_sink_query(GstPad *pad, GstObject *parent, GstQuery *q) {
 static void cv_finalize(GObject *o) {
     GstCova *s = (GstCova *)o;
     if (s->filter) covahip_gopfilter_free(s->filter);
+    if (s->sock >= 0) close(s->sock);
     g_hash_table_destroy(s->bufs);
     g_free(s->boxes);
     g_free(s->out);
@@ -696,6 +742,7 @@ static void cv_finalize(GObject *o) {
 static void gst_cova_init(GstCova *s) {
     GstElementClass *k = GST_ELEMENT_GET_CLASS(s);
     covahip_gopfilter_default_cfg(&s->cfg);
+    s->sock = -1;
     g_mutex_init(&s->lock);
     s->bufs = g_hash_table_new_full(g_direct_hash, g_direct_equal, NULL, (GDestroyNotify)gst_buffer_unref);
     s->boxes = g_new0(covahip_bbox, MAX_BOXES);
@@ -723,7 +770,7 @@ static void gst_cova_class_init(GstCovaClass *k) {
     g_object_class_install_property(g, CV_PROP_IOU, g_param_spec_float("sort-iou", "Track IoU", "IoU threshold used by SORT", 0.f, 1.f, 0.1f, rw));
     g_object_class_install_property(g, CV_PROP_MAXAGE, g_param_spec_uint("sort-maxage", "Track Max Age", "Max age parameter used by SORT", 0, G_MAXUINT, 30, rw));
     g_object_class_install_property(g, CV_PROP_MINHITS, g_param_spec_uint("sort-minhits", "Track Min Hits", "Min hits parameter used by SORT", 0, G_MAXUINT, 30, rw));
-    g_object_class_install_property(g, CV_PROP_PORT, g_param_spec_uint("port", "Port", "TCP port number for attatching to Aggregator (0: disabled; export not built here)", 0, G_MAXUINT, 0, rw));
+    g_object_class_install_property(g, CV_PROP_PORT, g_param_spec_uint("port", "Port", "TCP port number for attatching to Aggregator (0: disabled)", 0, G_MAXUINT, 0, rw));
     g_object_class_install_property(g, CV_PROP_INFER_I, g_param_spec_boolean("infer-i", "[DEPRECATED] Infer I frame", "[DEPRECATED] Run inference on I frames", FALSE, rw));
     g_object_class_install_property(g, CV_PROP_DEBUG, g_param_spec_boolean("debug", "Debug", "Run in debug mode", FALSE, rw));
     /* the reference declares 30 as the ParamSpec default of alpha/beta but initialises the struct with 0 */
@@ -732,6 +779,8 @@ static void gst_cova_class_init(GstCovaClass *k) {
     g_object_class_install_property(g, CV_PROP_DROPPED, g_param_spec_uint64("dropped", "Dropped frame counts", "Dropped frame counts", 0, G_MAXUINT64, 0, G_PARAM_READABLE));
     g_object_class_install_property(g, CV_PROP_DEC_DEP, g_param_spec_uint64("decoded-dependency", "Decoded for dependency counts", "Number of decoded frames for dependency", 0, G_MAXUINT64, 0, G_PARAM_READABLE));
     g_object_class_install_property(g, CV_PROP_DEC_INF, g_param_spec_uint64("decoded-inference", "Decoded for inference counts", "Number of decoded frames for inference", 0, G_MAXUINT64, 0, G_PARAM_READABLE));
+    /* not in the reference: how many encoded access units the element holds right now (bounded by the GoP window) */
+    g_object_class_install_property(g, CV_PROP_HELD, g_param_spec_uint64("held-buffers", "Held buffers", "Encoded access units currently buffered", 0, G_MAXUINT64, 0, G_PARAM_READABLE));
     gst_element_class_set_static_metadata(e, "CoVA Filter", "Filter/Video",
                                           "Filter optimal frames to decode using SORT on extracted masks (covahip)", "covahip");
     gst_element_class_add_pad_template(e, gst_pad_template_new("src", GST_PAD_SRC, GST_PAD_ALWAYS, gst_caps_new_any()));

@@ -102,7 +102,12 @@ int covahip_profile_read(covahip_ctx *ctx, covahip_kernel_time *out, int cap, in
  *
  * weights: blob in the format of cova_amd/weights.py (64-byte header + fp32 payload).
  * h_mb x w_mb: macroblock grid (e.g. 68x120 for 1080p, 45x80 for 720p); t must be 4.
- * max_batch sizes the activation workspace held in HBM by the ctx.               */
+ * max_batch sizes the activation workspace held in HBM by the ctx.
+ * Limits of the kernels, all checked HERE (COVAHIP_ERR_UNSUPPORTED), never at forward time:
+ *   16 <= h_mb, w_mb <= 1024; w_mb a multiple of 4 (the first level reads 16-byte groups of four
+ *   macroblocks); one band of every level must fit the 160 KB of LDS of a CU (holds far beyond 4K grids).
+ * A ctx holds ONE model: loading again replaces it.  Use one ctx per model (element instance).
+ * A failed load leaves the ctx without a model (later calls return COVAHIP_ERR_NOT_LOADED).  */
 int covahip_blobnet_load(covahip_ctx *ctx, const void *weights, size_t weights_bytes, int h_mb, int w_mb,
                          int t, int max_batch);
 /* rgba_stack: u8 [batch][t*h_mb][w_mb][4] -- metapreprocess output (row block k =
@@ -113,21 +118,8 @@ int covahip_blobnet_load(covahip_ctx *ctx, const void *weights, size_t weights_b
  * covahip_ctx_sync); synchronous for host pointers.                               */
 int covahip_blobnet_forward(covahip_ctx *ctx, const uint8_t *rgba_stack, int batch, float *logits,
                             uint8_t *mask, int mem_kind);
-/* Cross-batch pipelining of covahip_filter_forward on device pointers (default off): the bboxcc of
- * batch k runs on a second HIP stream while BlobNet of batch k+1 runs on the main one.  Results of
- * a call are complete after covahip_ctx_sync / covahip_memcpy_d2h / covahip_timer_stop (each joins
- * the second stream), exactly like any other asynchronous device-pointer call. */
-int covahip_set_pipeline(covahip_ctx *ctx, int on);
 /* Algorithmic MACs per frame of the loaded geometry. */
 int covahip_blobnet_macs_per_frame(covahip_ctx *ctx, int64_t *macs);
-/* Implementation switch: 1 = MFMA kernels, one kernel per level (default); 2 = MFMA kernels with encoder
- * levels 0 and 1 fused into one kernel (less HBM traffic, measured slower on MI355X, kept for study);
- * 0 = direct one-thread-per-output kernels (on-GPU bring-up path; also COVAHIP_BLOBNET_IMPL=naive). */
-int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl);
-/* 1: batches >= 32 are issued as two half-batches on two HIP streams (frames are independent);
- * 0 (default): one stream.  Per-kernel profiling of all kernels forces 0. */
-int covahip_blobnet_set_overlap(covahip_ctx *ctx, int on);
-
 /* ------------------------------------------------------------------- bboxcc
  * Replaces regionprops() (cova-rs/gst-plugins/src/bboxcc/process.rs:5-49): 8-connected
  * components with stats on an h x w u8 mask (non-zero = foreground), components in
@@ -139,7 +131,10 @@ typedef struct covahip_box {
 
 /* mask: u8 [batch][h][w]; boxes: [batch][max_boxes]; counts: i32 [batch] = number of
  * components that pass the filter (if > max_boxes only the first max_boxes are
- * written).  mem_kind applies to mask, boxes and counts.                          */
+ * written).  mem_kind applies to mask, boxes and counts.
+ * Limits (COVAHIP_ERR_UNSUPPORTED): w <= 256 and ceil(h/2)*ceil(w/2) <= about 6,400 2x2 blocks (the
+ * frame's union-find lives in the LDS of one CU): 1080p (68x120) and 1440p (90x160) macroblock
+ * grids fit, a 4K grid (135x240) does not.                                         */
 int covahip_bboxcc(covahip_ctx *ctx, const uint8_t *mask, int batch, int h, int w, int area_thresh,
                    covahip_box *boxes, int32_t *counts, int max_boxes, int mem_kind);
 
@@ -297,6 +292,14 @@ int covahip_gopfilter_push_boxes(covahip_gopfilter *g, const covahip_bbox *boxes
                                  covahip_au_out *out, size_t cap, size_t *n_out);
 /* Both-sinks-EOS flush (imp.rs:361-432). */
 int covahip_gopfilter_eos(covahip_gopfilter *g, covahip_au_out *out, size_t cap, size_t *n_out);
+/* Access units the filter has discarded for good since the last call (GoP leftovers of a flushed GoP, the AU
+ * popped and lost at imp.rs:167-172, everything still queued at EOS): the caller releases its buffers for
+ * these ids, as the reference frees a GoP's buffers when it drops it (imp.rs:268-305).  Call until *n < cap. */
+int covahip_gopfilter_take_dropped(covahip_gopfilter *g, uint64_t *ids, size_t cap, size_t *n);
+/* Bytes the element's tracker writes to its aggregator socket (`port`; cova/tracker.rs:59-83,91-118): one
+ * 4-byte big-endian length + bincode Frame per finished track, accumulated since the last successful call
+ * (tracks that died in push_boxes, Sort::finalize() at EOS).  Returns the size; copies and clears if it fits. */
+size_t covahip_gopfilter_take_track_export(covahip_gopfilter *g, uint8_t *out, size_t cap, int *status);
 int covahip_gopfilter_counters(const covahip_gopfilter *g, uint64_t *dropped, uint64_t *decoded_dependency,
                                uint64_t *decoded_inference);
 

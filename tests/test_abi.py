@@ -8,8 +8,8 @@ from cova_amd import _lib as L
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "covahip.h")).read()
+def _declared_symbols(header="covahip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(covahip_[a-z0-9_]+)\s*\(", text)))
 
@@ -22,6 +22,11 @@ def test_header_symbols_all_exported_and_bound():
         assert hasattr(lib, s), f"{s} declared in covahip.h but not exported"
     # and the Python binding covers exactly the declared set
     assert sorted(L.PROTOTYPES.keys()) == syms
+    # developer switches live in their own header, outside the drop-in boundary
+    dev = _declared_symbols("covahip_dev.h")
+    assert sorted(L.DEV_PROTOTYPES.keys()) == dev and not set(dev) & set(syms)
+    for s in dev:
+        assert hasattr(lib, s)
 
 
 def test_strerror_and_version():

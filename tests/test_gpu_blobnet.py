@@ -8,8 +8,9 @@ from oracle import ref
 
 pytestmark = pytest.mark.gpu
 
-# fp16 weights/activations with fp32 accumulation on the GPU vs an all-fp32 oracle:
-ATOL, RTOL = 2e-2, 1e-2
+# fp16 weights/activations with fp32 accumulation on the GPU vs an all-fp32 oracle.  Measured over 3 weight
+# seeds x 2 input seeds x 32 frames at 68x120 (test_many_seeds_at_baseline_size): max |dlogit| 8e-3.
+ATOL, RTOL = 1e-2, 5e-3
 
 
 def _check(logits, mask, ref_logits):
@@ -24,7 +25,7 @@ def _check(logits, mask, ref_logits):
     return float(err.max())
 
 
-@pytest.mark.parametrize("impl", ["naive", "mfma", "mfma_fused01"])
+@pytest.mark.parametrize("impl", ["mfma", "mfma_fused01"])
 @pytest.mark.parametrize("hw", [(68, 120), (67, 120), (45, 80), (35, 60)])
 def test_logits_match_oracle(ctx, weights_flat, hw, impl):
     h, w = hw
@@ -51,22 +52,44 @@ def test_alpha_channel_ignored_and_clip(ctx, weights_flat):
     np.testing.assert_array_equal(l0, l2)
 
 
-@pytest.mark.parametrize("impl", ["mfma", "mfma_fused01"])
-def test_negative_bn_gamma(ctx, impl):
-    """BN runs after ReLU and before max-pool; a negative gamma must not commute with the max."""
+def _mixed_gamma_weights(seed):
+    """Every second BN gamma of every encoder level negative: the ALLPOS=false kernel variants."""
     from cova_amd import weights as W
-    wts = W.unflatten(W.random_init(77))
+    wts = W.unflatten(W.random_init(seed))
     for i in range(4):
         g = wts[f"enc{i}.bn.gamma"]
         g[::2] *= -1.0
-    flat = W.flatten(wts)
-    h, w = 45, 80
-    stack = synth.stacked_batch(2, h, w, seed=21)
-    net = BlobNetInfer(ctx, flat, h, w, max_batch=2)
+    return W.flatten(wts)
+
+
+@pytest.mark.parametrize("impl", ["mfma", "mfma_fused01"])
+@pytest.mark.parametrize("hw,b", [((68, 120), 16), ((67, 120), 16), ((45, 80), 2)])
+def test_negative_bn_gamma(ctx, impl, hw, b):
+    """BN runs after ReLU and before max-pool; a negative gamma must not commute with the max
+    (encoder.py:61-66).  A trained model with one negative gamma per level takes these kernels."""
+    flat = _mixed_gamma_weights(77)
+    h, w = hw
+    stack = synth.stacked_batch(b, h, w, seed=21, streams=4)
+    net = BlobNetInfer(ctx, flat, h, w, max_batch=b)
     net.set_impl(impl)
     logits, mask = net.infer(stack)
     ref_logits, _ = ref.blobnet_forward(flat, stack, h, w)
     _check(logits, mask, ref_logits)
+
+
+@pytest.mark.parametrize("wseed", [1234, 7, 2025])
+@pytest.mark.parametrize("iseed", [42, 4242])
+def test_many_seeds_at_baseline_size(ctx, wseed, iseed):
+    """68x120 (BASELINE size): 32 frames x 3 weight seeds x 2 input seeds against the oracle."""
+    from cova_amd import weights as W
+    flat = W.random_init(wseed)
+    h, w = 68, 120
+    stack = synth.stacked_batch(32, h, w, seed=iseed, streams=4)
+    net = BlobNetInfer(ctx, flat, h, w, max_batch=32)
+    logits, mask = net.infer(stack)
+    ref_logits, _ = ref.blobnet_forward(flat, stack, h, w)
+    err = _check(logits, mask, ref_logits)
+    print(f"weights {wseed} inputs {iseed}: max |dlogit| = {err:.4g}")
 
 
 def test_batch_independence_and_full_batch(ctx, weights_flat):
@@ -97,52 +120,6 @@ def test_fused_filter_matches_separate(ctx, weights_flat):
             np.testing.assert_array_equal(boxes[i, :n][f], rb[i, :n][g])
     _, mask2 = net.infer(stack)
     np.testing.assert_array_equal(mask, mask2)
-
-
-def test_pipelined_device_path_matches_unpipelined(ctx, weights_flat):
-    """covahip_filter_forward on device pointers pipelines bboxcc(k) behind BlobNet(k+1) on a second
-    stream; after a sync every step's boxes must equal the unpipelined result, also when consecutive
-    steps reuse the same mask / box buffers with different inputs."""
-    from cova_amd import _lib as L
-    h, w, b, mb = 68, 120, 64, 2048
-    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=b)
-    stacks = [synth.stacked_batch(b, h, w, seed=100 + k, streams=4) for k in range(3)]
-    d_stack = [ctx.malloc(s.nbytes) for s in stacks]
-    for d, s in zip(d_stack, stacks):
-        ctx.h2d(d, s)
-    d_boxes, d_counts, d_mask = ctx.malloc(b * mb * 20), ctx.malloc(b * 4), ctx.malloc(b * h * w)
-
-    def run(pipeline):
-        ctx.set_pipeline(pipeline)
-        res = []
-        for rep in range(2):
-            for k in range(3):
-                net.filter_device(d_stack[k], b, 1, d_boxes, d_counts, mb, d_mask)
-                if k == 2 or not pipeline:      # pipelined: let two steps overlap before reading back
-                    pass
-                boxes = np.zeros((b, mb), dtype=L.BOX_DTYPE)
-                counts = np.zeros(b, dtype=np.int32)
-                ctx.d2h(counts, d_counts)        # joins the second stream
-                ctx.d2h(boxes, d_boxes)
-                res.append((counts.copy(), boxes.copy()))
-        return res
-
-    ref_res = run(False)
-    pip_res = run(True)
-    for (c0, b0), (c1, b1) in zip(ref_res, pip_res):
-        np.testing.assert_array_equal(c0, c1)
-        for i in range(b):
-            np.testing.assert_array_equal(b0[i, :c0[i]], b1[i, :c1[i]])
-    # back-to-back steps without reading in between: only the last result is observable, and it is right
-    ctx.set_pipeline(True)
-    for k in (0, 1, 2, 0, 1):
-        net.filter_device(d_stack[k], b, 1, d_boxes, d_counts, mb, d_mask)
-    ctx.sync()
-    counts = np.zeros(b, dtype=np.int32)
-    ctx.d2h(counts, d_counts)
-    np.testing.assert_array_equal(counts, ref_res[1][0])
-    for p in d_stack + [d_boxes, d_counts, d_mask]:
-        ctx.free(p)
 
 
 def test_fused_levels_match_per_level_kernels_bitwise(ctx, weights_flat):

@@ -1,0 +1,110 @@
+"""BASELINE config 4 on synthetic streams: the whole filter chain
+    metapreprocess -> BlobNet -> maskcopy -> bboxcc -> sorttracker / cova
+(pipeline/cova/pipeline.py:104-261, cova/imp.rs:90-317) over several multiplexed streams on the GPU, compared
+stage by stage with the same chain on the oracle (oracle/ref.py + oracle/sort_ref.py)."""
+import numpy as np
+import pytest
+
+from cova_amd import _lib as L
+from cova_amd import elements as E
+from cova_amd import synth
+from oracle import ref
+from oracle import sort_ref as R
+
+pytestmark = pytest.mark.gpu
+
+CLK = 1_000_000_000 // 30
+H, W, T = 45, 80, 4                # the grid cova's tracker is built for (cova/imp.rs:99-108)
+N_STREAMS, N_FRAMES, GOP = 4, 300, 250
+CC_THRESHOLD = 30                  # element default (bboxcc/imp.rs:16)
+SORT = dict(sort_iou=0.1, sort_maxage=10, sort_minhits=5)
+ATOL, RTOL = 1e-2, 5e-3            # tests/test_gpu_blobnet.py
+
+
+def test_four_streams_through_the_whole_chain(ctx, weights_flat):
+    # ---- metapreprocess per stream (element state in C++ behind the C-ABI) vs the oracle's stacking
+    carriers = [synth.carrier_frames(N_FRAMES, H, W, seed=900 + s, n_objects=6) for s in range(N_STREAMS)]
+    stacks, pts = [], []           # per stream: list of stacked frames and their PTS
+    for s in range(N_STREAMS):
+        mp = E.MetaPreprocess(timestep=T, gamma=1)
+        assert mp.set_caps(W * 16, H * 16) == (W, H * T)
+        out = []
+        for i in range(N_FRAMES):
+            flow, buf = mp.transform(carriers[s][i].reshape(-1))
+            if flow == E.FLOW_OK:
+                out.append((i * CLK, buf.reshape(T * H, W, 4)))
+        exp, idx = ref.metapreprocess(carriers[s].reshape(N_FRAMES, -1), H * W * 4, T, 1)
+        assert [p for p, _ in out] == [int(i) * CLK for i in idx]
+        np.testing.assert_array_equal(np.stack([b for _, b in out]).reshape(len(out), -1), exp)
+        pts.append([p for p, _ in out])
+        stacks.append(np.stack([b for _, b in out]))
+    n_out = N_FRAMES - T + 1
+    assert all(len(p) == n_out for p in pts)
+
+    # ---- nvstreammux order: frame k of every stream side by side, batches of 64 through the fused hot path
+    mux = np.stack([stacks[s][k] for k in range(n_out) for s in range(N_STREAMS)])
+    net = E.BlobNetInfer(ctx, weights_flat, H, W, max_batch=64)
+    boxes = np.zeros((len(mux), 1024), dtype=L.BOX_DTYPE)
+    counts = np.zeros(len(mux), dtype=np.int32)
+    masks = np.zeros((len(mux), H, W), dtype=np.uint8)
+    logits = np.zeros((len(mux), H, W), dtype=np.float32)
+    for b0 in range(0, len(mux), 64):
+        sl = slice(b0, min(b0 + 64, len(mux)))
+        boxes[sl], counts[sl], masks[sl] = net.filter(mux[sl], CC_THRESHOLD, max_boxes=1024, want_mask=True)
+        logits[sl], m2 = net.infer(mux[sl])
+        np.testing.assert_array_equal(masks[sl], m2)
+    # BlobNet against the oracle on every frame of every stream
+    ref_logits, _ = ref.blobnet_forward(weights_flat, mux, H, W)
+    err = np.abs(logits - ref_logits)
+    assert (err <= ATOL + RTOL * np.abs(ref_logits)).all(), err.max()
+    assert (np.abs(ref_logits[masks != (ref_logits > 0)]) <= ATOL).all()
+    # bboxcc bit-exact (set, order, statistics) against the oracle on the same masks
+    rb, rc = ref.regionprops_batch(masks, CC_THRESHOLD, 1024)
+    np.testing.assert_array_equal(counts, rc)
+    for i in range(len(mux)):
+        n = int(counts[i])
+        for f, g in (("left", "left"), ("top", "top"), ("width", "width"), ("height", "height"), ("area_px", "area")):
+            np.testing.assert_array_equal(boxes[i, :n][f], rb[i, :n][g])
+    assert counts.max() >= 1
+
+    # ---- nvstreamdemux -> per stream: bboxcc wire bytes -> sorttracker and cova, against oracle/sort_ref.py
+    total_inferred = 0
+    for s in range(N_STREAMS):
+        st = E.SortTracker(iou_threshold=SORT["sort_iou"], maxage=SORT["sort_maxage"], minhits=SORT["sort_minhits"])
+        st.set_caps(W, H)
+        cv = E.Cova(**SORT)
+        r_sort = R.Sort(SORT["sort_maxage"], SORT["sort_minhits"], SORT["sort_iou"])
+        r_cova = R.GopFilter(**SORT)
+        forwarded = []
+        for i in range(N_FRAMES):          # the encoded branch runs ahead of the mask branch
+            cv.sink_enc_chain(i, i * CLK, delta_unit=(i % GOP != 0))
+            r_cova.push_enc(i, i * CLK, 0 if i % GOP == 0 else R.DELTA_UNIT)
+        for k in range(n_out):
+            i = k * N_STREAMS + s
+            n = int(counts[i])
+            wire = E.serialize_vec(E.boxes_to_bbox(boxes[i, :n]))          # what bboxcc puts on its src pad
+            dets = [R.Bbox(float(b["left"]), float(b["top"]), float(b["width"]), float(b["height"])) for b in rb[i, :n]]
+            # sorttracker
+            dead = E.deserialize_vec(st.transform(wire, pts[s][k]))
+            exp = [b for t in r_sort.update(dets, pts[s][k]) for b in t.history]
+            assert len(dead) == len(exp)
+            for g, e in zip(dead, exp):
+                assert int(g["track_id"]) == e.track_id and int(g["timestamp"]) == e.timestamp
+                np.testing.assert_allclose([g["left"], g["top"], g["width"], g["height"]],
+                                           [e.left, e.top, e.width, e.height], rtol=1e-3, atol=1e-3)
+            # cova
+            forwarded.extend(cv.sink_mask_chain(wire, pts[s][k]))
+            r_cova.push_boxes(dets, pts[s][k])
+        fin = E.deserialize_vec(st.sink_event_eos())
+        assert len(fin) == sum(len(t.history) for t in r_sort.finalize())
+        assert cv.eos("sink_enc") is None
+        forwarded.extend(cv.eos("sink_mask"))
+        r_cova.eos()
+        assert (cv.dropped, cv.decoded_dependency, cv.decoded_inference) == (
+            r_cova.dropped, r_cova.decoded_dependency, r_cova.decoded_inference)
+        exp = [b for lst in r_cova.pushed for b in lst]
+        assert [(int(a["id"]), int(a["pts"]), int(a["flags"])) for a in forwarded] == [tuple(b) for b in exp]
+        total_inferred += cv.decoded_inference
+        cv.close()
+    print(f"chain: {len(mux)} frames, boxes/frame mean {counts.mean():.2f}, max |dlogit| {err.max():.4g}, "
+          f"frames forwarded for inference over {N_STREAMS} streams: {total_inferred}")

@@ -40,6 +40,28 @@ def test_bad_weight_blobs_rejected(weights_flat):
     ctx.close()
 
 
+def test_failed_load_leaves_no_model_and_limits_are_checked_at_load(weights_flat):
+    """A load that fails half way (workspace OOM) must not leave a half-built model behind; geometry the kernels
+    cannot run (width not a multiple of 4) is rejected by the load, not by the first forward."""
+    ctx = Context(0)
+    lib = L.lib()
+    blob = W.to_bytes(weights_flat)
+    assert lib.covahip_blobnet_load(ctx.handle, blob, len(blob), 45, 80, 4, 2) == 0
+    assert lib.covahip_blobnet_load(ctx.handle, blob, len(blob), 68, 120, 4, 1 << 22) == 3       # ~1 TB of workspace
+    stack = synth.stacked_batch(1, 68, 120, seed=1)
+    mask = np.zeros((1, 68, 120), np.uint8)
+    assert lib.covahip_blobnet_forward(ctx.handle, stack.ctypes.data, 1, None, mask.ctypes.data, L.MEM_HOST) == 4
+    boxes = np.zeros((1, 16), dtype=L.BOX_DTYPE)
+    counts = np.zeros(1, dtype=np.int32)
+    assert lib.covahip_filter_forward(ctx.handle, stack.ctypes.data, 1, 1, boxes.ctypes.data, counts.ctypes.data, 16,
+                                      None, None, L.MEM_HOST) == 4
+    assert lib.covahip_blobnet_load(ctx.handle, blob, len(blob), 45, 53, 4, 1) == 5             # 854 / 16 = 53 macroblocks
+    assert lib.covahip_blobnet_forward(ctx.handle, stack.ctypes.data, 1, None, mask.ctypes.data, L.MEM_HOST) == 4
+    assert lib.covahip_blobnet_load(ctx.handle, blob, len(blob), 68, 120, 4, 1) == 0            # and the ctx is still usable
+    assert lib.covahip_blobnet_forward(ctx.handle, stack.ctypes.data, 1, None, mask.ctypes.data, L.MEM_HOST) == 0
+    ctx.close()
+
+
 def test_bboxcc_geometry_limits_and_empty_batch(ctx):
     lib = L.lib()
     cc = BboxCc(ctx, cc_threshold=1, max_boxes=16)

@@ -150,6 +150,7 @@ def test_cova_element(tmp_path, props, kw):
     assert (info["dropped"], info["decoded_dependency"], info["decoded_inference"]) == \
         (r.dropped, r.decoded_dependency, r.decoded_inference)
     assert info["eos"] == 1                                  # EOS forwarded once both sinks saw it
+    assert info["held_end"] == 0
     outs = _read(tmp_path / "out.rec")
     lists, cur = [], None
     for kind, pts, flags, payload in outs:
@@ -164,6 +165,27 @@ def test_cova_element(tmp_path, props, kw):
     for got, exp in zip(lists, r.pushed):
         for (au, pts, discont, droppable), (eid, epts, eflags) in zip(got, exp):
             assert pts == epts and discont == bool(eflags & R.DISCONT) and droppable == bool(eflags & R.DROPPABLE)
+
+
+def test_cova_element_releases_dropped_access_units(tmp_path):
+    """Most access units are dropped by design; the element must release them when the filter discards them (the
+    reference frees a dropped GoP's buffers, cova/imp.rs:268-305), not keep the whole bitstream until EOS."""
+    n, gop, lead = 1500, 250, 30
+    dets = [[(5 + 0.4 * (i - 10), 5 + 0.2 * (i - 10), 6, 6)] if 10 <= i <= 120 else
+            ([(60 - 0.05 * (i - 900), 30, 8, 5)] if 900 <= i <= 1300 else []) for i in range(n)]
+    recs = []
+    for i in range(n + lead):
+        if i < n:
+            recs.append(("E", i * CLK, 0 if i % gop == 0 else 1, struct.pack("<I", i)))
+        j = i - lead
+        if 0 <= j < n:
+            recs.append(("M", j * CLK, 0, E.serialize_vec(_bb(dets[j]))))
+    recs += [("e", 0, 0, b""), ("m", 0, 0, b"")]
+    _write(tmp_path / "in.rec", recs)
+    info = _run(["cova", "sort-maxage=10 sort-minhits=5", str(tmp_path / "in.rec"), str(tmp_path / "out.rec")], tmp_path)
+    assert info["eos"] == 1 and info["held_end"] == 0
+    assert info["held_max"] <= 2 * gop + lead + 60 < n       # bounded by the GoP window, not by the stream length
+    assert info["dropped"] > n // 2
 
 
 @pytest.mark.gpu

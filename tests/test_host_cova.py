@@ -92,3 +92,46 @@ def test_delta_unit_before_any_key_frame_is_an_error():
     c = E.Cova()
     with pytest.raises(L.CovahipError):
         c.sink_enc_chain(0, 0, delta_unit=True)
+
+
+def test_every_access_unit_is_forwarded_or_reported_dropped_and_tracks_are_exported():
+    """The element keeps one buffer per access unit it has handed to the filter: the filter must give every id
+    back, either in an output list or through take_dropped (the reference frees a dropped GoP's buffers,
+    cova/imp.rs:268-305), and nothing may stay referenced for longer than the GoP window."""
+    import struct
+    n, gop = 1500, 250
+    objects = [(10, 120, 5, 5, 0.4, 0.2, 6, 6), (400, 620, 60, 30, -0.3, 0.0, 8, 5), (900, 1300, 10, 40, 0.2, -0.1, 7, 7)]
+    dets = _timeline(n, gop, objects)
+    c = E.Cova(sort_maxage=10, sort_minhits=5, sort_iou=0.1)
+    forwarded, dropped, held_max = [], [], 0
+    lead = 30
+    wire = b""
+    for i in range(n + lead):
+        if i < n:
+            c.sink_enc_chain(i, i * CLK, delta_unit=(i % gop != 0))
+        j = i - lead
+        if 0 <= j < n:
+            forwarded.extend(int(a["id"]) for a in c.sink_mask_chain(E.serialize_vec(_bb(dets[j])), j * CLK))
+            dropped.extend(c.take_dropped())
+            wire += c.take_track_export()
+        held_max = max(held_max, min(i, n - 1) + 1 - len(forwarded) - len(dropped))
+    c.eos("sink_enc")
+    forwarded.extend(int(a["id"]) for a in c.eos("sink_mask"))
+    dropped.extend(c.take_dropped())
+    wire += c.take_track_export()
+    assert sorted(forwarded + dropped) == list(range(n))          # every id exactly once
+    assert len(dropped) == c.dropped + (n - c.dropped - c.decoded_dependency - c.decoded_inference)
+    assert held_max <= 2 * gop + lead + 60                        # bounded by the GoP window, not by the stream length
+    # the three tracks left the tracker as length-delimited bincode Frames with the tracker's range_start
+    frames, off = [], 0
+    while off < len(wire):
+        (fl,) = struct.unpack_from(">I", wire, off)
+        frames.append(wire[off + 4:off + 4 + fl])
+        off += 4 + fl
+    assert off == len(wire) and len(frames) == 3
+    for f in frames:
+        range_start, oldest, nb = struct.unpack_from("<QQQ", f, 0)
+        assert range_start == 0 and nb >= 5
+    a = E.Associator([0])
+    for f in frames:
+        a.push_track_frame(f)                                     # the aggregator side parses them (track.rs:47-66)
