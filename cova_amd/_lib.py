@@ -132,6 +132,7 @@ PROTOTYPES = {
 # developer switches (include/covahip_dev.h): bound for tools/ and tests/, not part of the drop-in boundary
 DEV_PROTOTYPES = {
     "covahip_blobnet_set_impl": (C.c_int, [_P, C.c_int]),
+    "covahip_bboxcc_set_wave_cap": (C.c_int, [_P, C.c_int]),
 }
 
 _lib = None

@@ -30,43 +30,130 @@
 #include <vector>
 
 #include "bboxcc_body.h"
+#include "bboxcc_wave.h"
+#include "covahip_dev.h"
 #include "internal.h"
 
 namespace {
 
 using namespace ccbody;
 
+// ---- one 1,024-thread workgroup per frame (any shape that fits LDS; also the overflow pass of the wave kernel)
+// list == nullptr: frame = blockIdx.x.  Otherwise the launch is persistent over the *n_list frame indices in list.
 __global__ __launch_bounds__(CC_THREADS) void bboxcc_kernel(const uint8_t *__restrict__ masks, CcGeom g,
                                                              int area_thresh, covahip_box *__restrict__ boxes,
-                                                             int32_t *__restrict__ counts, int max_boxes) {
+                                                             int32_t *__restrict__ counts, int max_boxes,
+                                                             const int32_t *__restrict__ list,
+                                                             const int32_t *__restrict__ n_list) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int frame = blockIdx.x;
-    bboxcc_frame(masks + (size_t)frame * g.H * g.W, smem, g, area_thresh, boxes + (size_t)frame * max_boxes,
-                 counts + frame, max_boxes, threadIdx.x);
+    if (!list) {
+        const int frame = blockIdx.x;
+        bboxcc_frame(masks + (size_t)frame * g.H * g.W, smem, g, area_thresh, boxes + (size_t)frame * max_boxes,
+                     counts + frame, max_boxes, threadIdx.x);
+        return;
+    }
+    const int n = *n_list;
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        const int frame = list[k];
+        bboxcc_frame(masks + (size_t)frame * g.H * g.W, smem, g, area_thresh, boxes + (size_t)frame * max_boxes,
+                     counts + frame, max_boxes, threadIdx.x);
+        __syncthreads();   // the next frame reuses the LDS region
+    }
+}
+
+// ---- one WAVE per frame (bboxcc_wave.h): WV_WAVES frames per workgroup, no workgroup barrier at all
+constexpr int WV_WAVES = 4;
+__global__ __launch_bounds__(WV_WAVES * 64) void bboxcc_wave_kernel(const uint8_t *__restrict__ masks, ccwave::WvGeom g, int batch,
+                                                                    int area_thresh, covahip_box *__restrict__ boxes,
+                                                                    int32_t *__restrict__ counts, int max_boxes,
+                                                                    int32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_n) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frame = blockIdx.x * WV_WAVES + wave;
+    if (frame >= batch) return;
+    const bool done = ccwave::frame_wave(masks + (size_t)frame * g.H * g.W, smem + (size_t)wave * g.wave_bytes, g, area_thresh,
+                                         boxes + (size_t)frame * max_boxes, counts + frame, max_boxes, lane);
+    if (!done && lane == 0) ovf_list[atomicAdd(ovf_n, 1)] = frame;   // more runs than the LDS region holds
+}
+
+template <typename K>
+int open_lds(covahip_ctx *ctx, K kernel, size_t lds) {
+    if (lds <= 64 * 1024) return COVAHIP_OK;
+    static std::mutex mu;
+    static std::vector<std::pair<int, const void *>> opened;
+    const void *fn = reinterpret_cast<const void *>(kernel);
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto &o : opened)
+        if (o.first == ctx->device && o.second == fn) return COVAHIP_OK;
+    COVAHIP_CHECK_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    opened.emplace_back(ctx->device, fn);
+    return COVAHIP_OK;
 }
 
 }  // namespace
 
+// Launch plan.  Shapes the wave kernel takes (W a multiple of 8, H and W <= 128, 8-byte aligned frames) go to it:
+//   * small batches (a few frames per CU): every wave gets the worst-case run capacity (one run per 2x2 block),
+//     nothing can overflow, one launch;
+//   * large batches: 256 runs per wave (7 KB of LDS -> about twenty frames in flight per CU); frames with more
+//     runs -- noise-like masks -- are collected in an overflow list that a second, persistent launch of the
+//     workgroup-per-frame kernel drains (it exits at once when the list is empty).
+// Everything else runs the workgroup-per-frame kernel.
 int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, int h, int w, int area_thresh,
                           covahip_box *d_boxes, int32_t *d_counts, int max_boxes) {
     if (batch == 0) return COVAHIP_OK;
     CcGeom g;
     const size_t lds = cc_plan(h, w, g);   // shapes the kernel assumes, checked on the host before any launch
-    if (!lds) return COVAHIP_ERR_UNSUPPORTED;
-    if (lds > 64 * 1024) {   // the attribute is per device and sticky: set it once per device
-        static std::mutex mu;
-        static std::vector<int> opened;
-        std::lock_guard<std::mutex> lock(mu);
-        if (std::find(opened.begin(), opened.end(), ctx->device) == opened.end()) {
-            COVAHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bboxcc_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-            opened.push_back(ctx->device);
+    const int num_cu = ctx->props.multiProcessorCount;
+    ccwave::WvGeom wg;
+    const int nb = ((h + 1) / 2) * ((w + 1) / 2);
+    int cap = ctx->cc_wave_cap;            // developer override: > 0 capacity, < 0 wave kernel off, 0 automatic
+    // a few frames per CU: the workgroup kernel finishes a frame sooner than a single wave does (9.5 vs 13.5 us at
+    // b = 256), and there is nothing to overlap it with
+    if (cap == 0) cap = (lds && batch <= 3 * num_cu) ? -1 : (lds ? 128 : nb);
+    cap = std::min(cap, nb);
+    const bool aligned = (reinterpret_cast<uintptr_t>(d_mask) & 7) == 0 && (((size_t)h * w) & 7) == 0;
+    if (cap > 0 && aligned && ccwave::wv_plan(h, w, cap, wg) &&
+        (size_t)WV_WAVES * wg.wave_bytes <= 160 * 1024 - 64 && (cap >= nb || lds)) {
+        const bool can_overflow = cap < nb;
+        if (can_overflow) {
+            int rc = covahip_ensure_buffer(ctx, &ctx->cc_ovf, &ctx->cc_ovf_bytes, ((size_t)batch + 1) * sizeof(int32_t));
+            if (rc) return rc;
+            COVAHIP_CHECK_HIP(ctx, hipMemsetAsync(ctx->cc_ovf, 0, sizeof(int32_t), ctx->stream));
         }
+        int32_t *ovf_n = (int32_t *)ctx->cc_ovf, *ovf_list = ovf_n ? ovf_n + 1 : nullptr;
+        const size_t wlds = (size_t)WV_WAVES * wg.wave_bytes;
+        int rc = open_lds(ctx, bboxcc_wave_kernel, wlds);
+        if (rc) return rc;
+        {
+            ProfScope ps(ctx, "bboxcc_wave_kernel");
+            hipLaunchKernelGGL(bboxcc_wave_kernel, dim3((batch + WV_WAVES - 1) / WV_WAVES), dim3(WV_WAVES * 64), wlds, ctx->stream,
+                               d_mask, wg, batch, area_thresh, d_boxes, d_counts, max_boxes, ovf_list, ovf_n);
+            COVAHIP_CHECK_HIP(ctx, hipGetLastError());
+        }
+        if (can_overflow) {
+            rc = open_lds(ctx, bboxcc_kernel, lds);
+            if (rc) return rc;
+            ProfScope ps(ctx, "bboxcc_kernel");
+            hipLaunchKernelGGL(bboxcc_kernel, dim3(std::min(batch, 2 * num_cu)), dim3(CC_THREADS), lds, ctx->stream, d_mask, g,
+                               area_thresh, d_boxes, d_counts, max_boxes, (const int32_t *)ovf_list, (const int32_t *)ovf_n);
+            COVAHIP_CHECK_HIP(ctx, hipGetLastError());
+        }
+        return COVAHIP_OK;
     }
+    if (!lds) return COVAHIP_ERR_UNSUPPORTED;
+    int rc = open_lds(ctx, bboxcc_kernel, lds);
+    if (rc) return rc;
     ProfScope ps(ctx, "bboxcc_kernel");
     hipLaunchKernelGGL(bboxcc_kernel, dim3(batch), dim3(CC_THREADS), lds, ctx->stream, d_mask, g, area_thresh,
-                       d_boxes, d_counts, max_boxes);
+                       d_boxes, d_counts, max_boxes, (const int32_t *)nullptr, (const int32_t *)nullptr);
     COVAHIP_CHECK_HIP(ctx, hipGetLastError());
+    return COVAHIP_OK;
+}
+
+extern "C" int covahip_bboxcc_set_wave_cap(covahip_ctx *ctx, int cap) {
+    if (!ctx) return COVAHIP_ERR_INVALID_ARG;
+    ctx->cc_wave_cap = cap;
     return COVAHIP_OK;
 }
 

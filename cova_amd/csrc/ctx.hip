@@ -77,6 +77,7 @@ void covahip_ctx_destroy(covahip_ctx *ctx) {
     if (ctx->stage_in) hipFree(ctx->stage_in);
     if (ctx->stage_out) hipFree(ctx->stage_out);
     if (ctx->cc_scratch) hipFree(ctx->cc_scratch);
+    if (ctx->cc_ovf) hipFree(ctx->cc_ovf);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -39,6 +39,10 @@ struct covahip_ctx {
     // bboxcc scratch for the fused path (mask / boxes / counts on device)
     void *cc_scratch = nullptr;
     size_t cc_scratch_bytes = 0;
+    // bboxcc wave kernel: overflow list (count + frame indices) and the developer override of its run capacity
+    void *cc_ovf = nullptr;
+    size_t cc_ovf_bytes = 0;
+    int cc_wave_cap = 0;
     covahip_blobnet *blobnet = nullptr;
 };
 

@@ -300,6 +300,10 @@ class BboxCc:
         self.ctx, self.cc_threshold, self.max_boxes = ctx, cc_threshold, max_boxes
         self._lib = L.lib()
 
+    def set_wave_cap(self, cap: int):
+        """Developer switch (include/covahip_dev.h): > 0 run capacity of the wave-per-frame kernel, < 0 workgroup kernel only, 0 auto."""
+        L.check(self._lib.covahip_bboxcc_set_wave_cap(self.ctx.handle, cap), "covahip_bboxcc_set_wave_cap")
+
     def regionprops(self, masks: np.ndarray):
         """masks u8 [B][H][W] (host) -> (boxes [B][max_boxes], counts [B])."""
         masks = np.ascontiguousarray(masks, dtype=np.uint8)

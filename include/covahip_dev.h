@@ -15,6 +15,10 @@ extern "C" {
  * one kernel.  Both compute identical bits (tests/test_gpu_blobnet.py); the library picks its default. */
 int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl);
 
+/* bboxcc kernel choice: cap > 0 = run capacity of the wave-per-frame kernel (frames with more runs take the
+ * overflow pass), cap < 0 = workgroup-per-frame kernel only, 0 = automatic (default). */
+int covahip_bboxcc_set_wave_cap(covahip_ctx *ctx, int cap);
+
 #ifdef __cplusplus
 }
 #endif

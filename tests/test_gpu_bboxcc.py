@@ -10,11 +10,25 @@ from tests.ccl_cases import hand_cases
 pytestmark = pytest.mark.gpu
 
 
+# kernel choice (include/covahip_dev.h): automatic, wave-per-frame kernel with a run capacity small enough that dense
+# frames take the overflow pass, workgroup-per-frame kernel only
+WAVE_CAPS = (0, 24, -1)
+
+
 def _compare(ctx, masks, thresh, max_boxes=None):
+    for cap in WAVE_CAPS:
+        _compare_one(ctx, masks, thresh, max_boxes, cap)
+
+
+def _compare_one(ctx, masks, thresh, max_boxes, cap):
     b, h, w = masks.shape
     max_boxes = max_boxes or ((h + 1) // 2) * ((w + 1) // 2)
     cc = BboxCc(ctx, cc_threshold=thresh, max_boxes=max_boxes)
-    boxes, counts = cc.regionprops(masks)
+    cc.set_wave_cap(cap)
+    try:
+        boxes, counts = cc.regionprops(masks)
+    finally:
+        cc.set_wave_cap(0)
     rboxes, rcounts = ref.regionprops_batch(masks, thresh, max_boxes)
     np.testing.assert_array_equal(counts, rcounts)
     for i in range(b):

@@ -31,9 +31,12 @@ def make_masks(kind, n, seed=0):
 def main():
     ctx = Context(0)
     out = []
-    for kind in ("blobs", "noise", "p05", "p50"):
+    cap = int(os.environ.get("SWEEP_CAP", "0"))        # developer switch: wave-kernel run capacity (0 auto, < 0 off)
+    kinds = os.environ.get("SWEEP_KINDS", "blobs,noise,p05,p50").split(",")
+    batches = [int(x) for x in os.environ.get("SWEEP_BATCHES", "256,1024,4096,16384,65536").split(",")]
+    for kind in kinds:
         base = make_masks(kind, 256)
-        for B in (256, 1024, 4096, 16384, 65536):
+        for B in batches:
             masks = np.tile(base, (B // 256, 1, 1))
             d_m = ctx.malloc(masks.nbytes)
             ctx.h2d(d_m, masks)
@@ -41,6 +44,7 @@ def main():
             d_b = ctx.malloc(B * maxb * 20)
             d_c = ctx.malloc(B * 4)
             cc = BboxCc(ctx, cc_threshold=1, max_boxes=maxb)
+            cc.set_wave_cap(cap)
             for _ in range(3):
                 cc.regionprops_device(d_m, B, H, W, d_b, d_c)
             ctx.sync()
@@ -51,13 +55,14 @@ def main():
             ctx.timer_stop(1)
             us = ctx.timer_ms(1) / reps * 1e3
             gbs = B * H * W / (us * 1e-6) / 1e9
-            out.append({"kind": kind, "batch": B, "us": round(us, 1), "ns_per_frame": round(us * 1e3 / B, 1),
+            out.append({"kind": kind, "batch": B, "wave_cap": cap, "us": round(us, 1), "ns_per_frame": round(us * 1e3 / B, 1),
                         "GBps": round(gbs, 1), "frac_hbm_peak": round(gbs / 8000, 4)})
             print(out[-1], flush=True)
             for p in (d_m, d_b, d_c):
                 ctx.free(p)
-    json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
-                                     "bboxcc_sweep.json"), "w"), indent=1)
+    path = os.environ.get("SWEEP_OUT", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
+                                                    "bboxcc_sweep.json"))
+    json.dump(out, open(path, "w"), indent=1)
 
 
 if __name__ == "__main__":
