@@ -17,7 +17,13 @@ pytestmark = pytest.mark.gpu
 CLK = 1_000_000_000 // 30
 H, W, T = 45, 80, 4                # the grid cova's tracker is built for (cova/imp.rs:99-108)
 N_STREAMS, N_FRAMES, GOP = 4, 300, 250
-CC_THRESHOLD = 30                  # element default (bboxcc/imp.rs:16)
+# cc-threshold: 8 leaves one to three boxes per frame of this random-weight net (the element default 30 leaves almost
+# none).  It is kept that low on purpose: with ten and more boxes per frame the assignment problem of SORT gets exact
+# ties (an inactive tracker that predicts a detection exactly costs 2 - 1 = 1, the same as any non-overlapping
+# active tracker), and which of the equally cheap assignments a Kuhn-Munkres implementation returns is not defined
+# by the algorithm -- the crate the reference pins (linear_assignment @a992de6) is not in the reference tree, so
+# ties are unpinned for the product's solver and for scipy's in the oracle alike.
+CC_THRESHOLD = 8
 SORT = dict(sort_iou=0.1, sort_maxage=10, sort_minhits=5)
 
 
