@@ -87,6 +87,7 @@ PROTOTYPES = {
     "covahip_blobnet_macs_per_frame": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "covahip_bboxcc": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int]),
     "covahip_filter_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int]),
+    "covahip_filter_forward_frames": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int]),
     "covahip_boxes_to_bbox": (None, [_P, C.c_int, _P]),
     "covahip_bbox_serialize_vec": (_SZ, [_P, _SZ, _P, _SZ, C.POINTER(C.c_int)]),
     "covahip_bbox_deserialize_vec": (C.c_int, [_P, _SZ, _P, _SZ, C.POINTER(_SZ)]),

@@ -21,6 +21,12 @@ struct covahip_blobnet {
     // activations (fp16, channels-last)
     __half *act[BN_LEVELS + 1] = {};  // act[i], i=1..3: [B][T][H_i][W_i][C_i]; act[4]: [B][H_4][W_4][128] (t=0)
     __half *dact[BN_LEVELS] = {};     // dact[j], j=0..2: [B][Hd][Wd][Cout_j]
+    // carrier-frame path: pooled level-0 values per carrier frame, [frames][H_1][W_1][16] (pad row / column zero)
+    __half *pbuf = nullptr;
+    size_t pbuf_frames = 0;
+    int32_t *d_index = nullptr;       // [max_batch][4] stack -> frame index table of the call in flight
+    int32_t *h_index = nullptr;       // pinned host copy it is uploaded from
+    hipEvent_t ev_index = nullptr;    // upload of h_index done (the next call may overwrite it)
     // prepared (MFMA path) weights
     void *d_prepared = nullptr;
     size_t prepared_bytes = 0;
@@ -39,6 +45,15 @@ struct BnCcTail {
     covahip_box *boxes;   // [batch][max_boxes]
     int32_t *counts;
 };
-// d_stack == nullptr: planning only (every geometry / LDS check of the launch sequence, no kernel is launched)
-int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_stack, int batch, float *d_logits,
+// Input of a forward: either the stacked tensor [batch][T*H][W][4] (metapreprocess output), or carrier frames
+// [n_frames][H][W][4] plus, per stack, the indices of its T = 0..3 slices (device pointers all).
+// dry: planning only (every geometry / LDS check of the launch sequence, no kernel is launched).
+struct BnInput {
+    const uint8_t *stack = nullptr;
+    const uint8_t *frames = nullptr;
+    int n_frames = 0;
+    const int32_t *index = nullptr;   // i32 [batch][4]
+    bool dry = false;
+};
+int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const BnInput &in, int batch, float *d_logits,
                          uint8_t *d_mask, const BnCcTail *cc = nullptr, bool *cc_done = nullptr);

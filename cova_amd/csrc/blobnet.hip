@@ -4,6 +4,7 @@
 // Geometry follows utils/model/encoder.py:58-80 (level i -> ceil(H/2) x ceil(W/2), zero
 // row on top / zero column on the left when the pre-pool size is odd) and
 // utils/model/decoder.py:43-59 (convT output 2*in+2, crop ceil(p/2) top/left).
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -24,6 +25,10 @@ static void free_model(covahip_ctx *ctx, covahip_blobnet *m) {
         if (m->act[i]) hipFree(m->act[i]);
     for (int j = 0; j < BN_LEVELS; j++)
         if (m->dact[j]) hipFree(m->dact[j]);
+    if (m->pbuf) hipFree(m->pbuf);
+    if (m->d_index) hipFree(m->d_index);
+    if (m->h_index) hipHostFree(m->h_index);
+    if (m->ev_index) hipEventDestroy(m->ev_index);
     delete m;
 }
 
@@ -43,7 +48,7 @@ int covahip_blobnet_geometry(covahip_ctx *ctx, int *h, int *w) {
 }
 
 // BlobNet forward (+ optionally bboxcc) on device pointers, asynchronous on the ctx stream.
-static int filter_dev(covahip_ctx *ctx, const uint8_t *d_stack, int batch, float *d_logits, uint8_t *d_mask,
+static int filter_dev(covahip_ctx *ctx, const BnInput &in, int batch, float *d_logits, uint8_t *d_mask,
                       bool with_cc, int area_thresh, covahip_box *d_boxes, int32_t *d_counts, int max_boxes) {
     covahip_blobnet *m = ctx->blobnet;
     if (!m) return COVAHIP_ERR_NOT_LOADED;
@@ -51,7 +56,7 @@ static int filter_dev(covahip_ctx *ctx, const uint8_t *d_stack, int batch, float
     if (batch == 0) return COVAHIP_OK;
     BnCcTail tail{area_thresh, max_boxes, d_boxes, d_counts};
     bool cc_done = false;
-    int rc = blobnet_forward_mfma(ctx, m, d_stack, batch, d_logits, d_mask, with_cc ? &tail : nullptr, &cc_done);
+    int rc = blobnet_forward_mfma(ctx, m, in, batch, d_logits, d_mask, with_cc ? &tail : nullptr, &cc_done);
     if (rc) return rc;
     // the fused decoder tail normally runs bboxcc itself; the separate kernel is the fallback for
     // geometries whose frame does not fit its LDS plan
@@ -60,9 +65,52 @@ static int filter_dev(covahip_ctx *ctx, const uint8_t *d_stack, int batch, float
     return rc;
 }
 
+// Carrier-frame input: validates the stack -> frame table on the host (an index outside the frame array would be an
+// out-of-bounds read on the GPU), uploads it, sizes the P tensor.  stack_index == nullptr: one stream in order.
+static int prepare_frames(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_frames, int n_frames,
+                          const int32_t *stack_index, int batch, BnInput &in) {
+    if (n_frames < BN_T || n_frames > BN_T * m->max_batch) return COVAHIP_ERR_INVALID_ARG;
+    if (!stack_index && batch != n_frames - (BN_T - 1)) return COVAHIP_ERR_INVALID_ARG;
+    if (!m->d_index) {
+        COVAHIP_CHECK_HIP(ctx, hipMalloc((void **)&m->d_index, (size_t)m->max_batch * BN_T * sizeof(int32_t)));
+        COVAHIP_CHECK_HIP(ctx, hipHostMalloc((void **)&m->h_index, (size_t)m->max_batch * BN_T * sizeof(int32_t), hipHostMallocDefault));
+        COVAHIP_CHECK_HIP(ctx, hipEventCreateWithFlags(&m->ev_index, hipEventDisableTiming));
+    } else {
+        COVAHIP_CHECK_HIP(ctx, hipEventSynchronize(m->ev_index));
+    }
+    for (int b = 0; b < batch; b++)
+        for (int t = 0; t < BN_T; t++) {
+            const int32_t f = stack_index ? stack_index[b * BN_T + t] : b + (BN_T - 1) - t;
+            if (f < 0 || f >= n_frames) return COVAHIP_ERR_INVALID_ARG;
+            m->h_index[b * BN_T + t] = f;
+        }
+    COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(m->d_index, m->h_index, (size_t)batch * BN_T * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    COVAHIP_CHECK_HIP(ctx, hipEventRecord(m->ev_index, ctx->stream));
+    if (m->pbuf_frames < (size_t)n_frames) {
+        // grown in whole steps; the pad row / column of P (odd grids) is zeroed here and never written
+        const size_t want = std::min((size_t)BN_T * m->max_batch, std::max((size_t)n_frames, 2 * m->pbuf_frames));
+        const size_t bytes = want * m->lv[1].H * m->lv[1].W * m->enc_c[1] * sizeof(__half);
+        if (m->pbuf) {
+            COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            COVAHIP_CHECK_HIP(ctx, hipFree(m->pbuf));
+            m->pbuf = nullptr;
+            m->pbuf_frames = 0;
+        }
+        COVAHIP_CHECK_HIP(ctx, hipMalloc((void **)&m->pbuf, bytes));
+        COVAHIP_CHECK_HIP(ctx, hipMemsetAsync(m->pbuf, 0, bytes, ctx->stream));
+        m->pbuf_frames = want;
+    }
+    in.frames = d_frames;
+    in.n_frames = n_frames;
+    in.index = m->d_index;
+    return COVAHIP_OK;
+}
+
 int covahip_blobnet_forward_dev(covahip_ctx *ctx, const uint8_t *d_stack, int batch, float *d_logits,
                                 uint8_t *d_mask) {
-    return filter_dev(ctx, d_stack, batch, d_logits, d_mask, false, 0, nullptr, nullptr, 0);
+    BnInput in;
+    in.stack = d_stack;
+    return filter_dev(ctx, in, batch, d_logits, d_mask, false, 0, nullptr, nullptr, 0);
 }
 
 // Geometry, HBM workspace and prepared weights of a model.  Every limit of the kernels is checked here (a
@@ -108,9 +156,14 @@ static int build_model(covahip_ctx *ctx, covahip_blobnet *m, const float *h_w, i
     }
     int rc = blobnet_prepare_mfma(ctx, m, h_w);
     if (rc) return rc;
-    rc = blobnet_forward_mfma(ctx, m, nullptr, 1, nullptr, nullptr, nullptr, nullptr);   // planning only
-    if (rc) return rc;
-    return blobnet_forward_mfma(ctx, m, nullptr, max_batch, nullptr, nullptr, nullptr, nullptr);
+    BnInput plan;   // planning only, both input forms, smallest and largest batch
+    plan.dry = true;
+    for (int pass = 0; pass < 4 && !rc; pass++) {
+        const int b = (pass & 1) ? max_batch : 1;
+        plan.n_frames = (pass & 2) ? b + BN_T - 1 : 0;
+        rc = blobnet_forward_mfma(ctx, m, plan, b, nullptr, nullptr, nullptr, nullptr);
+    }
+    return rc;
 }
 
 extern "C" {
@@ -160,53 +213,78 @@ int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl) {
     return COVAHIP_OK;
 }
 
-int covahip_filter_forward(covahip_ctx *ctx, const uint8_t *rgba_stack, int batch, int area_thresh,
-                           covahip_box *boxes, int32_t *counts, int max_boxes, float *logits, uint8_t *mask,
-                           int mem_kind) {
-    if (!ctx || batch < 0 || max_boxes < 0) return COVAHIP_ERR_INVALID_ARG;
+// Shared body of covahip_filter_forward / covahip_filter_forward_frames: `src` is the stacked tensor (n_frames == 0)
+// or the carrier frames.
+static int filter_any(covahip_ctx *ctx, const uint8_t *src, int n_frames, const int32_t *stack_index, int batch,
+                      int area_thresh, covahip_box *boxes, int32_t *counts, int max_boxes, float *logits, uint8_t *mask,
+                      int mem_kind) {
+    if (!ctx || batch < 0 || max_boxes < 0 || n_frames < 0) return COVAHIP_ERR_INVALID_ARG;
     covahip_blobnet *m = ctx->blobnet;
     if (!m) return COVAHIP_ERR_NOT_LOADED;
     if (batch == 0) return COVAHIP_OK;
-    if (!rgba_stack || !counts || (!boxes && max_boxes > 0) || batch > m->max_batch) return COVAHIP_ERR_INVALID_ARG;
+    if (!src || !counts || (!boxes && max_boxes > 0) || batch > m->max_batch) return COVAHIP_ERR_INVALID_ARG;
     COVAHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    const bool by_frames = n_frames > 0;
     const size_t hw = (size_t)m->H * m->W;
-    const size_t in_bytes = (size_t)batch * BN_T * hw * 4;
+    const size_t in_bytes = by_frames ? (size_t)n_frames * hw * 4 : (size_t)batch * BN_T * hw * 4;
     const size_t mask_bytes = (size_t)batch * hw;
     const size_t logit_bytes = mask_bytes * sizeof(float);
     const size_t box_bytes = (size_t)batch * max_boxes * sizeof(covahip_box);
     const size_t cnt_bytes = (size_t)batch * sizeof(int32_t);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    if (mem_kind != COVAHIP_MEM_DEVICE && mem_kind != COVAHIP_MEM_HOST) return COVAHIP_ERR_INVALID_ARG;
 
-    if (mem_kind == COVAHIP_MEM_DEVICE) {
-        uint8_t *d_mask = mask;
-        if (!d_mask) {
-            int rc = covahip_ensure_buffer(ctx, &ctx->cc_scratch, &ctx->cc_scratch_bytes, mask_bytes);
-            if (rc) return rc;
-            d_mask = (uint8_t *)ctx->cc_scratch;
-        }
-        return filter_dev(ctx, rgba_stack, batch, logits, d_mask, true, area_thresh, boxes, counts, max_boxes);
+    const uint8_t *d_src = src;
+    uint8_t *d_mask = mask;
+    float *d_logits = logits;
+    covahip_box *d_boxes = boxes;
+    int32_t *d_counts = counts;
+    if (mem_kind == COVAHIP_MEM_HOST) {
+        int rc = covahip_ensure_buffer(ctx, &ctx->stage_in, &ctx->stage_in_bytes, in_bytes);
+        if (rc) return rc;
+        rc = covahip_ensure_buffer(ctx, &ctx->stage_out, &ctx->stage_out_bytes,
+                                   al(mask_bytes) + al(logit_bytes) + al(box_bytes) + al(cnt_bytes));
+        if (rc) return rc;
+        uint8_t *base = (uint8_t *)ctx->stage_out;
+        d_mask = base;
+        d_logits = logits ? (float *)(base + al(mask_bytes)) : nullptr;
+        d_boxes = (covahip_box *)(base + al(mask_bytes) + al(logit_bytes));
+        d_counts = (int32_t *)(base + al(mask_bytes) + al(logit_bytes) + al(box_bytes));
+        COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(ctx->stage_in, src, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+        d_src = (const uint8_t *)ctx->stage_in;
+    } else if (!d_mask) {
+        int rc = covahip_ensure_buffer(ctx, &ctx->cc_scratch, &ctx->cc_scratch_bytes, mask_bytes);
+        if (rc) return rc;
+        d_mask = (uint8_t *)ctx->cc_scratch;
     }
-    if (mem_kind != COVAHIP_MEM_HOST) return COVAHIP_ERR_INVALID_ARG;
-    int rc = covahip_ensure_buffer(ctx, &ctx->stage_in, &ctx->stage_in_bytes, in_bytes);
-    if (rc) return rc;
-    const size_t out_need = al(mask_bytes) + al(logit_bytes) + al(box_bytes) + al(cnt_bytes);
-    rc = covahip_ensure_buffer(ctx, &ctx->stage_out, &ctx->stage_out_bytes, out_need);
-    if (rc) return rc;
-    uint8_t *base = (uint8_t *)ctx->stage_out;
-    uint8_t *d_mask = base;
-    float *d_logits = (float *)(base + al(mask_bytes));
-    covahip_box *d_boxes = (covahip_box *)(base + al(mask_bytes) + al(logit_bytes));
-    int32_t *d_counts = (int32_t *)(base + al(mask_bytes) + al(logit_bytes) + al(box_bytes));
-    COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(ctx->stage_in, rgba_stack, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-    rc = filter_dev(ctx, (const uint8_t *)ctx->stage_in, batch, logits ? d_logits : nullptr, d_mask, true, area_thresh,
-                    d_boxes, d_counts, max_boxes);
-    if (rc) return rc;
+    BnInput in;
+    if (by_frames) {
+        int rc = prepare_frames(ctx, m, d_src, n_frames, stack_index, batch, in);
+        if (rc) return rc;
+    } else {
+        in.stack = d_src;
+    }
+    int rc = filter_dev(ctx, in, batch, d_logits, d_mask, true, area_thresh, d_boxes, d_counts, max_boxes);
+    if (rc || mem_kind == COVAHIP_MEM_DEVICE) return rc;
     if (logits) COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(logits, d_logits, logit_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (mask) COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(mask, d_mask, mask_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (box_bytes) COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(boxes, d_boxes, box_bytes, hipMemcpyDeviceToHost, ctx->stream));
     COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(counts, d_counts, cnt_bytes, hipMemcpyDeviceToHost, ctx->stream));
     COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return COVAHIP_OK;
+}
+
+int covahip_filter_forward(covahip_ctx *ctx, const uint8_t *rgba_stack, int batch, int area_thresh,
+                           covahip_box *boxes, int32_t *counts, int max_boxes, float *logits, uint8_t *mask,
+                           int mem_kind) {
+    return filter_any(ctx, rgba_stack, 0, nullptr, batch, area_thresh, boxes, counts, max_boxes, logits, mask, mem_kind);
+}
+
+int covahip_filter_forward_frames(covahip_ctx *ctx, const uint8_t *frames, int n_frames, const int32_t *stack_index,
+                                  int batch, int area_thresh, covahip_box *boxes, int32_t *counts, int max_boxes,
+                                  float *logits, uint8_t *mask, int mem_kind) {
+    if (n_frames <= 0) return COVAHIP_ERR_INVALID_ARG;
+    return filter_any(ctx, frames, n_frames, stack_index, batch, area_thresh, boxes, counts, max_boxes, logits, mask, mem_kind);
 }
 
 int covahip_blobnet_forward(covahip_ctx *ctx, const uint8_t *rgba_stack, int batch, float *logits, uint8_t *mask,

@@ -95,7 +95,9 @@ __device__ __forceinline__ float pool4(float a0, float a1, float a2, float a3, f
         const float mx = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
         const float mn = fminf(fminf(a0, a1), fminf(a2, a3));
         const float sel = e1 >= 0.f ? mx : mn;
-        return fmaxf(sel + e0, 0.f) * e1 + e2;
+        // an explicit fma: every kernel that shares this epilogue must round the same way whatever the compiler
+        // would otherwise contract (the carrier-frame and the stacked path are compared bit for bit)
+        return __builtin_fmaf(fmaxf(sel + e0, 0.f), e1, e2);
     }
 }
 
@@ -105,7 +107,7 @@ __device__ __forceinline__ float pool4(float a0, float a1, float a2, float a3, f
 // lane j + 4*block, D[i][j] in lane j + 4*block, register i.  Every lane feeds ITS element's
 // 4 T-values as a B column and gets that element's 4 outputs back as its D column; the A rows
 // (row lane%4 of W^T) are per-lane constants.  Inputs of the products are rounded to fp16 (like
-// every other MFMA operand here); the residual uses the fp32 value.
+// every other MFMA operand here).
 struct TmixW {
     half4 a1, a2;
 };
@@ -119,9 +121,10 @@ __device__ __forceinline__ TmixW load_tmix(const float *tm, int lane) {
     }
     return w;
 }
-__device__ __forceinline__ void tmix4(const TmixW &w, const float (&p)[BN_T], half4 &o) {
-    const f32x4 pv = {p[0], p[1], p[2], p[3]};
-    const half4 pb = __builtin_convertvector(pv, half4);
+// The pooled values are rounded to fp16 ONCE, before both uses (product operand and residual): the carrier-frame
+// path keeps them as an fp16 tensor between its level-0 kernel and this MLP, and both paths compute identical bits.
+__device__ __forceinline__ void tmix4h(const TmixW &w, const half4 pb, half4 &o) {
+    const f32x4 pv = __builtin_convertvector(pb, f32x4);
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     const half4 hz = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
     const f32x4 u = __builtin_amdgcn_mfma_f32_4x4x4f16(w.a1, pb, z, 0, 0, 0);
@@ -134,6 +137,10 @@ __device__ __forceinline__ void tmix4(const TmixW &w, const float (&p)[BN_T], ha
 #pragma unroll
     for (int t = 0; t < BN_T; t++) r[t] = fmaxf(fmaxf(sum[t], pv[t]), 0.f);
     o = __builtin_convertvector(r, half4);
+}
+__device__ __forceinline__ void tmix4(const TmixW &w, const float (&p)[BN_T], half4 &o) {
+    const f32x4 pv = {p[0], p[1], p[2], p[3]};
+    tmix4h(w, __builtin_convertvector(pv, half4), o);
 }
 
 // Asynchronous 16-byte global -> LDS copy (LDS-DMA): every lane supplies its own global source
@@ -234,6 +241,12 @@ struct EncArgs {
     Swz swz;           // LDS pixel swizzle of this launch (choose_swz)
     int scr_off;       // byte offset of the per-wave output transpose scratch (2 KB per wave) in LDS (WIDE)
     ItemPlan plan;
+    // PRE (level 1 of the carrier-frame path): `in` is the tensor P of enc0p_mfma, [F][H][W][CIN]; stack b takes its
+    // T = 0..3 slices from frames pidx[4b .. 4b+3]; the temporal MLP of the level below (weights tm_pre) is
+    // applied to the staged tile in LDS; its T = 0 slice goes to skip [B][T][H][W][CIN] (decoder skip input).
+    const int32_t *pidx;
+    __half *skip;
+    const float *tm_pre;
 };
 
 struct DecArgs {
@@ -411,10 +424,134 @@ __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
     }
 }
 
+// ------------------------------------------------------------------ enc level 0, one carrier frame at a time
+// Carrier-frame entry point (covahip_filter_forward_frames): conv + ReLU + BN + pool of level 0 work on single T
+// slices (kernel depth 1, encoder.py:35-52), and with gamma = 1 a carrier frame is a slice of four consecutive
+// stacks.  This kernel runs that part ONCE per carrier frame and leaves the pooled values -- the input of the
+// level's temporal MLP -- as an fp16 tensor P [F][Ho][Wo][16]; the MLP itself moves into the staging of level 1
+// (enc_mfma<.., PRE>), which gathers the four frames of a stack by index.  Same tiles, same MFMA operands and the
+// same rounding point (tmix4h) as enc0_mfma, so both entry points compute identical bits.
+struct Enc0pArgs {
+    const uint8_t *in;  // [F][H][W][4]
+    __half *out;        // [F][Ho][Wo][16]
+    const half8 *wfrag;
+    const float *epi;
+    int F, H, W, Hp, Wp, Ho, Wo, oy, ox;
+    int nbands, TC;
+    uint32_t mWp, mNb, mW4;
+    int scr_off;        // per-wave output scratch (1 KB per wave) behind the tile
+};
+template <bool ALLPOS>
+__global__ __launch_bounds__(WG0, 4) void enc0p_mfma(Enc0pArgs p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int TC = p.TC;
+    const half8 be0 = p.wfrag[lane], be1 = p.wfrag[64 + lane];
+    const half8 bo0 = p.wfrag[128 + lane], bo1 = p.wfrag[192 + lane];
+    const int co = lane & 15;
+    const float e0 = p.epi[co], e1 = p.epi[16 + co], e2 = p.epi[32 + co];
+    const int n_items = p.F * p.nbands;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int f = fdiv(item, p.mNb), band = item - f * p.nbands;
+        const int y0 = 2 * ((band * p.Hp) / p.nbands);
+        const int rows = 2 * (((band + 1) * p.Hp) / p.nbands) - y0;
+        const int n2 = rows + 2;
+        lds_barrier();
+        {   // stage rows y0-1 .. y0+rows as fp16 (see enc0_mfma); the host keeps n2 * W/4 <= 2 * WG0
+            const int W4 = p.W >> 2;
+            const int per_t = n2 * W4;
+            const uint8_t *fb = p.in + (size_t)f * p.H * p.W * 4;
+            uint4 v[2];
+            int dsto[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int i = tid + k * WG0;
+                dsto[k] = -1;
+                if (i < per_t) {
+                    const int r = fdiv(i, p.mW4), c4 = i - r * W4;
+                    const int y = y0 - 1 + r;
+                    dsto[k] = r * TC * 8 + 16 + c4 * 32;
+                    v[k] = (y >= 0 && y < p.H) ? *reinterpret_cast<const uint4 *>(fb + ((size_t)y * p.W + c4 * 4) * 4)
+                                               : make_uint4(0, 0, 0, 0);
+                }
+            }
+            const half2v clip = {(_Float16)1030.f, (_Float16)1030.f}, off = {(_Float16)1024.f, (_Float16)1024.f};
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (dsto[k] >= 0) {
+                    const uint32_t px[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+                    uint32_t o[8];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t c01 = __builtin_amdgcn_perm(0x64646464u, px[q], 0x05010500u);
+                        const uint32_t c23 = __builtin_amdgcn_perm(0x64646464u, px[q], 0x05030502u);
+                        const half2v h01 = __builtin_elementwise_min(__builtin_bit_cast(half2v, c01), clip) - off;
+                        const half2v h23 = __builtin_elementwise_min(__builtin_bit_cast(half2v, c23), clip) - off;
+                        o[2 * q] = __builtin_bit_cast(uint32_t, h01);
+                        o[2 * q + 1] = __builtin_bit_cast(uint32_t, h23);
+                    }
+                    uint8_t *d = smem + dsto[k];
+                    *reinterpret_cast<uint4 *>(d) = make_uint4(o[0], o[1], o[2], o[3]);
+                    *reinterpret_cast<uint4 *>(d + 16) = make_uint4(o[4], o[5], o[6], o[7]);
+                }
+            }
+            for (int i = tid; i < n2 * 2; i += WG0)   // zero halo columns 0,1 and W+2,W+3
+                *reinterpret_cast<uint4 *>(smem + (i >> 1) * TC * 8 + ((i & 1) ? (p.W + 2) * 8 : 0)) = make_uint4(0, 0, 0, 0);
+        }
+        lds_barrier();
+        // four tiles of 8 pool windows per wave pass (tile layout of enc0_mfma): the 32 windows x 16 channels leave
+        // the wave as one 16-byte store per lane
+        const int nwin = (rows / 2) * p.Wp;
+        const int ngroups = (nwin + 31) / 32;
+        const int m = lane & 15, g = lane >> 4;
+        uint8_t *const scr = smem + p.scr_off + wave * 1024;
+        __half *const ob = p.out + (size_t)f * p.Ho * p.Wo * 16;
+        for (int grp = wave; grp < ngroups; grp += WG0 / 64) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int win = min((grp * 4 + k) * 8 + (m >> 1), nwin - 1);
+                const int wy = fdiv(win, p.mWp), wx = win - wy * p.Wp;
+                const int yy = 2 * wy + (m & 1), xe = 2 * wx;
+                const int offe0 = ((yy + (g >> 1)) * TC + xe + 2 * (g & 1)) * 8;
+                const int offe1 = ((yy + 2) * TC + xe + 2 * (g & 1)) * 8;
+                const half8 ae0 = *reinterpret_cast<const half8 *>(smem + offe0);
+                const half8 ae1 = *reinterpret_cast<const half8 *>(smem + offe1);
+                const half8 ao0 = *reinterpret_cast<const half8 *>(smem + offe0 + 16);
+                const half8 ao1 = *reinterpret_cast<const half8 *>(smem + offe1 + 16);
+                f32x4 ce = {0.f, 0.f, 0.f, 0.f}, co_ = {0.f, 0.f, 0.f, 0.f};
+                ce = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae0, be0, ce, 0, 0, 0);
+                co_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao0, bo0, co_, 0, 0, 0);
+                ce = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae1, be1, ce, 0, 0, 0);
+                co_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao1, bo1, co_, 0, 0, 0);
+                _Float16 *sw = reinterpret_cast<_Float16 *>(scr + (k * 8 + 2 * g) * 32) + co;
+                // the fp32 value is made opaque before the conversion: hipcc would otherwise fuse the BN multiply-add and
+                // the conversion into one v_fma_mixlo_f16 (ONE rounding), while enc0_mfma rounds to fp32 and then to fp16
+                float v0 = pool4<ALLPOS>(ce[0], ce[1], co_[0], co_[1], e0, e1, e2);
+                float v1 = pool4<ALLPOS>(ce[2], ce[3], co_[2], co_[3], e0, e1, e2);
+                asm volatile("" : "+v"(v0), "+v"(v1));
+                sw[0] = (_Float16)v0;
+                sw[16] = (_Float16)v1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int owin = grp * 32 + (lane >> 1);
+            if (owin < nwin) {
+                const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
+                const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
+                *reinterpret_cast<uint4 *>(ob + (gy * p.Wo + gx) * 16 + 8 * (lane & 1)) =
+                    *reinterpret_cast<const uint4 *>(scr + lane * 16);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next pass's values stay behind these reads
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // ------------------------------------------------------------------ enc levels 1..3
 // conv3x3 CIN -> COUT on v_mfma_f32_32x32x16_f16.  Wave roles: N-tile = wave % NT,
 // M-group = wave / NT.  One K-step = one tap x 16 input channels.
-template <int CIN, int COUT, int TPAR, int OCC, int NWV, bool WIDE, bool ALLPOS>
+template <int CIN, int COUT, int TPAR, int OCC, int NWV, bool WIDE, bool ALLPOS, bool PRE = false>
 __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     constexpr int WGS = NWV * 64;
     constexpr int NT = COUT / 32, MG = NWV / NT, KC = CIN / 16, KSTEPS = 9 * KC;
@@ -452,7 +589,10 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
             const int RC = TC * CPP;  // chunks per tile row
             const int nchunk = n2 * RC;
             const size_t tplane = (size_t)p.H * p.W * CIN * 2;   // bytes
-            const uint8_t *fbase = reinterpret_cast<const uint8_t *>(p.in) + (size_t)b * BN_T * tplane;
+            const uint8_t *fbase = reinterpret_cast<const uint8_t *>(p.in) + (PRE ? 0 : (size_t)b * BN_T * tplane);
+            size_t foff[BN_T];   // byte offset of the frame that holds T slice t
+#pragma unroll
+            for (int t = 0; t < BN_T; t++) foff[t] = PRE ? (size_t)p.pidx[b * BN_T + t] * tplane : t * tplane;
             for (int s0 = wave * 64; s0 < nchunk; s0 += WGS) {
                 const int sidx = s0 + ll;
                 if (sidx < nchunk) {
@@ -463,14 +603,47 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
                     const bool in = y >= 0 && y < p.H && x >= 0 && x < p.W;
                     const uint8_t *src = in ? fbase + ((size_t)(y * p.W + x) * CIN + ch * 8) * 2
                                             : reinterpret_cast<const uint8_t *>(p.zero);
-                    const size_t step = in ? tplane : 0;
 #pragma unroll
-                    for (int t = 0; t < BN_T; t++) glds16(src + t * step, smem + t * tsz + s0 * 16);
+                    for (int t = 0; t < BN_T; t++) glds16(src + (in ? foff[t] : 0), smem + t * tsz + s0 * 16);
                 }
             }
         }
         wait_vmem();
         lds_barrier();
+        if constexpr (PRE) {
+            // ---- temporal MLP of the level below, in place: a lane takes one 16-byte piece (8 channels of a pixel) of
+            // all four T slices; the MLP does not depend on the channel, so the swizzle is irrelevant here.  Zero
+            // padding stays zero (no bias).
+            const TmixW tmp = load_tmix(p.tm_pre, ll);
+            const int nchunk = n2 * TC * CPP;
+            for (int sidx = tid; sidx < nchunk; sidx += WGS) {
+                half8 v[BN_T], o[BN_T];
+#pragma unroll
+                for (int t = 0; t < BN_T; t++) v[t] = *reinterpret_cast<const half8 *>(smem + t * tsz + sidx * 16);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const half4 pb = {v[0][j], v[1][j], v[2][j], v[3][j]};
+                    half4 r;
+                    tmix4h(tmp, pb, r);
+#pragma unroll
+                    for (int t = 0; t < BN_T; t++) o[t][j] = r[t];
+                }
+#pragma unroll
+                for (int t = 0; t < BN_T; t++) *reinterpret_cast<half8 *>(smem + t * tsz + sidx * 16) = o[t];
+            }
+            lds_barrier();
+            // ---- T = 0 slice of the band's own rows -> skip tensor (the last band also owns the odd last row)
+            const int ya = y0, yb = (band == p.nbands - 1) ? p.H : y0 + rows;
+            const int npc = (yb - ya) * p.W * CPP;
+            __half *const sk = p.skip + (size_t)b * BN_T * p.H * p.W * CIN;
+            for (int i = tid; i < npc; i += WGS) {
+                const int pix = i / CPP, ch = i % CPP;
+                const int ry = pix / p.W, x = pix - ry * p.W;
+                const int r = ya - y0 + 1 + ry, c = x + 1;
+                const uint4 v = *reinterpret_cast<const uint4 *>(smem + (r * TC + c) * PS + ((ch ^ swz_eval<CPP>(p.swz, c, r)) * 16));
+                *reinterpret_cast<uint4 *>(sk + ((size_t)(ya + ry) * p.W + x) * CIN + ch * 8) = v;
+            }
+        }
         // ---- compute
         const int nwin = (rows / 2) * p.Wp;
         const int ntiles = (nwin + 7) / 8;
@@ -1457,10 +1630,12 @@ void blobnet_release_mfma(covahip_ctx *, covahip_blobnet *m) {
     m->prep = nullptr;
 }
 
-int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_stack, int batch, float *d_logits,
+int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const BnInput &inp, int batch, float *d_logits,
                          uint8_t *d_mask, const BnCcTail *cc, bool *cc_done) {
     if (cc_done) *cc_done = false;
-    const bool dry = d_stack == nullptr;   // planning only: every check below runs, no kernel is launched
+    const bool dry = inp.dry;              // planning only: every check below runs, no kernel is launched
+    const uint8_t *d_stack = inp.stack;
+    const bool by_frames = inp.frames != nullptr || (dry && inp.n_frames > 0);
     __half *const *act = m->act;
     __half *const *dact = m->dact;
     const uint8_t *prep = (const uint8_t *)m->d_prepared;
@@ -1469,7 +1644,39 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
 
     // ---------------- encoder
     int first_level = 0;
-    if (m->fuse01) {
+    if (by_frames) {
+        // carrier-frame path: level 0 up to the pool ONCE per carrier frame (enc0p_mfma -> P); level 1 gathers the
+        // four frames of a stack, applies level 0's temporal MLP in LDS and writes the decoder's skip slice
+        const int H = m->lv[0].H, W = m->lv[0].W, Hp = H / 2, Wp = W / 2;
+        const int TC = ((W + 4 - 16 + 31) / 32) * 32 + 16;
+        if (W % 4) return COVAHIP_ERR_UNSUPPORTED;
+        // bands of whole pool-window rows: at most 2 * WG0 16-byte pieces per band (two per thread), <= 38 KB of LDS
+        int nbands = 0;
+        for (int nb = 1; nb <= Hp; nb++) {
+            const int rb = (Hp + nb - 1) / nb, n2 = 2 * rb + 2;
+            if (n2 * (W / 4) > 2 * WG0 || (size_t)n2 * TC * 8 > 30 * 1024) continue;
+            if ((long long)inp.n_frames * nb < 2LL * num_cu && nb < Hp) continue;   // keep every CU busy
+            nbands = nb;
+            break;
+        }
+        if (!nbands) return COVAHIP_ERR_UNSUPPORTED;
+        const int rbmax = (Hp + nbands - 1) / nbands;
+        const size_t tile_bytes = (((size_t)(2 * rbmax + 2) * TC * 8) + 15) & ~(size_t)15;
+        Enc0pArgs a;
+        a.in = inp.frames; a.out = m->pbuf;
+        a.wfrag = (const half8 *)(prep + pr->enc[0].wfrag); a.epi = (const float *)(prep + pr->enc[0].epi);
+        a.F = inp.n_frames; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.Ho = m->lv[1].H; a.Wo = m->lv[1].W;
+        a.oy = H & 1; a.ox = W & 1; a.nbands = nbands; a.TC = TC;
+        a.mWp = magic(Wp); a.mNb = magic(nbands); a.mW4 = magic(W / 4); a.scr_off = (int)tile_bytes;
+        const size_t lds = tile_bytes + (size_t)(WG0 / 64) * 1024;
+        const int grid = std::min(inp.n_frames * nbands, 4 * num_cu);
+        {
+            ProfScope ps(ctx, "enc0p_mfma");
+            if (pr->allpos[0]) LAUNCH(enc0p_mfma<true>, dim3(grid), dim3(WG0), lds, ctx->stream, a);
+            else LAUNCH(enc0p_mfma<false>, dim3(grid), dim3(WG0), lds, ctx->stream, a);
+        }
+        COVAHIP_CHECK_HIP(ctx, hipGetLastError());
+    } else if (m->fuse01) {
         // levels 0 + 1 in one kernel when the geometry fits its LDS plan (otherwise: one kernel per level)
         const int H0 = m->lv[0].H, W0 = m->lv[0].W, H1 = m->lv[1].H, W1 = m->lv[1].W;
         const int Hp1 = H1 / 2, Wp1 = W1 / 2;
@@ -1518,6 +1725,7 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
             first_level = 2;
         }
     }
+    if (by_frames) first_level = 1;
     for (int i = first_level; i < BN_LEVELS; i++) {
         const int H = m->lv[i].H, W = m->lv[i].W, Hp = H / 2, Wp = W / 2;
         const int cin = m->enc_c[i];
@@ -1581,8 +1789,16 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
             a.mWp = magic(Wp); a.mNb = magic(nbands); a.mRC = magic(TC * (cin / 8)); a.zero = prep + pr->zero; a.scr_off = (int)tile_bytes;
             a.plan = make_plan(grid, num_cu, wgs_per_cu, batch, nbands, Hp);
             a.swz = choose_swz(true, cin, W, Wp, RB / 2);
+            a.pidx = inp.index; a.skip = act[1]; a.tm_pre = (const float *)(prep + pr->enc[0].epi) + 48;
             int rc = COVAHIP_OK;
-            if (i == 1) {
+            if (i == 1 && by_frames) {
+                a.in = m->pbuf;
+                rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true, true, true>, lds) : set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true, false, true>, lds);
+                if (rc) return rc;
+                ProfScope ps(ctx, "enc1t_mfma");
+                if (pr->allpos[i]) LAUNCH((enc_mfma<16, 32, 2, 4, 8, true, true, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
+                else LAUNCH((enc_mfma<16, 32, 2, 4, 8, true, false, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
+            } else if (i == 1) {
                 rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true, true>, lds) : set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true, false>, lds);
                 if (rc) return rc;
                 ProfScope ps(ctx, "enc1_mfma");

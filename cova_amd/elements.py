@@ -193,6 +193,34 @@ class BlobNetInfer:
                 "covahip_filter_forward", self.ctx.handle)
         return boxes, counts, mask
 
+    def filter_frames(self, frames: np.ndarray, stack_index: np.ndarray | None, cc_threshold: int, max_boxes: int = 256,
+                      want_mask: bool = False, want_logits: bool = False):
+        """The hot path fed with carrier frames u8 [F][h][w][4] (host) and the stack -> frame index table i32 [B][4]
+        (None: one stream in order): returns (boxes, counts, mask|None, logits|None) like filter()."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        f = frames.shape[0]
+        assert frames.shape == (f, self.h, self.w, 4), frames.shape
+        idx = None if stack_index is None else np.ascontiguousarray(stack_index, dtype=np.int32).reshape(-1, 4)
+        b = f - 3 if idx is None else idx.shape[0]
+        boxes = np.zeros((b, max_boxes), dtype=L.BOX_DTYPE)
+        counts = np.zeros(b, dtype=np.int32)
+        mask = np.empty((b, self.h, self.w), dtype=np.uint8) if want_mask else None
+        logits = np.empty((b, self.h, self.w), dtype=np.float32) if want_logits else None
+        L.check(self._lib.covahip_filter_forward_frames(self.ctx.handle, _ptr(frames), f, None if idx is None else _ptr(idx), b,
+                                                        cc_threshold, _ptr(boxes), _ptr(counts), max_boxes,
+                                                        _ptr(logits) if want_logits else None,
+                                                        _ptr(mask) if want_mask else None, L.MEM_HOST),
+                "covahip_filter_forward_frames", self.ctx.handle)
+        return boxes, counts, mask, logits
+
+    def filter_frames_device(self, d_frames: int, n_frames: int, stack_index: np.ndarray | None, batch: int, cc_threshold: int,
+                             d_boxes: int, d_counts: int, max_boxes: int, d_mask: int | None = None):
+        idx = None if stack_index is None else np.ascontiguousarray(stack_index, dtype=np.int32).reshape(-1, 4)
+        L.check(self._lib.covahip_filter_forward_frames(self.ctx.handle, d_frames, n_frames, None if idx is None else _ptr(idx),
+                                                        batch, cc_threshold, d_boxes, d_counts, max_boxes, None, d_mask,
+                                                        L.MEM_DEVICE),
+                "covahip_filter_forward_frames", self.ctx.handle)
+
     def filter_device(self, d_stack: int, batch: int, cc_threshold: int, d_boxes: int, d_counts: int, max_boxes: int,
                       d_mask: int | None = None):
         L.check(self._lib.covahip_filter_forward(self.ctx.handle, d_stack, batch, cc_threshold, d_boxes, d_counts,

@@ -67,3 +67,19 @@ def stacked_batch(batch: int, h_mb: int, w_mb: int, t: int = 4, seed: int = 0xC0
 def random_masks(batch: int, h: int, w: int, density: float, seed: int = 7) -> np.ndarray:
     rng = np.random.default_rng(seed)
     return (rng.random((batch, h, w)) < density).astype(np.uint8)
+
+
+def carrier_batch(batch: int, h_mb: int, w_mb: int, t: int = 4, seed: int = 0xC07A, streams: int = 1):
+    """The carrier-frame form of stacked_batch(batch, ..., seed, streams): (frames u8 [F][h][w][4], index i32 [batch][t])
+    such that stacking frames[index[b, k]] for k = 0..t-1 along the row axis gives stacked_batch(...)[b]."""
+    per = -(-batch // streams)
+    frames = np.concatenate([carrier_frames(per + t - 1, h_mb, w_mb, seed=seed + s) for s in range(streams)])
+    index = np.empty((batch, t), dtype=np.int32)
+    for s in range(streams):
+        for j in range(per):
+            b = j * streams + s
+            if b >= batch:
+                break
+            for k in range(t):
+                index[b, k] = s * (per + t - 1) + j + t - 1 - k
+    return frames, index

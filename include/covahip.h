@@ -144,6 +144,19 @@ int covahip_filter_forward(covahip_ctx *ctx, const uint8_t *rgba_stack, int batc
                            covahip_box *boxes, int32_t *counts, int max_boxes, float *logits,
                            uint8_t *mask, int mem_kind);
 
+/* The same hot path fed with CARRIER frames instead of stacks: metapreprocess' temporal stacking (timestep 4,
+ * cova-rs/gst-plugins/src/metapreprocess/imp.rs:288-332) becomes an index gather on the GPU.  With gamma = 1 a
+ * carrier frame is a slice of four consecutive stacks; here it crosses PCIe / HBM once and the first encoder
+ * level's convolution runs once per carrier frame instead of once per (stack, slice).  Results are bit-identical
+ * to covahip_filter_forward on the stacks those indices describe.
+ *   frames:      u8 [n_frames][h_mb][w_mb][4], any mix of streams (mem_kind as for the other pointers)
+ *   stack_index: HOST i32 [batch][4]: for output b the indices into `frames` of its T = 0 (current), 1, 2, 3
+ *                (oldest) slices; NULL = one stream in order (batch == n_frames - 3, output b = frames b+3 .. b)
+ *   4 <= n_frames <= 4 * max_batch; an index outside [0, n_frames) is COVAHIP_ERR_INVALID_ARG.               */
+int covahip_filter_forward_frames(covahip_ctx *ctx, const uint8_t *frames, int n_frames, const int32_t *stack_index,
+                                  int batch, int area_thresh, covahip_box *boxes, int32_t *counts, int max_boxes,
+                                  float *logits, uint8_t *mask, int mem_kind);
+
 /* --------------------------------------------------------- Bbox wire format
  * bincode 1.3 (default config) bytes of Vec<Bbox> / Frame as the reference's elements
  * exchange them (cova-rs/bbox/src/bbox.rs:4-14,84-90; cova-rs/bbox/src/lib.rs:8-22).  */

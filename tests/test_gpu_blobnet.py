@@ -192,3 +192,46 @@ def test_host_buffer_call_equals_device_pointer_call(ctx, weights_flat):
     np.testing.assert_array_equal(mask, mask2)
     for i in range(b):
         np.testing.assert_array_equal(boxes[i, :counts[i]], boxes2[i, :counts[i]])
+
+
+@pytest.mark.parametrize("hw", [(68, 120), (67, 120), (45, 80), (35, 60)])
+@pytest.mark.parametrize("mixed_gamma", [False, True])
+def test_carrier_frame_entry_equals_stacked_entry_bitwise(ctx, weights_flat, hw, mixed_gamma):
+    """covahip_filter_forward_frames (stacking as an index gather on the GPU, level 0 computed once per carrier frame)
+    gives the logits, masks and boxes of covahip_filter_forward on the stacks the index table describes, bit for bit."""
+    h, w = hw
+    b, streams = 40, 3
+    flat = _mixed_gamma_weights(77) if mixed_gamma else weights_flat
+    frames, index = synth.carrier_batch(b, h, w, seed=61, streams=streams)
+    stack = synth.stacked_batch(b, h, w, seed=61, streams=streams)
+    np.testing.assert_array_equal(np.concatenate([frames[index[:, k]] for k in range(4)], axis=1), stack)
+    net = BlobNetInfer(ctx, flat, h, w, max_batch=64)
+    boxes, counts, mask = net.filter(stack, cc_threshold=2, max_boxes=2048, want_mask=True)
+    logits, _ = net.infer(stack)
+    fboxes, fcounts, fmask, flogits = net.filter_frames(frames, index, 2, max_boxes=2048, want_mask=True, want_logits=True)
+    np.testing.assert_array_equal(flogits, logits)
+    np.testing.assert_array_equal(fmask, mask)
+    np.testing.assert_array_equal(fcounts, counts)
+    for i in range(b):
+        np.testing.assert_array_equal(fboxes[i, :counts[i]], boxes[i, :counts[i]])
+    # one stream in order, no table: output k = frames k+3 .. k
+    one = synth.carrier_frames(20, h, w, seed=5)
+    st1 = np.stack([np.concatenate([one[i - k] for k in range(4)], axis=0) for i in range(3, 20)])
+    b1, c1, m1 = net.filter(st1, cc_threshold=2, max_boxes=2048, want_mask=True)
+    b2, c2, m2, _ = net.filter_frames(one, None, 2, max_boxes=2048, want_mask=True)
+    np.testing.assert_array_equal(m2, m1)
+    np.testing.assert_array_equal(c2, c1)
+
+
+def test_carrier_frame_entry_rejects_bad_tables(ctx, weights_flat):
+    from cova_amd import _lib as L
+    h, w = 45, 80
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=8)
+    frames = synth.carrier_frames(6, h, w, seed=3)
+    idx = np.array([[3, 2, 1, 0], [4, 3, 2, 6]], dtype=np.int32)          # 6 is outside the 6 frames
+    with pytest.raises(L.CovahipError):
+        net.filter_frames(frames, idx, 1)
+    with pytest.raises(L.CovahipError):
+        net.filter_frames(frames, np.array([[3, 2, 1, -1]], dtype=np.int32), 1)
+    boxes, counts, _, _ = net.filter_frames(frames, np.array([[5, 4, 3, 2], [5, 5, 5, 5]], dtype=np.int32), 1)
+    assert counts.shape == (2,)

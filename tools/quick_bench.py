@@ -18,20 +18,35 @@ flat = W.random_init(1234)
 net = BlobNetInfer(ctx, flat, H, Wd, max_batch=B)
 if os.environ.get("QB_IMPL"):
     net.set_impl(os.environ["QB_IMPL"])
-stack = synth.stacked_batch(min(B, 64), H, Wd, seed=1, streams=8)
-stack = np.concatenate([stack] * (B // stack.shape[0] + 1))[:B]
-d_stack = ctx.malloc(stack.nbytes)
-ctx.h2d(d_stack, stack)
+FRAMES = os.environ.get("QB_INPUT", "stack") == "frames"     # carrier-frame entry point instead of stacks
+if FRAMES:
+    frames, index = synth.carrier_batch(B, H, Wd, seed=1, streams=8)
+    d_frames = ctx.malloc(frames.nbytes)
+    ctx.h2d(d_frames, frames)
+else:
+    stack = synth.stacked_batch(min(B, 64), H, Wd, seed=1, streams=8)
+    stack = np.concatenate([stack] * (B // stack.shape[0] + 1))[:B]
+    d_stack = ctx.malloc(stack.nbytes)
+    ctx.h2d(d_stack, stack)
 max_boxes = 256
 d_boxes = ctx.malloc(B * max_boxes * 20)
 d_counts = ctx.malloc(B * 4)
 d_mask = ctx.malloc(B * H * Wd)
+
+
+def step():
+    if FRAMES:
+        net.filter_frames_device(d_frames, frames.shape[0], index, B, 1, d_boxes, d_counts, max_boxes, d_mask)
+    else:
+        net.filter_device(d_stack, B, 1, d_boxes, d_counts, max_boxes, d_mask)
+
+
 for _ in range(3):
-    net.filter_device(d_stack, B, 1, d_boxes, d_counts, max_boxes, d_mask)
+    step()
 ctx.sync()
 ctx.timer_start(0)
 for _ in range(steps):
-    net.filter_device(d_stack, B, 1, d_boxes, d_counts, max_boxes, d_mask)
+    step()
 ctx.timer_stop(0)
 ms = ctx.timer_ms(0) / steps
 macs = net.macs_per_frame
@@ -40,7 +55,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "noprofile":
     sys.exit(0)
 ctx.profile(True)
 for _ in range(steps):
-    net.filter_device(d_stack, B, 1, d_boxes, d_counts, max_boxes, d_mask)
+    step()
 ctx.sync()
 prof = ctx.profile_read()
 tot = 0
