@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "blobnet.h"
 #include "covahip_dev.h"
@@ -66,26 +67,63 @@ static int filter_dev(covahip_ctx *ctx, const BnInput &in, int batch, float *d_l
 }
 
 // Carrier-frame input: validates the stack -> frame table on the host (an index outside the frame array would be an
-// out-of-bounds read on the GPU), uploads it, sizes the P tensor.  stack_index == nullptr: one stream in order.
+// out-of-bounds read on the GPU), plans the time walk (chains of stacks that shift by one frame), uploads table and
+// plan.  stack_index == nullptr: one stream in order.  A table equal to the previous call's is not planned again.
 static int prepare_frames(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_frames, int n_frames,
                           const int32_t *stack_index, int batch, BnInput &in) {
     if (n_frames < BN_T || n_frames > BN_T * m->max_batch) return COVAHIP_ERR_INVALID_ARG;
     if (!stack_index && batch != n_frames - (BN_T - 1)) return COVAHIP_ERR_INVALID_ARG;
-    if (!m->d_index) {
-        COVAHIP_CHECK_HIP(ctx, hipMalloc((void **)&m->d_index, (size_t)m->max_batch * BN_T * sizeof(int32_t)));
-        COVAHIP_CHECK_HIP(ctx, hipHostMalloc((void **)&m->h_index, (size_t)m->max_batch * BN_T * sizeof(int32_t), hipHostMallocDefault));
-        COVAHIP_CHECK_HIP(ctx, hipEventCreateWithFlags(&m->ev_index, hipEventDisableTiming));
-    } else {
-        COVAHIP_CHECK_HIP(ctx, hipEventSynchronize(m->ev_index));
-    }
+    std::vector<int32_t> table((size_t)batch * BN_T);
     for (int b = 0; b < batch; b++)
         for (int t = 0; t < BN_T; t++) {
             const int32_t f = stack_index ? stack_index[b * BN_T + t] : b + (BN_T - 1) - t;
             if (f < 0 || f >= n_frames) return COVAHIP_ERR_INVALID_ARG;
-            m->h_index[b * BN_T + t] = f;
+            table[(size_t)b * BN_T + t] = f;
         }
-    COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(m->d_index, m->h_index, (size_t)batch * BN_T * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    COVAHIP_CHECK_HIP(ctx, hipEventRecord(m->ev_index, ctx->stream));
+    const bool same = m->d_index && table == m->last_table && n_frames == m->last_n_frames;
+    if (!same) {
+        std::vector<int32_t> order, items;
+        WalkGeom g;
+        const bool walk = m->frames_impl == 2 &&
+                          blobnet_plan_walk(m, ctx->props.multiProcessorCount, table.data(), batch, order, items, g);
+        if (!walk) { order.clear(); items.clear(); }
+        const size_t need = table.size() + order.size() + items.size();
+        if (m->d_index) COVAHIP_CHECK_HIP(ctx, hipEventSynchronize(m->ev_index));
+        if (need > m->index_ints) {
+            if (m->d_index) {
+                COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                hipFree(m->d_index);
+                hipHostFree(m->h_index);
+                m->d_index = nullptr; m->h_index = nullptr; m->index_ints = 0;
+                m->last_table.clear();
+            }
+            const size_t cap = std::max(need, (size_t)m->max_batch * 16);
+            COVAHIP_CHECK_HIP(ctx, hipMalloc((void **)&m->d_index, cap * sizeof(int32_t)));
+            COVAHIP_CHECK_HIP(ctx, hipHostMalloc((void **)&m->h_index, cap * sizeof(int32_t), hipHostMallocDefault));
+            m->index_ints = cap;
+            if (!m->ev_index) COVAHIP_CHECK_HIP(ctx, hipEventCreateWithFlags(&m->ev_index, hipEventDisableTiming));
+        }
+        std::copy(table.begin(), table.end(), m->h_index);
+        std::copy(order.begin(), order.end(), m->h_index + table.size());
+        std::copy(items.begin(), items.end(), m->h_index + table.size() + order.size());
+        COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(m->d_index, m->h_index, need * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        COVAHIP_CHECK_HIP(ctx, hipEventRecord(m->ev_index, ctx->stream));
+        m->last_table = std::move(table);
+        m->last_n_frames = n_frames;
+        m->last_n_items = (int)(items.size() / 4);
+        m->last_walk = g;
+    }
+    in.frames = d_frames;
+    in.n_frames = n_frames;
+    in.index = m->d_index;
+    if (m->last_n_items > 0) {
+        in.order = m->d_index + (size_t)batch * BN_T;
+        in.items = in.order + batch;
+        in.n_items = m->last_n_items;
+        in.walk = m->last_walk;
+        return COVAHIP_OK;
+    }
+    // two-kernel form: the tensor P of pooled level-0 values, one slice per carrier frame
     if (m->pbuf_frames < (size_t)n_frames) {
         // grown in whole steps; the pad row / column of P (odd grids) is zeroed here and never written
         const size_t want = std::min((size_t)BN_T * m->max_batch, std::max((size_t)n_frames, 2 * m->pbuf_frames));
@@ -100,9 +138,6 @@ static int prepare_frames(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d
         COVAHIP_CHECK_HIP(ctx, hipMemsetAsync(m->pbuf, 0, bytes, ctx->stream));
         m->pbuf_frames = want;
     }
-    in.frames = d_frames;
-    in.n_frames = n_frames;
-    in.index = m->d_index;
     return COVAHIP_OK;
 }
 
@@ -160,7 +195,7 @@ static int build_model(covahip_ctx *ctx, covahip_blobnet *m, const float *h_w, i
     plan.dry = true;
     for (int pass = 0; pass < 4 && !rc; pass++) {
         const int b = (pass & 1) ? max_batch : 1;
-        plan.n_frames = (pass & 2) ? b + BN_T - 1 : 0;
+        plan.n_frames = (pass & 2) ? b + BN_T - 1 : 0;   // the two-kernel form of the carrier-frame path must always fit
         rc = blobnet_forward_mfma(ctx, m, plan, b, nullptr, nullptr, nullptr, nullptr);
     }
     return rc;
@@ -208,8 +243,10 @@ int covahip_blobnet_macs_per_frame(covahip_ctx *ctx, int64_t *macs) {
 
 int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl) {
     if (!ctx || !ctx->blobnet) return COVAHIP_ERR_NOT_LOADED;
-    if (impl < 1 || impl > 2) return COVAHIP_ERR_INVALID_ARG;
+    if (impl < 1 || impl > 3) return COVAHIP_ERR_INVALID_ARG;
     ctx->blobnet->fuse01 = impl == 2;
+    ctx->blobnet->frames_impl = impl == 3 ? 2 : 0;
+    ctx->blobnet->last_table.clear();   // the resident plan belongs to the other form
     return COVAHIP_OK;
 }
 

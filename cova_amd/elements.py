@@ -158,7 +158,7 @@ class BlobNetInfer:
 
     def set_impl(self, impl: str):
         """Developer switch (include/covahip_dev.h): encoder levels 0/1 as two kernels or as one."""
-        L.check(self._lib.covahip_blobnet_set_impl(self.ctx.handle, {"mfma": 1, "mfma_fused01": 2}[impl]), "set_impl")
+        L.check(self._lib.covahip_blobnet_set_impl(self.ctx.handle, {"mfma": 1, "mfma_fused01": 2, "frames_walk": 3}[impl]), "set_impl")
 
     @property
     def macs_per_frame(self) -> int:

@@ -208,12 +208,21 @@ def test_carrier_frame_entry_equals_stacked_entry_bitwise(ctx, weights_flat, hw,
     net = BlobNetInfer(ctx, flat, h, w, max_batch=64)
     boxes, counts, mask = net.filter(stack, cc_threshold=2, max_boxes=2048, want_mask=True)
     logits, _ = net.infer(stack)
-    fboxes, fcounts, fmask, flogits = net.filter_frames(frames, index, 2, max_boxes=2048, want_mask=True, want_logits=True)
-    np.testing.assert_array_equal(flogits, logits)
-    np.testing.assert_array_equal(fmask, mask)
-    np.testing.assert_array_equal(fcounts, counts)
-    for i in range(b):
-        np.testing.assert_array_equal(fboxes[i, :counts[i]], boxes[i, :counts[i]])
+    # both forms of the carrier-frame path: two kernels (default) and the time-walking level-0+1 kernel
+    for impl in ("mfma", "frames_walk"):
+        net.set_impl(impl)
+        fboxes, fcounts, fmask, flogits = net.filter_frames(frames, index, 2, max_boxes=2048, want_mask=True, want_logits=True)
+        np.testing.assert_array_equal(flogits, logits, err_msg=impl)
+        np.testing.assert_array_equal(fmask, mask)
+        np.testing.assert_array_equal(fcounts, counts)
+        for i in range(b):
+            np.testing.assert_array_equal(fboxes[i, :counts[i]], boxes[i, :counts[i]])
+        # a shuffled batch: the chains of the time walk are found wherever the stacks sit in the batch
+        perm = np.random.default_rng(3).permutation(b)
+        _, pcounts, pmask, plogits = net.filter_frames(frames, index[perm], 2, max_boxes=2048, want_mask=True, want_logits=True)
+        np.testing.assert_array_equal(plogits, logits[perm], err_msg=impl + " shuffled")
+        np.testing.assert_array_equal(pcounts, counts[perm])
+    net.set_impl("mfma")
     # one stream in order, no table: output k = frames k+3 .. k
     one = synth.carrier_frames(20, h, w, seed=5)
     st1 = np.stack([np.concatenate([one[i - k] for k in range(4)], axis=0) for i in range(3, 20)])
