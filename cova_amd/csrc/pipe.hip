@@ -1,0 +1,242 @@
+// Pipelined host-buffer form of the hot path (covahip_pipe_*): what a batching element needs to keep the GPU fed
+// from host-side entropy decoders.
+//
+//   * every slot owns PINNED host buffers (hipHostMalloc) for its carrier frames, its stack -> frame table and its
+//     results; the caller writes the frames of a batch straight into the slot (the copy a batching element makes
+//     anyway, nvstreammux-style), so no pageable copy ever blocks the calling thread;
+//   * three HIP streams: H2D of batch k+1, the kernels of batch k (the ctx stream; the activation workspace is shared,
+//     so compute is serial), D2H of batch k-1, chained by events -- PCIe traffic in both directions hides behind
+//     the kernels;
+//   * boxes are compacted on the device (exclusive scan of the per-frame counts -> one packed array + offsets), so
+//     the D2H copy carries what exists, not batch x max_boxes slots.
+//
+// Reference pipeline stage this stands for: nvstreammux -> nvinfer(BlobNet) -> nvstreamdemux -> maskcopy -> bboxcc
+// (pipeline/cova/pipeline.py:139-261), with metapreprocess' stacking (imp.rs:288-332) as the GPU-side gather of
+// covahip_filter_forward_frames.
+#include <algorithm>
+#include <vector>
+
+#include "blobnet.h"
+#include "internal.h"
+
+namespace {
+
+// counts -> offsets (exclusive scan of min(count, max_boxes)); one 1,024-thread workgroup, batch <= 1,024 * PER
+constexpr int SCAN_THREADS = 1024;
+__global__ __launch_bounds__(SCAN_THREADS) void pack_scan_kernel(const int32_t *__restrict__ counts, int batch, int max_boxes,
+                                                                 int32_t *__restrict__ offsets) {
+    __shared__ int32_t wave_tot[SCAN_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (batch + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int i0 = tid * per;
+    int32_t sum = 0;
+    for (int k = 0; k < per; k++)
+        if (i0 + k < batch) sum += min(counts[i0 + k], max_boxes);
+    int32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    int32_t base = 0;
+    for (int k = 0; k < wv; k++) base += wave_tot[k];
+    int32_t run = base + incl - sum;
+    for (int k = 0; k < per; k++)
+        if (i0 + k < batch) {
+            offsets[i0 + k] = run;
+            run += min(counts[i0 + k], max_boxes);
+        }
+    if (tid == SCAN_THREADS - 1) offsets[batch] = run;
+}
+
+__global__ __launch_bounds__(64) void pack_gather_kernel(const covahip_box *__restrict__ boxes, const int32_t *__restrict__ counts,
+                                                         const int32_t *__restrict__ offsets, int max_boxes,
+                                                         covahip_box *__restrict__ packed) {
+    const int b = blockIdx.x;
+    const int n = min(counts[b], max_boxes);
+    // 20-byte boxes as 5 dwords: consecutive lanes move consecutive dwords
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(boxes + (size_t)b * max_boxes);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(packed + offsets[b]);
+    for (int i = threadIdx.x; i < n * 5; i += 64) dst[i] = src[i];
+}
+
+struct Slot {
+    uint8_t *h_frames = nullptr;
+    int32_t *h_index = nullptr;
+    int32_t *h_meta = nullptr;       // counts [B] | offsets [B + 1]
+    covahip_box *h_packed = nullptr;
+    uint8_t *h_mask = nullptr;
+    uint8_t *d_frames = nullptr;
+    covahip_box *d_boxes = nullptr, *d_packed = nullptr;
+    int32_t *d_meta = nullptr;
+    uint8_t *d_mask = nullptr;
+    hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;
+    int state = 0;                   // 0 free, 1 acquired, 2 submitted
+    int batch = 0, n_frames = 0;
+    int spec = 0;                    // packed boxes the pipelined D2H of this submission carries
+};
+
+}  // namespace
+
+struct covahip_pipe {
+    covahip_ctx *ctx = nullptr;
+    int max_batch = 0, max_frames = 0, max_boxes = 0, n_slots = 0, want_mask = 0;
+    size_t frame_bytes = 0, hw = 0;
+    int spec = 0;                    // packed boxes copied back by the pipelined D2H; grows to what the stream produces
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    std::vector<Slot> slots;
+    int next = 0;
+};
+
+#define PIPE_CHECK(expr) COVAHIP_CHECK_HIP(p->ctx, expr)
+
+extern "C" {
+
+void covahip_pipe_destroy(covahip_pipe *p) {
+    if (!p) return;
+    hipSetDevice(p->ctx->device);
+    hipStreamSynchronize(p->ctx->stream);
+    if (p->s_h2d) hipStreamSynchronize(p->s_h2d);
+    if (p->s_d2h) hipStreamSynchronize(p->s_d2h);
+    for (Slot &s : p->slots) {
+        if (s.h_frames) hipHostFree(s.h_frames);
+        if (s.h_index) hipHostFree(s.h_index);
+        if (s.h_meta) hipHostFree(s.h_meta);
+        if (s.h_packed) hipHostFree(s.h_packed);
+        if (s.h_mask) hipHostFree(s.h_mask);
+        if (s.d_frames) hipFree(s.d_frames);
+        if (s.d_boxes) hipFree(s.d_boxes);
+        if (s.d_packed) hipFree(s.d_packed);
+        if (s.d_meta) hipFree(s.d_meta);
+        if (s.d_mask) hipFree(s.d_mask);
+        if (s.ev_in) hipEventDestroy(s.ev_in);
+        if (s.ev_done) hipEventDestroy(s.ev_done);
+        if (s.ev_out) hipEventDestroy(s.ev_out);
+    }
+    if (p->s_h2d) hipStreamDestroy(p->s_h2d);
+    if (p->s_d2h) hipStreamDestroy(p->s_d2h);
+    delete p;
+}
+
+int covahip_pipe_create(covahip_ctx *ctx, int max_batch, int max_frames, int max_boxes, int n_slots, int want_mask,
+                        covahip_pipe **out) {
+    if (!ctx || !out || max_batch <= 0 || max_frames < BN_T || max_boxes <= 0 || n_slots < 1 || n_slots > 8)
+        return COVAHIP_ERR_INVALID_ARG;
+    *out = nullptr;
+    covahip_blobnet *m = ctx->blobnet;
+    if (!m) return COVAHIP_ERR_NOT_LOADED;
+    if (max_batch > m->max_batch || max_frames > BN_T * m->max_batch || max_batch > SCAN_THREADS * 64) return COVAHIP_ERR_INVALID_ARG;
+    COVAHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    covahip_pipe *p = new covahip_pipe();
+    p->ctx = ctx;
+    p->max_batch = max_batch; p->max_frames = max_frames; p->max_boxes = max_boxes; p->n_slots = n_slots;
+    p->want_mask = want_mask != 0;
+    p->hw = (size_t)m->H * m->W;
+    p->frame_bytes = p->hw * 4;
+    p->spec = std::min(max_batch * max_boxes, std::max(1024, max_batch * 16));
+    p->slots.resize(n_slots);
+    auto fail = [&](int rc) { covahip_pipe_destroy(p); return rc; };
+    if (hipStreamCreateWithFlags(&p->s_h2d, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&p->s_d2h, hipStreamNonBlocking) != hipSuccess)
+        return fail(COVAHIP_ERR_HIP);
+    const size_t meta_ints = (size_t)2 * max_batch + 1;
+    for (Slot &s : p->slots) {
+        bool ok = hipHostMalloc((void **)&s.h_frames, (size_t)max_frames * p->frame_bytes, hipHostMallocDefault) == hipSuccess &&
+                  hipHostMalloc((void **)&s.h_index, (size_t)max_batch * BN_T * sizeof(int32_t), hipHostMallocDefault) == hipSuccess &&
+                  hipHostMalloc((void **)&s.h_meta, meta_ints * sizeof(int32_t), hipHostMallocDefault) == hipSuccess &&
+                  hipHostMalloc((void **)&s.h_packed, (size_t)max_batch * max_boxes * sizeof(covahip_box), hipHostMallocDefault) == hipSuccess &&
+                  hipMalloc((void **)&s.d_frames, (size_t)max_frames * p->frame_bytes) == hipSuccess &&
+                  hipMalloc((void **)&s.d_boxes, (size_t)max_batch * max_boxes * sizeof(covahip_box)) == hipSuccess &&
+                  hipMalloc((void **)&s.d_packed, (size_t)max_batch * max_boxes * sizeof(covahip_box)) == hipSuccess &&
+                  hipMalloc((void **)&s.d_meta, meta_ints * sizeof(int32_t)) == hipSuccess &&
+                  hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming) == hipSuccess;
+        if (ok && p->want_mask)
+            ok = hipHostMalloc((void **)&s.h_mask, (size_t)max_batch * p->hw, hipHostMallocDefault) == hipSuccess &&
+                 hipMalloc((void **)&s.d_mask, (size_t)max_batch * p->hw) == hipSuccess;
+        if (!ok) {
+            ctx->last_hip_error = "covahip_pipe_create: allocation failed";
+            return fail(COVAHIP_ERR_HIP);
+        }
+    }
+    *out = p;
+    return COVAHIP_OK;
+}
+
+int covahip_pipe_acquire(covahip_pipe *p, int *slot, uint8_t **frames, int32_t **stack_index) {
+    if (!p || !slot || !frames || !stack_index) return COVAHIP_ERR_INVALID_ARG;
+    for (int k = 0; k < p->n_slots; k++) {
+        const int i = (p->next + k) % p->n_slots;
+        if (p->slots[i].state == 0) {
+            p->slots[i].state = 1;
+            p->next = (i + 1) % p->n_slots;
+            *slot = i;
+            *frames = p->slots[i].h_frames;
+            *stack_index = p->slots[i].h_index;
+            return COVAHIP_OK;
+        }
+    }
+    return COVAHIP_ERR_OVERFLOW;   // every slot is acquired or in flight: collect one first
+}
+
+int covahip_pipe_submit(covahip_pipe *p, int slot, int n_frames, int batch, int area_thresh) {
+    if (!p || slot < 0 || slot >= p->n_slots || p->slots[slot].state != 1) return COVAHIP_ERR_INVALID_ARG;
+    if (batch <= 0 || batch > p->max_batch || n_frames < BN_T || n_frames > p->max_frames) return COVAHIP_ERR_INVALID_ARG;
+    Slot &s = p->slots[slot];
+    covahip_ctx *ctx = p->ctx;
+    PIPE_CHECK(hipSetDevice(ctx->device));
+    PIPE_CHECK(hipMemcpyAsync(s.d_frames, s.h_frames, (size_t)n_frames * p->frame_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    PIPE_CHECK(hipEventRecord(s.ev_in, p->s_h2d));
+    PIPE_CHECK(hipStreamWaitEvent(ctx->stream, s.ev_in, 0));
+    int32_t *d_counts = s.d_meta, *d_offsets = s.d_meta + p->max_batch;
+    int rc = covahip_filter_forward_frames(ctx, s.d_frames, n_frames, s.h_index, batch, area_thresh, s.d_boxes, d_counts, p->max_boxes,
+                                           nullptr, s.d_mask, COVAHIP_MEM_DEVICE);
+    if (rc) return rc;
+    {
+        ProfScope ps(ctx, "pack_boxes");
+        hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, (const int32_t *)d_counts, batch, p->max_boxes, d_offsets);
+        hipLaunchKernelGGL(pack_gather_kernel, dim3(batch), dim3(64), 0, ctx->stream, (const covahip_box *)s.d_boxes, (const int32_t *)d_counts,
+                           (const int32_t *)d_offsets, p->max_boxes, s.d_packed);
+    }
+    PIPE_CHECK(hipGetLastError());
+    PIPE_CHECK(hipEventRecord(s.ev_done, ctx->stream));
+    PIPE_CHECK(hipStreamWaitEvent(p->s_d2h, s.ev_done, 0));
+    // counts [batch] and offsets [batch + 1] sit max_batch apart: one copy covers both
+    PIPE_CHECK(hipMemcpyAsync(s.h_meta, s.d_meta, ((size_t)p->max_batch + batch + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, p->s_d2h));
+    s.spec = std::min(p->spec, batch * p->max_boxes);
+    PIPE_CHECK(hipMemcpyAsync(s.h_packed, s.d_packed, (size_t)s.spec * sizeof(covahip_box), hipMemcpyDeviceToHost, p->s_d2h));
+    if (p->want_mask)
+        PIPE_CHECK(hipMemcpyAsync(s.h_mask, s.d_mask, (size_t)batch * p->hw, hipMemcpyDeviceToHost, p->s_d2h));
+    PIPE_CHECK(hipEventRecord(s.ev_out, p->s_d2h));
+    s.batch = batch;
+    s.n_frames = n_frames;
+    s.state = 2;
+    return COVAHIP_OK;
+}
+
+int covahip_pipe_collect(covahip_pipe *p, int slot, const int32_t **counts, const int32_t **offsets, const covahip_box **boxes,
+                         const uint8_t **mask) {
+    if (!p || slot < 0 || slot >= p->n_slots || p->slots[slot].state != 2) return COVAHIP_ERR_INVALID_ARG;
+    Slot &s = p->slots[slot];
+    PIPE_CHECK(hipSetDevice(p->ctx->device));
+    PIPE_CHECK(hipEventSynchronize(s.ev_out));
+    const int32_t *off = s.h_meta + p->max_batch;
+    const int total = off[s.batch];
+    if (total > s.spec) {   // more boxes than the pipelined copy carried: fetch the rest now, and copy more from the next batch on
+        PIPE_CHECK(hipMemcpyAsync(s.h_packed + s.spec, s.d_packed + s.spec, (size_t)(total - s.spec) * sizeof(covahip_box),
+                                  hipMemcpyDeviceToHost, p->s_d2h));
+        PIPE_CHECK(hipStreamSynchronize(p->s_d2h));
+        p->spec = std::min(p->max_batch * p->max_boxes, total + total / 4);
+    }
+    if (counts) *counts = s.h_meta;
+    if (offsets) *offsets = off;
+    if (boxes) *boxes = s.h_packed;
+    if (mask) *mask = s.h_mask;
+    s.state = 0;   // results stay valid until the slot is acquired again
+    return COVAHIP_OK;
+}
+
+}  // extern "C"

@@ -228,6 +228,65 @@ class BlobNetInfer:
                 "covahip_filter_forward", self.ctx.handle)
 
 
+class FilterPipe:
+    """covahip_pipe_*: batches of carrier frames in pinned host memory, H2D / kernels / D2H of consecutive batches
+    overlapped on three HIP streams, boxes compacted on the device."""
+
+    def __init__(self, net: "BlobNetInfer", max_batch: int, max_frames: int, max_boxes: int = 256, n_slots: int = 3,
+                 want_mask: bool = False):
+        self.net, self.max_batch, self.max_frames, self.max_boxes = net, max_batch, max_frames, max_boxes
+        self._lib = L.lib()
+        h = C.c_void_p()
+        L.check(self._lib.covahip_pipe_create(net.ctx.handle, max_batch, max_frames, max_boxes, n_slots, int(want_mask),
+                                              C.byref(h)), "covahip_pipe_create", net.ctx.handle)
+        self._h = h
+        self._batch = {}
+        self._views = {}     # slot -> numpy views of its pinned input buffers (the addresses never change)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.covahip_pipe_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def acquire(self):
+        """-> (slot, frames u8 [max_frames][h][w][4], index i32 [max_batch][4]): numpy views of the slot's pinned buffers,
+        or None when every slot is in flight."""
+        slot, fp, ip = C.c_int(), C.c_void_p(), C.c_void_p()
+        rc = self._lib.covahip_pipe_acquire(self._h, C.byref(slot), C.byref(fp), C.byref(ip))
+        if rc == 7:
+            return None
+        L.check(rc, "covahip_pipe_acquire")
+        if slot.value not in self._views:
+            n = self.max_frames * self.net.h * self.net.w * 4
+            frames = np.ctypeslib.as_array(C.cast(fp.value, C.POINTER(C.c_uint8)), shape=(n,)).reshape(self.max_frames, self.net.h, self.net.w, 4)
+            index = np.ctypeslib.as_array(C.cast(ip.value, C.POINTER(C.c_int32)), shape=(self.max_batch * 4,)).reshape(self.max_batch, 4)
+            self._views[slot.value] = (frames, index)
+        return (slot.value,) + self._views[slot.value]
+
+    def submit(self, slot: int, n_frames: int, batch: int, cc_threshold: int):
+        L.check(self._lib.covahip_pipe_submit(self._h, slot, n_frames, batch, cc_threshold), "covahip_pipe_submit", self.net.ctx.handle)
+        self._batch[slot] = batch
+
+    def collect(self, slot: int):
+        """-> (counts [B], offsets [B+1], packed boxes [offsets[B]], mask [B][h][w] | None): views, valid until the slot
+        is acquired again."""
+        cp, op, bp, mp = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        L.check(self._lib.covahip_pipe_collect(self._h, slot, C.byref(cp), C.byref(op), C.byref(bp), C.byref(mp)),
+                "covahip_pipe_collect", self.net.ctx.handle)
+        b = self._batch.pop(slot)
+        counts = np.ctypeslib.as_array(C.cast(cp.value, C.POINTER(C.c_int32)), shape=(b,))
+        offsets = np.ctypeslib.as_array(C.cast(op.value, C.POINTER(C.c_int32)), shape=(b + 1,))
+        total = int(offsets[b])
+        raw = np.ctypeslib.as_array(C.cast(bp.value, C.POINTER(C.c_int32)), shape=(max(total, 1) * 5,))[:total * 5]
+        boxes = raw.view(L.BOX_DTYPE)
+        mask = None
+        if mp.value:
+            mask = np.ctypeslib.as_array(C.cast(mp.value, C.POINTER(C.c_uint8)), shape=(b * self.net.h * self.net.w,)).reshape(b, self.net.h, self.net.w)
+        return counts, offsets, boxes, mask
+
+
 # -------------------------------------------------------------------------------- bbox
 def boxes_to_bbox(boxes: np.ndarray) -> np.ndarray:
     """covahip_box[] (CC stats) -> covahip_bbox[] via Bbox::new (process.rs:47)."""

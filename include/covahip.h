@@ -157,6 +157,28 @@ int covahip_filter_forward_frames(covahip_ctx *ctx, const uint8_t *frames, int n
                                   int batch, int area_thresh, covahip_box *boxes, int32_t *counts, int max_boxes,
                                   float *logits, uint8_t *mask, int mem_kind);
 
+/* Pipelined host-buffer form of the carrier-frame hot path, for a caller that batches frames continuously (the
+ * batching element gst/gstcova.c `blobnetfilter`; stands where nvstreammux -> nvinfer -> nvstreamdemux -> maskcopy
+ * -> bboxcc stand in pipeline/cova/pipeline.py:139-261).  A pipe owns n_slots batches in flight: H2D of batch k+1,
+ * the kernels of batch k and D2H of batch k-1 run on three HIP streams.  Per batch:
+ *   acquire: a free slot and its PINNED host buffers -- frames u8 [max_frames][h_mb][w_mb][4] and stack_index
+ *            i32 [max_batch][4] (see covahip_filter_forward_frames) -- which the caller fills in place;
+ *            COVAHIP_ERR_OVERFLOW when every slot is taken (collect one first);
+ *   submit:  enqueues copy-in, kernels, on-device compaction of the boxes and copy-out; returns at once;
+ *   collect: waits for that slot; counts i32 [batch] (components that pass the filter), offsets i32 [batch + 1] and
+ *            boxes [offsets[batch]] = the first min(count, max_boxes) boxes of every frame, packed; mask u8
+ *            [batch][h_mb][w_mb] when the pipe was created with want_mask (else NULL).  The pointers stay valid
+ *            until the slot is acquired again.
+ * One thread at a time per pipe and its ctx.                                                          */
+typedef struct covahip_pipe covahip_pipe;
+int covahip_pipe_create(covahip_ctx *ctx, int max_batch, int max_frames, int max_boxes, int n_slots, int want_mask,
+                        covahip_pipe **out);
+void covahip_pipe_destroy(covahip_pipe *pipe);
+int covahip_pipe_acquire(covahip_pipe *pipe, int *slot, uint8_t **frames, int32_t **stack_index);
+int covahip_pipe_submit(covahip_pipe *pipe, int slot, int n_frames, int batch, int area_thresh);
+int covahip_pipe_collect(covahip_pipe *pipe, int slot, const int32_t **counts, const int32_t **offsets,
+                         const covahip_box **boxes, const uint8_t **mask);
+
 /* --------------------------------------------------------- Bbox wire format
  * bincode 1.3 (default config) bytes of Vec<Bbox> / Frame as the reference's elements
  * exchange them (cova-rs/bbox/src/bbox.rs:4-14,84-90; cova-rs/bbox/src/lib.rs:8-22).  */

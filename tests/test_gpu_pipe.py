@@ -1,0 +1,86 @@
+"""covahip_pipe_* (pinned, three-stream pipelined host path with on-device box compaction) against the synchronous
+carrier-frame entry point on the same batches."""
+import numpy as np
+import pytest
+
+from cova_amd import _lib as L
+from cova_amd import synth
+from cova_amd.elements import BlobNetInfer, FilterPipe
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pipelined_batches_equal_synchronous_calls(ctx, weights_flat):
+    h, w, b, streams, n_batches = 45, 80, 48, 4, 7
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=64)
+    data = [synth.carrier_batch(b, h, w, seed=300 + 10 * k, streams=streams) for k in range(n_batches)]
+    ref = []
+    for frames, index in data:
+        boxes, counts, mask, _ = net.filter_frames(frames, index, 4, max_boxes=512, want_mask=True)
+        ref.append((boxes, counts, mask))
+    pipe = FilterPipe(net, max_batch=64, max_frames=64 + 3 * streams, max_boxes=512, n_slots=3, want_mask=True)
+    got, in_flight = {}, []
+    for k, (frames, index) in enumerate(data):
+        acq = pipe.acquire()
+        while acq is None:                       # every slot busy: drain the oldest
+            s0, k0 = in_flight.pop(0)
+            c, o, bx, m = pipe.collect(s0)
+            got[k0] = (c.copy(), o.copy(), bx.copy(), m.copy())
+            acq = pipe.acquire()
+        slot, pf, pi = acq
+        pf[:frames.shape[0]] = frames
+        pi[:b] = index
+        pipe.submit(slot, frames.shape[0], b, 4)
+        in_flight.append((slot, k))
+    assert len(in_flight) == 3                   # three batches were in flight at once
+    for s0, k0 in in_flight:
+        c, o, bx, m = pipe.collect(s0)
+        got[k0] = (c.copy(), o.copy(), bx.copy(), m.copy())
+    for k in range(n_batches):
+        boxes, counts, mask = ref[k]
+        c, o, bx, m = got[k]
+        np.testing.assert_array_equal(c, counts)
+        np.testing.assert_array_equal(m, mask)
+        np.testing.assert_array_equal(o, np.concatenate([[0], np.cumsum(np.minimum(counts, 512))]))
+        for i in range(b):
+            np.testing.assert_array_equal(bx[o[i]:o[i + 1]], boxes[i, :min(counts[i], 512)])
+    assert sum(int(g[1][-1]) for g in got.values()) > 0
+    pipe.close()
+
+
+def test_more_boxes_than_the_speculative_copy_and_truncation(ctx, weights_flat):
+    """Noise-like masks give hundreds of boxes per frame: more than the part of the packed array that is copied back
+    unconditionally, and with a small max_boxes every frame is truncated -- offsets follow min(count, max_boxes)."""
+    h, w, b = 68, 120, 16
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=16)
+    frames, index = synth.carrier_batch(b, h, w, seed=77, streams=2)
+    for max_boxes in (2048, 8):
+        boxes, counts, _, _ = net.filter_frames(frames, index, 1, max_boxes=max_boxes)
+        pipe = FilterPipe(net, max_batch=16, max_frames=32, max_boxes=max_boxes, n_slots=2)
+        slot, pf, pi = pipe.acquire()
+        pf[:frames.shape[0]] = frames
+        pi[:b] = index
+        pipe.submit(slot, frames.shape[0], b, 1)
+        c, o, bx, m = pipe.collect(slot)
+        assert m is None
+        np.testing.assert_array_equal(c, counts)
+        assert counts.min() > 8 and int(o[b]) == int(np.minimum(counts, max_boxes).sum())
+        for i in range(b):
+            np.testing.assert_array_equal(bx[o[i]:o[i + 1]], boxes[i, :min(counts[i], max_boxes)])
+        pipe.close()
+
+
+def test_pipe_argument_checks(ctx, weights_flat):
+    lib = L.lib()
+    net = BlobNetInfer(ctx, weights_flat, 45, 80, max_batch=8)
+    import ctypes as C
+    h = C.c_void_p()
+    assert lib.covahip_pipe_create(ctx.handle, 16, 32, 64, 2, 0, C.byref(h)) == 1      # max_batch above the model's
+    pipe = FilterPipe(net, max_batch=8, max_frames=16, max_boxes=64, n_slots=1)
+    slot, pf, pi = pipe.acquire()
+    assert pipe.acquire() is None                                                      # the only slot is taken
+    assert lib.covahip_pipe_submit(pipe._h, slot, 2, 1, 1) == 1                        # fewer than four frames
+    pi[0] = (3, 2, 1, 9)
+    assert lib.covahip_pipe_submit(pipe._h, slot, 6, 1, 1) == 1                        # index outside the frames
+    assert lib.covahip_pipe_collect(pipe._h, slot, None, None, None, None) == 1        # nothing submitted
+    pipe.close()
