@@ -172,8 +172,82 @@ static int run_cova(const char *props, const char *in_path, const char *out_path
     return rc;
 }
 
+/* ---- blobnetfilter: N request sink pads / N src pads.  Input records: 'B' with the pad index in flags >> 8, 'e' = EOS on
+ * pad flags >> 8.  Output records: 'B', pts, flags = pad index, payload. ---- */
+static FILE *mux_out;
+static GMutex mux_lock;
+static int mux_eos = 0, mux_bufs = 0;
+static GstFlowReturn mux_chain(GstPad *pad, GstObject *parent, GstBuffer *b) {
+    GstMapInfo m;
+    const uint32_t idx = (uint32_t)GPOINTER_TO_UINT(gst_pad_get_element_private(pad));
+    gst_buffer_map(b, &m, GST_MAP_READ);
+    g_mutex_lock(&mux_lock);
+    write_rec(mux_out, 'B', GST_BUFFER_PTS(b), idx, m.data, (uint32_t)m.size);
+    mux_bufs++;
+    g_mutex_unlock(&mux_lock);
+    gst_buffer_unmap(b, &m);
+    gst_buffer_unref(b);
+    return GST_FLOW_OK;
+}
+static gboolean mux_sink_event(GstPad *pad, GstObject *parent, GstEvent *ev) {
+    if (GST_EVENT_TYPE(ev) == GST_EVENT_EOS) { g_mutex_lock(&mux_lock); mux_eos++; g_mutex_unlock(&mux_lock); }
+    gst_event_unref(ev);
+    return TRUE;
+}
+static int run_mux(const char *desc, int n_pads, const char *caps, const char *in_path, const char *out_path, int sleep_ms_at_end) {
+    GError *err = NULL;
+    GstElement *e = gst_parse_launch(desc, &err);
+    FILE *fi = fopen(in_path, "rb");
+    rec_t r;
+    GstPad *srcs[64];
+    guint64 batches = 0;
+    int rc = 0;
+    if (!e || !fi || n_pads > 64) { fprintf(stderr, "mux setup failed: %s\n", err ? err->message : "?"); return 2; }
+    mux_out = fopen(out_path, "wb");
+    for (int i = 0; i < n_pads; i++) {
+        GstPad *esink = gst_element_get_request_pad(e, "sink_%u");
+        gchar *sn = g_strdup_printf("src_%d", i);
+        GstPad *esrc = gst_element_get_static_pad(e, sn);
+        GstPad *tsink = gst_pad_new("out", GST_PAD_SINK);
+        g_free(sn);
+        srcs[i] = gst_pad_new("in", GST_PAD_SRC);
+        gst_pad_set_element_private(tsink, GUINT_TO_POINTER((guint)i));
+        gst_pad_set_chain_function(tsink, mux_chain);
+        gst_pad_set_event_function(tsink, mux_sink_event);
+        gst_pad_set_active(tsink, TRUE);
+        if (!esink || !esrc || gst_pad_link(srcs[i], esink) != GST_PAD_LINK_OK || gst_pad_link(esrc, tsink) != GST_PAD_LINK_OK) {
+            fprintf(stderr, "mux link failed on pad %d\n", i);
+            return 2;
+        }
+    }
+    gst_element_set_state(e, GST_STATE_PLAYING);
+    for (int i = 0; i < n_pads; i++) { gchar *sid = g_strdup_printf("s%d", i); start_pad(srcs[i], sid, caps); g_free(sid); }
+    while (read_rec(fi, &r)) {
+        const int pad = (int)(r.flags >> 8);
+        GstFlowReturn fr = GST_FLOW_OK;
+        if (pad >= n_pads) { free(r.data); continue; }
+        if (r.kind == 'B') { r.flags &= 0xFF; fr = gst_pad_push(srcs[pad], buffer_from(&r)); }
+        else if (r.kind == 'e') gst_pad_push_event(srcs[pad], gst_event_new_eos());
+        else if (r.kind == 's') g_usleep(1000 * (gulong)r.pts);   /* pause: lets batched-push-timeout fire */
+        free(r.data);
+        if (fr != GST_FLOW_OK) { fprintf(stderr, "flow %s on pad %d\n", gst_flow_get_name(fr), pad); rc = 3; break; }
+    }
+    if (sleep_ms_at_end) g_usleep(1000 * (gulong)sleep_ms_at_end);
+    g_object_get(e, "batches", &batches, NULL);
+    g_mutex_lock(&mux_lock);
+    printf("{\"buffers\": %d, \"eos\": %d, \"batches\": %llu}\n", mux_bufs, mux_eos, (unsigned long long)batches);
+    g_mutex_unlock(&mux_lock);
+    gst_element_set_state(e, GST_STATE_NULL);
+    g_mutex_lock(&mux_lock);
+    fclose(mux_out);
+    g_mutex_unlock(&mux_lock);
+    fclose(fi);
+    return rc;
+}
+
 int main(int argc, char **argv) {
     gst_init(&argc, &argv);
+    if (argc >= 7 && !strcmp(argv[1], "mux")) return run_mux(argv[2], atoi(argv[3]), argv[4], argv[5], argv[6], argc > 7 ? atoi(argv[7]) : 0);
     if (argc >= 6 && !strcmp(argv[1], "harness")) return run_harness(argv[2], argv[3], argv[4], argv[5]);
     if (argc >= 5 && !strcmp(argv[1], "cova")) return run_cova(argv[2], argv[3], argv[4]);
     if (argc >= 5 && !strcmp(argv[1], "sink")) return run_sink(argv[2], argv[3], argv[4]);

@@ -6,6 +6,7 @@
  *   metapreprocess  <- cova-rs/gst-plugins/src/metapreprocess/imp.rs   (BaseTransform, NeverInPlace)
  *   blobnetinfer    <- nvinfer(BlobNet TensorRT engine) + maskcopy:
  *                      config/blobnet/amsterdam_b128.txt, gst-plugins/gst-maskcopy/gstmaskcopy.cpp
+ *   blobnetfilter / maskcopy: gstblobnetfilter.c (the batching filter element; maskcopy by name)
  *   bboxcc          <- cova-rs/gst-plugins/src/bboxcc/imp.rs           (BaseTransform, AlwaysInPlace)
  *   sorttracker     <- cova-rs/gst-plugins/src/sorttracker/imp.rs      (BaseTransform, NeverInPlace)
  *   cova            <- cova-rs/gst-plugins/src/cova/imp.rs             (Element, 2 sink pads + src)
@@ -31,7 +32,9 @@
 
 #include "covahip.h"
 
-GST_DEBUG_CATEGORY_STATIC(cova_debug);
+GST_DEBUG_CATEGORY(cova_debug);
+GType gst_blobnetfilter_get_type_public(void);   /* gstblobnetfilter.c */
+GType gst_maskcopy_get_type_public(void);
 #define GST_CAT_DEFAULT cova_debug
 
 #define BBOX_CAPS "bbox, width=(int)[0,2147483647], height=(int)[0,2147483647]"
@@ -1018,6 +1021,8 @@ static gboolean plugin_init(GstPlugin *plugin) {
     /* the reference registers every element with Rank::None (cova-rs/gst-plugins/src/<element>/mod.rs) */
     return gst_element_register(plugin, "metapreprocess", GST_RANK_NONE, gst_metapreprocess_get_type()) &&
            gst_element_register(plugin, "blobnetinfer", GST_RANK_NONE, gst_blobnetinfer_get_type()) &&
+           gst_element_register(plugin, "blobnetfilter", GST_RANK_NONE, gst_blobnetfilter_get_type_public()) &&
+           gst_element_register(plugin, "maskcopy", GST_RANK_NONE, gst_maskcopy_get_type_public()) &&
            gst_element_register(plugin, "bboxcc", GST_RANK_NONE, gst_bboxcc_get_type()) &&
            gst_element_register(plugin, "sorttracker", GST_RANK_NONE, gst_sorttracker_get_type()) &&
            gst_element_register(plugin, "cova", GST_RANK_NONE, gst_cova_get_type()) &&

@@ -67,6 +67,8 @@ def test_inspect_lists_reference_elements_and_properties(tmp_path):
             "cova": ["sort-iou", "sort-maxage", "sort-minhits", "port", "infer-i", "debug", "alpha", "beta", "dropped",
                      "decoded-dependency", "decoded-inference"],
             "blobnetinfer": ["model-weights-file", "gpu-id"], "bboxsink": ["location"],
+            "blobnetfilter": ["model-weights-file", "gpu-id", "batch-size", "batched-push-timeout", "cc-threshold"],
+            "maskcopy": ["unique-id", "gpu-id", "timestep"],
             "tfrecordsink": ["location", "gt", "gop"]}
     for el, props in want.items():
         r = subprocess.run([insp, el], env=_env(tmp_path), capture_output=True, text=True, timeout=60)
@@ -261,3 +263,48 @@ def test_tfrecordsink_element(tmp_path, gop):
                 assert ex[name][k] == bytes(w * h)
         for k, i in enumerate(g):
             assert ex["gt"][k] == gt[i].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch_size,timeout_us,pause", [(64, 0, False), (32, 0, False), (64, 20000, True)])
+def test_blobnetfilter_batching_element(tmp_path, weights_flat, batch_size, timeout_us, pause):
+    """blobnetfilter (N request pads; stands for metapreprocess ! nvstreammux ! nvinfer ! nvstreamdemux ! maskcopy ! bboxcc):
+    8 streams x 64 carrier frames -> per stream, per frame from the fourth on, the bincode boxes of the C-ABI path on the
+    stacks metapreprocess would have built, with the frame's PTS; batches are formed across the streams."""
+    from cova_amd import synth, weights as W
+    from cova_amd.elements import BlobNetInfer, Context
+    h, w, n_streams, n = 45, 80, 8, 64
+    carriers = [synth.carrier_frames(n, h, w, seed=700 + s, n_objects=5) for s in range(n_streams)]
+    wpath = tmp_path / "weights.bin"
+    wpath.write_bytes(W.to_bytes(weights_flat))
+    recs = []
+    for i in range(n):
+        for s in range(n_streams):
+            recs.append(("B", i * CLK, s << 8, carriers[s][i].tobytes()))
+        if pause and i == 12:
+            recs.append(("s", 150, 0, b""))                  # 150 ms without input: the open batch (16 stacks) leaves by timeout
+    recs += [("e", 0, s << 8, b"") for s in range(n_streams)]
+    _write(tmp_path / "in.rec", recs)
+    info = _run(["mux", f"blobnetfilter model-weights-file={wpath} batch-size={batch_size} batched-push-timeout={timeout_us} "
+                 f"cc-threshold=4 max-boxes=512", str(n_streams), f"video/x-raw,format=I420,width={w * 16},height={h * 16},framerate=30/1",
+                 str(tmp_path / "in.rec"), str(tmp_path / "out.rec")], tmp_path)
+    n_out = n_streams * (n - 3)
+    assert info["buffers"] == n_out and info["eos"] == n_streams
+    full = -(-n_out // batch_size)
+    assert info["batches"] == (full + 1 if pause else full)                  # the pause splits one batch in two
+    outs = _read(tmp_path / "out.rec")
+    per_stream = {s: [] for s in range(n_streams)}
+    for kind, pts, pad, payload in outs:
+        per_stream[pad].append((pts, payload))
+    ctx = Context(0)
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=n - 3)
+    total = 0
+    for s in range(n_streams):
+        stack = np.stack([np.concatenate([carriers[s][i - k] for k in range(4)], axis=0) for i in range(3, n)])
+        boxes, counts, _ = net.filter(stack, cc_threshold=4, max_boxes=512)
+        assert [p for p, _ in per_stream[s]] == [i * CLK for i in range(3, n)]        # in order, PTS of the current frame
+        for j, (_, payload) in enumerate(per_stream[s]):
+            assert payload == E.serialize_vec(E.boxes_to_bbox(boxes[j, :counts[j]]))
+            total += int(counts[j])
+    assert total > 0
+    ctx.close()
