@@ -73,7 +73,7 @@ struct Slot {
     int32_t *d_meta = nullptr;
     uint8_t *d_mask = nullptr;
     hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;
-    int state = 0;                   // 0 free, 1 acquired, 2 submitted
+    int state = 0;                   // 0 free, 1 acquired (being filled), 2 submitted, 3 collected (results in use)
     int batch = 0, n_frames = 0;
     int spec = 0;                    // packed boxes the pipelined D2H of this submission carries
 };
@@ -217,6 +217,18 @@ int covahip_pipe_submit(covahip_pipe *p, int slot, int n_frames, int batch, int 
     return COVAHIP_OK;
 }
 
+int covahip_pipe_wait(covahip_pipe *p, int slot) {
+    if (!p || slot < 0 || slot >= p->n_slots || p->slots[slot].state != 2) return COVAHIP_ERR_INVALID_ARG;
+    if (hipEventSynchronize(p->slots[slot].ev_out) != hipSuccess) return COVAHIP_ERR_HIP;
+    return COVAHIP_OK;
+}
+
+int covahip_pipe_release(covahip_pipe *p, int slot) {
+    if (!p || slot < 0 || slot >= p->n_slots || p->slots[slot].state != 3) return COVAHIP_ERR_INVALID_ARG;
+    p->slots[slot].state = 0;
+    return COVAHIP_OK;
+}
+
 int covahip_pipe_collect(covahip_pipe *p, int slot, const int32_t **counts, const int32_t **offsets, const covahip_box **boxes,
                          const uint8_t **mask) {
     if (!p || slot < 0 || slot >= p->n_slots || p->slots[slot].state != 2) return COVAHIP_ERR_INVALID_ARG;
@@ -235,7 +247,7 @@ int covahip_pipe_collect(covahip_pipe *p, int slot, const int32_t **counts, cons
     if (offsets) *offsets = off;
     if (boxes) *boxes = s.h_packed;
     if (mask) *mask = s.h_mask;
-    s.state = 0;   // results stay valid until the slot is acquired again
+    s.state = 3;   // the results belong to the caller until covahip_pipe_release
     return COVAHIP_OK;
 }
 

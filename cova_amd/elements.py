@@ -242,6 +242,7 @@ class FilterPipe:
         self._h = h
         self._batch = {}
         self._views = {}     # slot -> numpy views of its pinned input buffers (the addresses never change)
+        self._held = []      # collected slots whose result views are still handed out
 
     def close(self):
         if getattr(self, "_h", None):
@@ -252,7 +253,10 @@ class FilterPipe:
 
     def acquire(self):
         """-> (slot, frames u8 [max_frames][h][w][4], index i32 [max_batch][4]): numpy views of the slot's pinned buffers,
-        or None when every slot is in flight."""
+        or None when every slot is in flight.  Result views of earlier collect() calls become invalid."""
+        for held in self._held:
+            L.check(self._lib.covahip_pipe_release(self._h, held), "covahip_pipe_release")
+        self._held = []
         slot, fp, ip = C.c_int(), C.c_void_p(), C.c_void_p()
         rc = self._lib.covahip_pipe_acquire(self._h, C.byref(slot), C.byref(fp), C.byref(ip))
         if rc == 7:
@@ -270,12 +274,13 @@ class FilterPipe:
         self._batch[slot] = batch
 
     def collect(self, slot: int):
-        """-> (counts [B], offsets [B+1], packed boxes [offsets[B]], mask [B][h][w] | None): views, valid until the slot
-        is acquired again."""
+        """-> (counts [B], offsets [B+1], packed boxes [offsets[B]], mask [B][h][w] | None): views, valid until the next
+        acquire()."""
         cp, op, bp, mp = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
         L.check(self._lib.covahip_pipe_collect(self._h, slot, C.byref(cp), C.byref(op), C.byref(bp), C.byref(mp)),
                 "covahip_pipe_collect", self.net.ctx.handle)
         b = self._batch.pop(slot)
+        self._held.append(slot)
         counts = np.ctypeslib.as_array(C.cast(cp.value, C.POINTER(C.c_int32)), shape=(b,))
         offsets = np.ctypeslib.as_array(C.cast(op.value, C.POINTER(C.c_int32)), shape=(b + 1,))
         total = int(offsets[b])

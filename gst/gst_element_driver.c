@@ -245,8 +245,84 @@ static int run_mux(const char *desc, int n_pads, const char *caps, const char *i
     return rc;
 }
 
+/* ---- muxbench: blobnetfilter fed by one thread per stream with in-memory carrier frames; prints frames/s ---- */
+typedef struct { GstPad *src; GstBuffer **bufs; int n_bufs, n_frames; } bench_feed_t;
+static gpointer bench_feeder(gpointer data) {
+    bench_feed_t *f = data;
+    for (int i = 0; i < f->n_frames; i++) {
+        GstBuffer *b = gst_buffer_copy(f->bufs[i % f->n_bufs]);   /* shares the memory, own metadata */
+        GST_BUFFER_PTS(b) = (GstClockTime)i * (GST_SECOND / 30);
+        if (gst_pad_push(f->src, b) != GST_FLOW_OK) break;
+    }
+    gst_pad_push_event(f->src, gst_event_new_eos());
+    return NULL;
+}
+static GstFlowReturn bench_chain(GstPad *pad, GstObject *parent, GstBuffer *b) {
+    g_mutex_lock(&mux_lock);
+    mux_bufs++;
+    g_mutex_unlock(&mux_lock);
+    gst_buffer_unref(b);
+    return GST_FLOW_OK;
+}
+static int run_muxbench(const char *desc, int n_pads, int w_px, int h_px, int frames_per_pad) {
+    GError *err = NULL;
+    GstElement *e = gst_parse_launch(desc, &err);
+    bench_feed_t feeds[64];
+    GThread *th[64];
+    gchar *caps = g_strdup_printf("video/x-raw,format=I420,width=%d,height=%d,framerate=30/1", w_px, h_px);
+    const gsize fb = (gsize)(w_px / 16) * (h_px / 16) * 4;
+    guint64 batches = 0;
+    if (!e || n_pads > 64) { fprintf(stderr, "muxbench setup failed: %s\n", err ? err->message : "?"); return 2; }
+    for (int i = 0; i < n_pads; i++) {
+        GstPad *esink = gst_element_get_request_pad(e, "sink_%u");
+        gchar *sn = g_strdup_printf("src_%d", i);
+        GstPad *esrc = gst_element_get_static_pad(e, sn);
+        GstPad *tsink = gst_pad_new("out", GST_PAD_SINK);
+        g_free(sn);
+        feeds[i].src = gst_pad_new("in", GST_PAD_SRC);
+        feeds[i].n_bufs = 16;
+        feeds[i].n_frames = frames_per_pad;
+        feeds[i].bufs = g_new(GstBuffer *, 16);
+        for (int k = 0; k < 16; k++) {
+            GstMapInfo m;
+            unsigned x = 777u * (unsigned)(i * 16 + k + 1);
+            feeds[i].bufs[k] = gst_buffer_new_allocate(NULL, fb, NULL);
+            gst_buffer_map(feeds[i].bufs[k], &m, GST_MAP_WRITE);
+            for (gsize q = 0; q < fb; q++) { x = x * 1664525u + 1013904223u; m.data[q] = (x >> 24) < 40 ? (x >> 16) % 7 : 0; }
+            gst_buffer_unmap(feeds[i].bufs[k], &m);
+        }
+        gst_pad_set_chain_function(tsink, bench_chain);
+        gst_pad_set_event_function(tsink, mux_sink_event);
+        gst_pad_set_active(tsink, TRUE);
+        if (!esink || !esrc || gst_pad_link(feeds[i].src, esink) != GST_PAD_LINK_OK || gst_pad_link(esrc, tsink) != GST_PAD_LINK_OK) return 2;
+    }
+    gst_element_set_state(e, GST_STATE_PLAYING);
+    for (int i = 0; i < n_pads; i++) { gchar *sid = g_strdup_printf("s%d", i); start_pad(feeds[i].src, sid, caps); g_free(sid); }
+    {   /* model load and pipe creation happen with the first frame: push one warm-up frame per stream before the clock starts */
+        for (int i = 0; i < n_pads; i++) {
+            GstBuffer *b = gst_buffer_copy(feeds[i].bufs[0]);
+            GST_BUFFER_PTS(b) = 0;
+            gst_pad_push(feeds[i].src, b);
+        }
+    }
+    const gint64 t0 = g_get_monotonic_time();
+    for (int i = 0; i < n_pads; i++) th[i] = g_thread_new("feed", bench_feeder, &feeds[i]);
+    for (int i = 0; i < n_pads; i++) g_thread_join(th[i]);
+    const gint64 t1 = g_get_monotonic_time();
+    g_object_get(e, "batches", &batches, NULL);
+    g_mutex_lock(&mux_lock);
+    printf("{\"frames_per_s_through_elements\": %.1f, \"streams\": %d, \"frames_in\": %d, \"buffers_out\": %d, \"eos\": %d, \"batches\": %llu, \"seconds\": %.4f}\n",
+           (double)n_pads * frames_per_pad / ((t1 - t0) * 1e-6), n_pads, n_pads * frames_per_pad, mux_bufs, mux_eos,
+           (unsigned long long)batches, (t1 - t0) * 1e-6);
+    g_mutex_unlock(&mux_lock);
+    gst_element_set_state(e, GST_STATE_NULL);
+    g_free(caps);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     gst_init(&argc, &argv);
+    if (argc >= 7 && !strcmp(argv[1], "muxbench")) return run_muxbench(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
     if (argc >= 7 && !strcmp(argv[1], "mux")) return run_mux(argv[2], atoi(argv[3]), argv[4], argv[5], argv[6], argc > 7 ? atoi(argv[7]) : 0);
     if (argc >= 6 && !strcmp(argv[1], "harness")) return run_harness(argv[2], argv[3], argv[4], argv[5]);
     if (argc >= 5 && !strcmp(argv[1], "cova")) return run_cova(argv[2], argv[3], argv[4]);

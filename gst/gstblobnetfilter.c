@@ -27,13 +27,13 @@ GST_DEBUG_CATEGORY_EXTERN(cova_debug);
 #define GST_CAT_DEFAULT cova_debug
 
 #define BF_TIMESTEP 4
-#define BF_SLOTS 3
+#define BF_SLOTS 6
 
 /* ===================================================================== blobnetfilter */
 typedef struct {
     GstPad *sink, *src;
     guint idx;
-    guint8 *hist[BF_TIMESTEP - 1];   /* the last three carrier frames: [0] newest */
+    GstBuffer *hist[BF_TIMESTEP - 1]; /* the last three carrier frames (references, no copies): [0] newest */
     gint hist_pos[BF_TIMESTEP - 1];  /* their position in the slot being filled, -1 = not copied into it yet */
     guint n_seen;
     gboolean eos, caps_sent;
@@ -41,12 +41,22 @@ typedef struct {
 
 typedef struct { guint pad; GstClockTime pts, duration; } BfMeta;
 typedef struct { int slot; int n_stacks; BfMeta *meta; } BfFlight;
+#define BF_PUSHERS 8
+typedef struct _GstBlobNetFilter GstBlobNetFilter;
+typedef struct {   /* one share of a finished batch: the stacks of the src pads with pad % BF_PUSHERS == group */
+    GstBlobNetFilter *s;
+    BfFlight *fl;
+    const int32_t *counts, *offsets;
+    const covahip_box *boxes;
+    guint group;
+} BfPushTask;
 
-typedef struct {
+struct _GstBlobNetFilter {
     GstElement parent;
     GMutex lock, push_lock;
     GCond cond, flush_cond;
     gboolean flushing;        /* a flush has dropped the lock to push results: the slot pointers are in flux */
+    gint pending;             /* streaming threads still copying their frame into the slot being filled (lock not held) */
     gchar *weights;
     guint gpu_id, batch_size, cc_threshold, max_boxes;
     guint64 timeout_us;
@@ -62,11 +72,17 @@ typedef struct {
     int n_frames, n_stacks, max_frames;
     BfMeta *meta;
     gint64 first_us;
-    GQueue flights;           /* BfFlight*, oldest first */
-    GThread *timer;
+    GQueue flights;           /* BfFlight*, oldest first: submitted, not yet taken by the collector */
+    guint in_flight;          /* submitted batches whose results have not all been pushed yet */
+    GCond slot_cond;          /* a slot was released / a flight was queued / all flights are done */
+    GCond push_cond;          /* with push_lock: the last share of a batch has been pushed */
+    GThread *timer, *collector;
+    GThreadPool *pushers;
+    gint push_left;           /* shares of the current batch still being pushed */
+    GstFlowReturn push_ret;
     gboolean stop, failed;
     guint64 batches, frames_out;
-} GstBlobNetFilter;
+};
 typedef struct { GstElementClass parent_class; } GstBlobNetFilterClass;
 G_DEFINE_TYPE(GstBlobNetFilter, gst_blobnetfilter, GST_TYPE_ELEMENT)
 enum { BF_PROP_0, BF_PROP_WEIGHTS, BF_PROP_GPU, BF_PROP_BATCH, BF_PROP_TIMEOUT, BF_PROP_CC, BF_PROP_MAXBOXES, BF_PROP_BATCHES };
@@ -103,76 +119,104 @@ static gboolean bf_ensure_model(GstBlobNetFilter *s) {   /* lock held */
     return TRUE;
 }
 
-/* Pushes the results of one finished batch on the src pads of its streams (push_lock held, element lock NOT held). */
-static GstFlowReturn bf_push_results(GstBlobNetFilter *s, BfFlight *fl, const int32_t *counts, const int32_t *offsets,
-                                     const covahip_box *boxes) {
+/* One share of a finished batch: the boxes of every stack of this share's src pads as bincode Vec<Bbox> buffers with
+ * the frame's PTS (bboxcc/imp.rs:232-272).  A src pad is served by exactly one pusher thread, batches are pushed one
+ * after the other: buffers leave every pad in order. */
+static void bf_push_share(gpointer data, gpointer user) {
+    BfPushTask *t = data;
+    GstBlobNetFilter *s = t->s;
     GstFlowReturn ret = GST_FLOW_OK;
     covahip_bbox *bb = g_new(covahip_bbox, s->max_boxes ? s->max_boxes : 1);
-    for (int i = 0; i < fl->n_stacks; i++) {
-        const int n = offsets[i + 1] - offsets[i];
+    for (int i = 0; i < t->fl->n_stacks; i++) {
+        const BfMeta *mt = &t->fl->meta[i];
+        if (mt->pad % BF_PUSHERS != t->group) continue;
+        const int n = t->offsets[i + 1] - t->offsets[i];
         int st = 0;
         GstMapInfo m;
-        GstBuffer *b;
-        gsize len;
-        BfPad *p = g_ptr_array_index(s->pads, fl->meta[i].pad);
-        if (counts[i] > n) GST_WARNING_OBJECT(s, "frame with %d boxes truncated to max-boxes = %d", counts[i], n);
-        covahip_boxes_to_bbox(boxes + offsets[i], n, bb);                      /* Bbox::new, process.rs:47 */
-        len = covahip_bbox_serialize_vec(bb, (size_t)n, NULL, 0, NULL);
-        b = gst_buffer_new_allocate(NULL, len, NULL);
+        BfPad *p = g_ptr_array_index(s->pads, mt->pad);
+        if (t->counts[i] > n) GST_WARNING_OBJECT(s, "frame with %d boxes truncated to max-boxes = %d", t->counts[i], n);
+        covahip_boxes_to_bbox(t->boxes + t->offsets[i], n, bb);                /* Bbox::new, process.rs:47 */
+        const gsize len = covahip_bbox_serialize_vec(bb, (size_t)n, NULL, 0, NULL);
+        GstBuffer *b = gst_buffer_new_allocate(NULL, len, NULL);
         gst_buffer_map(b, &m, GST_MAP_WRITE);
         covahip_bbox_serialize_vec(bb, (size_t)n, m.data, m.size, &st);
         gst_buffer_unmap(b, &m);
-        GST_BUFFER_PTS(b) = fl->meta[i].pts;
-        GST_BUFFER_DURATION(b) = fl->meta[i].duration;
-        {
-            const GstFlowReturn r = gst_pad_push(p->src, b);
-            if (r != GST_FLOW_OK && r != GST_FLOW_NOT_LINKED && ret == GST_FLOW_OK) ret = r;
-        }
+        GST_BUFFER_PTS(b) = mt->pts;
+        GST_BUFFER_DURATION(b) = mt->duration;
+        const GstFlowReturn r = gst_pad_push(p->src, b);
+        if (r != GST_FLOW_OK && r != GST_FLOW_NOT_LINKED && ret == GST_FLOW_OK) ret = r;
     }
     g_free(bb);
-    return ret;
-}
-
-/* Collects the oldest batch in flight and pushes it.  Called with the element lock held; drops it while pushing. */
-static GstFlowReturn bf_collect_one(GstBlobNetFilter *s) {
-    BfFlight *fl = g_queue_pop_head(&s->flights);
-    const int32_t *counts, *offsets;
-    const covahip_box *boxes;
-    GstFlowReturn ret;
-    int rc;
-    if (!fl) return GST_FLOW_OK;
-    /* push_lock is taken before the element lock is dropped: results leave in submission order */
     g_mutex_lock(&s->push_lock);
-    rc = covahip_pipe_collect(s->pipe, fl->slot, &counts, &offsets, &boxes, NULL);
-    g_mutex_unlock(&s->lock);
-    if (rc == COVAHIP_OK) {
-        ret = bf_push_results(s, fl, counts, offsets, boxes);
-        s->frames_out += (guint64)fl->n_stacks;
-    } else {
-        GST_ELEMENT_ERROR(s, LIBRARY, FAILED, ("covahip_pipe_collect: %s", covahip_strerror(rc)), (NULL));
-        ret = GST_FLOW_ERROR;
-    }
+    if (ret != GST_FLOW_OK) s->push_ret = ret;
+    if (--s->push_left == 0) g_cond_broadcast(&s->push_cond);
     g_mutex_unlock(&s->push_lock);
-    g_free(fl->meta);
-    g_free(fl);
-    g_mutex_lock(&s->lock);
-    return ret;
+    g_free(t);
 }
 
+/* Collector thread: takes the submitted batches in order, waits for their results (the GPU works on the next batch
+ * meanwhile, the streaming threads fill the one after), fans the pushes out to the pusher threads, releases the slot. */
+static gpointer bf_collector(gpointer data) {
+    GstBlobNetFilter *s = data;
+    g_mutex_lock(&s->lock);
+    while (TRUE) {
+        BfFlight *fl;
+        const int32_t *counts = NULL, *offsets = NULL;
+        const covahip_box *boxes = NULL;
+        int rc;
+        while (!s->stop && g_queue_is_empty(&s->flights)) g_cond_wait(&s->slot_cond, &s->lock);
+        if (g_queue_is_empty(&s->flights)) break;   /* stop */
+        fl = g_queue_pop_head(&s->flights);
+        g_mutex_unlock(&s->lock);
+        rc = covahip_pipe_wait(s->pipe, fl->slot);   /* blocks on the D2H event only: no pipe state is touched */
+        g_mutex_lock(&s->lock);
+        if (rc == COVAHIP_OK) rc = covahip_pipe_collect(s->pipe, fl->slot, &counts, &offsets, &boxes, NULL);
+        g_mutex_unlock(&s->lock);
+        if (rc == COVAHIP_OK) {
+            g_mutex_lock(&s->push_lock);
+            s->push_left = BF_PUSHERS;
+            g_mutex_unlock(&s->push_lock);
+            for (guint g = 0; g < BF_PUSHERS; g++) {
+                BfPushTask *t = g_new(BfPushTask, 1);
+                t->s = s; t->fl = fl; t->counts = counts; t->offsets = offsets; t->boxes = boxes; t->group = g;
+                g_thread_pool_push(s->pushers, t, NULL);
+            }
+            g_mutex_lock(&s->push_lock);
+            while (s->push_left > 0) g_cond_wait(&s->push_cond, &s->push_lock);
+            g_mutex_unlock(&s->push_lock);
+        } else {
+            GST_ELEMENT_ERROR(s, LIBRARY, FAILED, ("covahip_pipe_collect: %s", covahip_strerror(rc)), (NULL));
+        }
+        g_mutex_lock(&s->lock);
+        if (rc == COVAHIP_OK) covahip_pipe_release(s->pipe, fl->slot);
+        s->frames_out += (guint64)fl->n_stacks;
+        s->in_flight--;
+        g_cond_broadcast(&s->slot_cond);
+        g_free(fl->meta);
+        g_free(fl);
+    }
+    g_mutex_unlock(&s->lock);
+    return NULL;
+}
+
+/* Waits until no other thread is in the middle of a flush.  The caller re-evaluates its reason to flush afterwards:
+ * the batch it saw full has been submitted by then. */
+static void bf_wait_idle(GstBlobNetFilter *s) {
+    while (s->flushing) g_cond_wait(&s->flush_cond, &s->lock);
+}
 /* Submits the batch being filled (if any) and opens the next slot.  Lock held; it is dropped while results of
  * older batches are pushed downstream, `flushing` keeps every other thread away from the slot state meanwhile. */
 static GstFlowReturn bf_flush_locked(GstBlobNetFilter *s);
-static GstFlowReturn bf_flush(GstBlobNetFilter *s) {
+static GstFlowReturn bf_flush(GstBlobNetFilter *s) {   /* caller: lock held, s->flushing false (bf_wait_idle) */
     GstFlowReturn ret;
-    while (s->flushing) g_cond_wait(&s->flush_cond, &s->lock);
     s->flushing = TRUE;
+    while (g_atomic_int_get(&s->pending) > 0) g_thread_yield();   /* frames of this batch still being copied in (microseconds) */
     ret = bf_flush_locked(s);
     s->flushing = FALSE;
     g_cond_broadcast(&s->flush_cond);
     return ret;
 }
 static GstFlowReturn bf_flush_locked(GstBlobNetFilter *s) {
-    GstFlowReturn ret = GST_FLOW_OK;
     int rc;
     if (s->n_stacks > 0) {
         BfFlight *fl = g_new0(BfFlight, 1);
@@ -186,21 +230,21 @@ static GstFlowReturn bf_flush_locked(GstBlobNetFilter *s) {
         fl->n_stacks = s->n_stacks;
         fl->meta = g_memdup(s->meta, sizeof(BfMeta) * (guint)s->n_stacks);
         g_queue_push_tail(&s->flights, fl);
+        s->in_flight++;
         s->batches++;
         s->slot = -1;
+        g_cond_broadcast(&s->slot_cond);
     } else if (s->slot >= 0) {
-        /* frames without a complete stack yet (stream start): keep filling the same slot */
-        return GST_FLOW_OK;
+        return GST_FLOW_OK;   /* frames without a complete stack yet (stream start): keep filling the same slot */
     }
-    /* keep at most BF_SLOTS - 1 batches in flight: one slot is always being filled */
-    while (ret == GST_FLOW_OK && (int)g_queue_get_length(&s->flights) > BF_SLOTS - 1) ret = bf_collect_one(s);
+    /* the next slot: when all of them are in flight, wait for the collector to release one (the lock is dropped in the
+     * wait; `flushing` keeps the other streaming threads out meanwhile) */
     while (s->slot < 0) {
         rc = covahip_pipe_acquire(s->pipe, &s->slot, &s->pf, &s->pi);
         if (rc == COVAHIP_ERR_OVERFLOW) {
             s->slot = -1;
-            const GstFlowReturn r = bf_collect_one(s);
-            if (ret == GST_FLOW_OK) ret = r;
-            if (g_queue_is_empty(&s->flights) && r != GST_FLOW_OK) break;
+            if (s->stop) return GST_FLOW_FLUSHING;
+            g_cond_wait(&s->slot_cond, &s->lock);
         } else if (rc != COVAHIP_OK) {
             return GST_FLOW_ERROR;
         }
@@ -210,69 +254,92 @@ static GstFlowReturn bf_flush_locked(GstBlobNetFilter *s) {
         BfPad *p = g_ptr_array_index(s->pads, i);
         for (int k = 0; k < BF_TIMESTEP - 1; k++) p->hist_pos[k] = -1;
     }
-    return ret;
+    return s->push_ret;
 }
 
+/* One carrier frame of one stream.  Positions in the slot are reserved under the lock; the 32 KB copies into the pinned
+ * slot run outside it, so the streaming threads of the N decoder branches copy in parallel. */
 static GstFlowReturn bf_chain(GstPad *pad, GstObject *parent, GstBuffer *buf) {
     GstBlobNetFilter *s = (GstBlobNetFilter *)parent;
     BfPad *p = bf_pad_of(s, pad);
     GstFlowReturn ret = GST_FLOW_OK;
-    GstMapInfo m;
+    GstBuffer *need[BF_TIMESTEP - 1] = {NULL, NULL, NULL};   /* history frames this slot does not hold yet */
+    int need_pos[BF_TIMESTEP - 1] = {0, 0, 0};
+    uint8_t *pf;
+    int pos;
+    gboolean full = FALSE;
+    if (gst_buffer_get_size(buf) < s->frame_bytes || !s->frame_bytes) {
+        GST_ELEMENT_ERROR(s, STREAM, FORMAT, ("carrier frame of %" G_GSIZE_FORMAT " bytes, need %" G_GSIZE_FORMAT " (caps set?)",
+                                              gst_buffer_get_size(buf), s->frame_bytes), (NULL));
+        gst_buffer_unref(buf);
+        return GST_FLOW_ERROR;
+    }
     g_mutex_lock(&s->lock);
-    while (s->flushing) g_cond_wait(&s->flush_cond, &s->lock);
-    if (!p->hist[0] || !bf_ensure_model(s) || !gst_buffer_map(buf, &m, GST_MAP_READ)) {
-        g_mutex_unlock(&s->lock);
-        gst_buffer_unref(buf);
-        return GST_FLOW_ERROR;
+    bf_wait_idle(s);
+    if (!bf_ensure_model(s)) ret = GST_FLOW_ERROR;
+    /* room for this frame and, at worst, three history frames of its stream; a full batch whose last copier has not
+     * come back yet is flushed by whoever arrives first */
+    while (ret == GST_FLOW_OK && (s->n_frames + BF_TIMESTEP > s->max_frames || s->n_stacks >= (int)s->batch_size)) {
+        if (s->n_stacks == 0) break;   /* nothing to submit: the streams' warm-up frames alone fill the slot */
+        ret = bf_flush(s);
+        bf_wait_idle(s);
     }
-    if (m.size < s->frame_bytes) {
-        gst_buffer_unmap(buf, &m);
-        g_mutex_unlock(&s->lock);
-        gst_buffer_unref(buf);
-        GST_ELEMENT_ERROR(s, STREAM, FORMAT, ("carrier frame of %" G_GSIZE_FORMAT " bytes, need %" G_GSIZE_FORMAT, m.size, s->frame_bytes), (NULL));
-        return GST_FLOW_ERROR;
-    }
-    /* room for this frame and, at worst, three history frames of its stream */
-    if (s->n_frames + BF_TIMESTEP > s->max_frames) ret = bf_flush(s);
     if (ret == GST_FLOW_OK && s->n_frames + BF_TIMESTEP > s->max_frames) {
         GST_ELEMENT_ERROR(s, CORE, FAILED, ("batch-size %u is too small for %u streams", s->batch_size, s->pads->len), (NULL));
         ret = GST_FLOW_ERROR;
     }
-    if (ret == GST_FLOW_OK) {
-        const int pos = s->n_frames++;
-        memcpy(s->pf + (gsize)pos * s->frame_bytes, m.data, s->frame_bytes);   /* metapreprocess copies the same bytes (imp.rs:311-312) */
-        if (p->n_seen >= BF_TIMESTEP - 1) {
-            /* a complete stack: T = 0 is this frame, T = k the frame k steps back (imp.rs:307-320) */
-            int32_t *row = s->pi + (gsize)s->n_stacks * BF_TIMESTEP;
-            row[0] = pos;
-            for (int k = 0; k < BF_TIMESTEP - 1; k++) {
-                if (p->hist_pos[k] < 0) {   /* first use in this slot: the frame came with an earlier batch */
-                    p->hist_pos[k] = s->n_frames++;
-                    memcpy(s->pf + (gsize)p->hist_pos[k] * s->frame_bytes, p->hist[k], s->frame_bytes);
-                }
-                row[k + 1] = p->hist_pos[k];
-            }
-            s->meta[s->n_stacks].pad = p->idx;
-            s->meta[s->n_stacks].pts = GST_BUFFER_PTS(buf);
-            s->meta[s->n_stacks].duration = GST_BUFFER_DURATION(buf);
-            if (s->n_stacks == 0) s->first_us = g_get_monotonic_time();
-            s->n_stacks++;
-        }
-        /* history: newest first */
-        {
-            guint8 *oldest = p->hist[BF_TIMESTEP - 2];
-            for (int k = BF_TIMESTEP - 2; k > 0; k--) { p->hist[k] = p->hist[k - 1]; p->hist_pos[k] = p->hist_pos[k - 1]; }
-            p->hist[0] = oldest;
-            memcpy(p->hist[0], m.data, s->frame_bytes);
-            p->hist_pos[0] = pos;
-            p->n_seen++;
-        }
-        if (s->n_stacks >= (int)s->batch_size) ret = bf_flush(s);
+    if (ret != GST_FLOW_OK) {
+        g_mutex_unlock(&s->lock);
+        gst_buffer_unref(buf);
+        return ret;
     }
-    gst_buffer_unmap(buf, &m);
-    g_cond_signal(&s->cond);
+    pf = s->pf;
+    pos = s->n_frames++;
+    if (p->n_seen >= BF_TIMESTEP - 1) {
+        /* a complete stack: T = 0 is this frame, T = k the frame k steps back (metapreprocess/imp.rs:307-320) */
+        int32_t *row = s->pi + (gsize)s->n_stacks * BF_TIMESTEP;
+        row[0] = pos;
+        for (int k = 0; k < BF_TIMESTEP - 1; k++) {
+            if (p->hist_pos[k] < 0) {   /* first use in this slot: the frame came with an earlier batch */
+                p->hist_pos[k] = s->n_frames++;
+                need[k] = gst_buffer_ref(p->hist[k]);
+                need_pos[k] = p->hist_pos[k];
+            }
+            row[k + 1] = p->hist_pos[k];
+        }
+        s->meta[s->n_stacks].pad = p->idx;
+        s->meta[s->n_stacks].pts = GST_BUFFER_PTS(buf);
+        s->meta[s->n_stacks].duration = GST_BUFFER_DURATION(buf);
+        if (s->n_stacks == 0) {
+            s->first_us = g_get_monotonic_time();
+            if (s->timeout_us) g_cond_signal(&s->cond);   /* the timeout thread starts its clock for this batch */
+        }
+        s->n_stacks++;
+        full = s->n_stacks >= (int)s->batch_size;
+    }
+    /* history: newest first; the element keeps references, the frame bytes are copied once, into the slot */
+    if (p->hist[BF_TIMESTEP - 2]) gst_buffer_unref(p->hist[BF_TIMESTEP - 2]);
+    for (int k = BF_TIMESTEP - 2; k > 0; k--) { p->hist[k] = p->hist[k - 1]; p->hist_pos[k] = p->hist_pos[k - 1]; }
+    p->hist[0] = buf;                 /* takes over the reference the chain function was given */
+    p->hist_pos[0] = pos;
+    p->n_seen++;
+    g_atomic_int_inc(&s->pending);
     g_mutex_unlock(&s->lock);
-    gst_buffer_unref(buf);
+
+    gst_buffer_extract(buf, 0, pf + (gsize)pos * s->frame_bytes, s->frame_bytes);   /* metapreprocess copies the same bytes (imp.rs:311-312) */
+    for (int k = 0; k < BF_TIMESTEP - 1; k++)
+        if (need[k]) {
+            gst_buffer_extract(need[k], 0, pf + (gsize)need_pos[k] * s->frame_bytes, s->frame_bytes);
+            gst_buffer_unref(need[k]);
+        }
+
+    g_atomic_int_add(&s->pending, -1);
+    if (full) {   /* the frame that completed the batch submits it, unless a later arrival has done so already */
+        g_mutex_lock(&s->lock);
+        bf_wait_idle(s);
+        if (s->n_stacks >= (int)s->batch_size) ret = bf_flush(s);
+        g_mutex_unlock(&s->lock);
+    }
     return ret;
 }
 
@@ -283,7 +350,7 @@ static gpointer bf_timer(gpointer data) {
     while (!s->stop) {
         if (s->pipe && s->n_stacks > 0 && s->timeout_us > 0) {
             const gint64 due = s->first_us + (gint64)s->timeout_us;
-            if (s->flushing) g_cond_wait(&s->flush_cond, &s->lock);
+            if (s->flushing) bf_wait_idle(s);
             else if (g_get_monotonic_time() >= due) bf_flush(s);
             else g_cond_wait_until(&s->cond, &s->lock, due);
         } else {
@@ -310,9 +377,6 @@ static gboolean bf_sink_event(GstPad *pad, GstObject *parent, GstEvent *ev) {
             ok = (s->w_mb == 0 && s->h_mb == 0) || (s->w_mb == w && s->h_mb == h);
             if (ok) { s->w_mb = w; s->h_mb = h; s->frame_bytes = (gsize)w * h * 4; }
         }
-        if (ok)
-            for (int k = 0; k < BF_TIMESTEP - 1; k++)
-                if (!p->hist[k]) p->hist[k] = g_malloc0(s->frame_bytes);
         g_mutex_unlock(&s->lock);
         if (!ok) { GST_ELEMENT_ERROR(s, CORE, NEGOTIATION, ("all streams of a blobnetfilter must have one picture size"), (NULL)); gst_event_unref(ev); return FALSE; }
         out = gst_caps_new_simple("bbox", "width", G_TYPE_INT, s->w_mb, "height", G_TYPE_INT, s->h_mb, NULL);   /* bboxcc/imp.rs:199-211 */
@@ -327,8 +391,9 @@ static gboolean bf_sink_event(GstPad *pad, GstObject *parent, GstEvent *ev) {
         p->eos = TRUE;
         for (guint i = 0; i < s->pads->len; i++) all = all && ((BfPad *)g_ptr_array_index(s->pads, i))->eos;
         if (all && s->pipe) {   /* the last stream ended: the open batch and everything in flight leave, then EOS on every src pad */
+            bf_wait_idle(s);
             bf_flush(s);
-            while (!g_queue_is_empty(&s->flights)) bf_collect_one(s);
+            while (s->in_flight > 0) g_cond_wait(&s->slot_cond, &s->lock);   /* every result has been pushed */
         }
         g_mutex_unlock(&s->lock);
         gst_event_unref(ev);
@@ -375,19 +440,27 @@ static GstStateChangeReturn bf_change_state(GstElement *e, GstStateChange t) {
     if (t == GST_STATE_CHANGE_READY_TO_PAUSED) {
         g_mutex_lock(&s->lock);
         s->stop = FALSE;
+        s->push_ret = GST_FLOW_OK;
+        if (!s->pushers) s->pushers = g_thread_pool_new(bf_push_share, s, BF_PUSHERS, FALSE, NULL);
         if (!s->timer) s->timer = g_thread_new("blobnetfilter-timeout", bf_timer, s);
+        if (!s->collector) s->collector = g_thread_new("blobnetfilter-collect", bf_collector, s);
         g_mutex_unlock(&s->lock);
     }
     r = GST_ELEMENT_CLASS(gst_blobnetfilter_parent_class)->change_state(e, t);
     if (t == GST_STATE_CHANGE_PAUSED_TO_READY) {
-        GThread *th;
+        GThread *th, *tc;
         g_mutex_lock(&s->lock);
         s->stop = TRUE;
-        g_cond_signal(&s->cond);
+        g_cond_broadcast(&s->cond);
+        g_cond_broadcast(&s->slot_cond);
+        g_cond_broadcast(&s->flush_cond);
         th = s->timer;
-        s->timer = NULL;
+        tc = s->collector;
+        s->timer = s->collector = NULL;
         g_mutex_unlock(&s->lock);
         if (th) g_thread_join(th);
+        if (tc) g_thread_join(tc);   /* drains the batches still queued */
+        if (s->pushers) { g_thread_pool_free(s->pushers, FALSE, TRUE); s->pushers = NULL; }
     }
     return r;
 }
@@ -427,7 +500,8 @@ static void bf_finalize(GObject *o) {
     if (s->ctx) covahip_ctx_destroy(s->ctx);
     for (guint i = 0; i < s->pads->len; i++) {
         BfPad *p = g_ptr_array_index(s->pads, i);
-        for (int k = 0; k < BF_TIMESTEP - 1; k++) g_free(p->hist[k]);
+        for (int k = 0; k < BF_TIMESTEP - 1; k++)
+            if (p->hist[k]) gst_buffer_unref(p->hist[k]);
         g_free(p);
     }
     g_ptr_array_free(s->pads, TRUE);
@@ -437,6 +511,8 @@ static void bf_finalize(GObject *o) {
     g_mutex_clear(&s->push_lock);
     g_cond_clear(&s->cond);
     g_cond_clear(&s->flush_cond);
+    g_cond_clear(&s->slot_cond);
+    g_cond_clear(&s->push_cond);
     G_OBJECT_CLASS(gst_blobnetfilter_parent_class)->finalize(o);
 }
 static void gst_blobnetfilter_init(GstBlobNetFilter *s) {
@@ -444,6 +520,8 @@ static void gst_blobnetfilter_init(GstBlobNetFilter *s) {
     g_mutex_init(&s->push_lock);
     g_cond_init(&s->cond);
     g_cond_init(&s->flush_cond);
+    g_cond_init(&s->slot_cond);
+    g_cond_init(&s->push_cond);
     g_queue_init(&s->flights);
     s->pads = g_ptr_array_new();
     s->batch_size = 128;       /* experiment/cova/config.yaml:30-35 */

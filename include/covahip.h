@@ -167,17 +167,21 @@ int covahip_filter_forward_frames(covahip_ctx *ctx, const uint8_t *frames, int n
  *   submit:  enqueues copy-in, kernels, on-device compaction of the boxes and copy-out; returns at once;
  *   collect: waits for that slot; counts i32 [batch] (components that pass the filter), offsets i32 [batch + 1] and
  *            boxes [offsets[batch]] = the first min(count, max_boxes) boxes of every frame, packed; mask u8
- *            [batch][h_mb][w_mb] when the pipe was created with want_mask (else NULL).  The pointers stay valid
- *            until the slot is acquired again.
- * One thread at a time per pipe and its ctx.                                                          */
+ *            [batch][h_mb][w_mb] when the pipe was created with want_mask (else NULL);
+ *   release: the caller is done with the results, the slot can be acquired again.
+ * acquire / submit / collect / release: one thread at a time per pipe and its ctx (the caller's lock).
+ * covahip_pipe_wait only blocks until a submitted slot's results have landed in host memory; it may run on
+ * another thread, concurrently with acquire / submit of other slots (collect returns at once after it).   */
 typedef struct covahip_pipe covahip_pipe;
 int covahip_pipe_create(covahip_ctx *ctx, int max_batch, int max_frames, int max_boxes, int n_slots, int want_mask,
                         covahip_pipe **out);
 void covahip_pipe_destroy(covahip_pipe *pipe);
 int covahip_pipe_acquire(covahip_pipe *pipe, int *slot, uint8_t **frames, int32_t **stack_index);
 int covahip_pipe_submit(covahip_pipe *pipe, int slot, int n_frames, int batch, int area_thresh);
+int covahip_pipe_wait(covahip_pipe *pipe, int slot);
 int covahip_pipe_collect(covahip_pipe *pipe, int slot, const int32_t **counts, const int32_t **offsets,
                          const covahip_box **boxes, const uint8_t **mask);
+int covahip_pipe_release(covahip_pipe *pipe, int slot);
 
 /* --------------------------------------------------------- Bbox wire format
  * bincode 1.3 (default config) bytes of Vec<Bbox> / Frame as the reference's elements

@@ -83,4 +83,5 @@ def test_pipe_argument_checks(ctx, weights_flat):
     pi[0] = (3, 2, 1, 9)
     assert lib.covahip_pipe_submit(pipe._h, slot, 6, 1, 1) == 1                        # index outside the frames
     assert lib.covahip_pipe_collect(pipe._h, slot, None, None, None, None) == 1        # nothing submitted
+    assert lib.covahip_pipe_release(pipe._h, slot) == 1                                # nothing collected
     pipe.close()

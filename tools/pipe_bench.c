@@ -41,13 +41,14 @@ int main(int argc, char **argv) {
             const int32_t *off;
             if (covahip_pipe_collect(pipe, inflight[0], NULL, &off, NULL, NULL)) return 5;
             boxes += off[B];
+            covahip_pipe_release(pipe, inflight[0]);
             memmove(inflight, inflight + 1, sizeof(int) * --nin);
         }
         if (fill || k < -3) { memcpy(pf, src, NF * fb); memcpy(pi, idx, sizeof(int32_t) * B * 4); }
         if (covahip_pipe_submit(pipe, slot, NF, B, 1)) return 6;
         inflight[nin++] = slot;
     }
-    for (int i = 0; i < nin; i++) covahip_pipe_collect(pipe, inflight[i], NULL, NULL, NULL, NULL);
+    for (int i = 0; i < nin; i++) { covahip_pipe_collect(pipe, inflight[i], NULL, NULL, NULL, NULL); covahip_pipe_release(pipe, inflight[i]); }
     const double dt = now() - t0;
     printf("{\"frames_per_s\": %.1f, \"fill\": %d, \"us_per_batch\": %.1f}\n", steps * (double)B / dt, fill, dt / steps * 1e6);
     covahip_pipe_destroy(pipe);
