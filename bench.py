@@ -8,15 +8,22 @@ the same batch size on its own GPU (frames/streams are independent: no collectiv
 data path), the timed region is bracketed by barrier + synchronize on both sides, the
 MAX over ranks is taken and rank 0 prints ONE JSON line.
 
-    python bench.py                       # N=1, defaults finish in about a minute
+    python bench.py                       # N=1, defaults finish in a few minutes
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+Beside `value` (the stacked entry point, as in round 1) the line carries, as extra keys measured outside the
+timed region on rank 0: the carrier-frame entry point (stacking as a GPU gather, level 0 once per carrier frame),
+the PCIe-inclusive rates (pageable host call, pinned pipelined covahip_pipe, through the GStreamer batching
+element), BASELINE configs[1] (BlobNet only, b=32) and the reference's default geometry (45x80, b=512), a leg with
+mixed-sign BN gammas (the ALLPOS=false kernel variants), and the CPU baselines of SURVEY.md section 8(d).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,11 +40,16 @@ HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16 MFMA peak
 
 
-def kernel_macs_per_frame():
-    """Algorithmic MACs per frame of each BlobNet kernel at 68x120 (SURVEY.md section 8d)."""
-    hs = [H_MB]; ws = [W_MB]
+def level_dims(h=H_MB, w=W_MB):
+    hs, ws = [h], [w]
     for _ in range(4):
         hs.append((hs[-1] + 1) // 2); ws.append((ws[-1] + 1) // 2)
+    return hs, ws
+
+
+def kernel_macs_per_frame():
+    """Algorithmic MACs per frame of each BlobNet kernel at 68x120 (SURVEY.md section 8d)."""
+    hs, ws = level_dims()
     enc_c = [3, 16, 32, 64, 128]
     out = {}
     for i in range(4):
@@ -54,9 +66,7 @@ def kernel_macs_per_frame():
 def kernel_bytes_per_frame():
     """Compulsory HBM bytes per frame of each BlobNet kernel at 68x120 when every level is its own kernel:
     input tensor(s) read once + output tensor written once (fp16 activations, u8 input / mask; weights excluded)."""
-    hs = [H_MB]; ws = [W_MB]
-    for _ in range(4):
-        hs.append((hs[-1] + 1) // 2); ws.append((ws[-1] + 1) // 2)
+    hs, ws = level_dims()
     enc_c = [3, 16, 32, 64, 128]
     out = {"enc0_mfma": T * hs[0] * ws[0] * 4 + T * hs[1] * ws[1] * enc_c[1] * 2}
     for i in range(1, 4):
@@ -89,12 +99,14 @@ def committed_traffic(kernel):
     return None, None
 
 
-def cpu_baseline(flat, stack_sample, target_seconds=10.0):
+# ------------------------------------------------------------------------------------------------ CPU baselines
+def cpu_baseline(flat, stack_sample, target_seconds=8.0):
     """CPU baseline on this host, on a bounded sample of the same workload.  Two ports of the reference
     path are timed and the FASTER one is reported as `value` (the reference itself -- Rust + OpenCV +
     TensorRT -- cannot be built in this image, and onnxruntime is not installed):
       * the C oracle (oracle/blobnet_ref.c, OpenMP over frames, fp32) + oracle regionprops (1 thread);
-      * the same graph in PyTorch-CPU (oneDNN convs, all cores) + oracle regionprops."""
+      * the same graph in PyTorch-CPU (oneDNN convs, all cores) + oracle regionprops.
+    Both are straightforward, untuned ports: a reported baseline, not a target."""
     from oracle import ref
     cores = os.cpu_count() or 1
     n0 = min(len(stack_sample), max(2, cores))
@@ -114,7 +126,7 @@ def cpu_baseline(flat, stack_sample, target_seconds=10.0):
         ref.regionprops_batch(mask, CC_THRESHOLD, MAX_BOXES)
     t_cc = (time.perf_counter() - t0) / reps           # single thread, as the reference element runs
     oracle_fps = n / (t_net + t_cc)
-    out = {"unit": "frames/s", "cores": cores, "kind": "port",
+    out = {"unit": "frames/s", "cores": cores, "kind": "port", "tuning": "untuned ports of the reference path",
            "oracle_c_blobnet_frames_per_s": round(n / t_net, 2), "oracle_bboxcc_frames_per_s": round(n / t_cc, 1),
            "oracle_c_combined_frames_per_s": round(oracle_fps, 2)}
     best, which = oracle_fps, "C oracle (OpenMP)"
@@ -146,6 +158,166 @@ def cpu_baseline(flat, stack_sample, target_seconds=10.0):
     return out
 
 
+def _blob_masks(n, seed):
+    """Sparse-blob masks with temporally coherent objects (what a trained BlobNet emits): a few ellipses that move."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H_MB, 0:W_MB]
+    objs = [(rng.uniform(0, H_MB), rng.uniform(0, W_MB), rng.uniform(1.5, 7), rng.uniform(1.5, 7),
+             rng.uniform(-0.4, 0.4), rng.uniform(-0.6, 0.6), int(rng.integers(0, n // 2)), int(rng.integers(n // 2, n)))
+            for _ in range(6)]
+    m = np.zeros((n, H_MB, W_MB), np.uint8)
+    for i in range(n):
+        for cy, cx, ry, rx, vy, vx, a, b in objs:
+            if a <= i <= b:
+                m[i] |= ((((yy - cy - vy * (i - a)) / ry) ** 2 + ((xx - cx - vx * (i - a)) / rx) ** 2) <= 1).astype(np.uint8)
+    return m
+
+
+def _track_stream(args):
+    """bboxcc (C oracle regionprops, what the Rust element computes through OpenCV) + SORT (the C++ port behind the
+    C-ABI, sort/src/lib.rs:134-187) over one stream on ONE thread, as the reference's per-branch elements run."""
+    seed, n = args
+    from cova_amd import elements as E
+    from cova_amd import _lib as L
+    from oracle import ref
+    masks = _blob_masks(n, seed)
+    sort = E._SortHandle(60, 30, 0.1)          # experiment/cova/launch.py:43-44, config.yaml:67
+    t0 = time.perf_counter()
+    t_sort = 0.0
+    for i in range(n):
+        boxes, cnt = ref.regionprops(masks[i], CC_THRESHOLD, 256)
+        bx = np.zeros(cnt, dtype=L.BOX_DTYPE)
+        for f, g in (("left", "left"), ("top", "top"), ("width", "width"), ("height", "height"), ("area_px", "area")):
+            bx[f] = boxes[:cnt][g]
+        dets = E.boxes_to_bbox(bx)
+        t1 = time.perf_counter()
+        sort.update(dets, i * (1_000_000_000 // 30))
+        t_sort += time.perf_counter() - t1
+    return time.perf_counter() - t0, t_sort
+
+
+def cpu_tracking_baseline(frames_per_stream=600):
+    """SURVEY.md section 8(d) CPU leg (1): bboxcc + sorttracker on the host, one thread per stream -- at one thread and
+    at N = min(cores, 32) independent streams in N processes."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    out = {}
+    try:
+        # worker processes, forked before this process has loaded the HIP library or touched the GPU
+        n = max(1, min(cores, 32))
+        with mp.get_context("fork").Pool(n) as pool:
+            t_all, t_sort = pool.map(_track_stream, [(11, frames_per_stream)])[0]
+            out["bboxcc_sort_1thread_frames_per_s"] = round(frames_per_stream / t_all, 1)
+            out["sort_update_frames_per_s"] = round(frames_per_stream / max(t_sort, 1e-9), 1)
+            t0 = time.perf_counter()
+            pool.map(_track_stream, [(100 + s, frames_per_stream) for s in range(n)])
+            out["bboxcc_sort_nstreams_frames_per_s"] = round(n * frames_per_stream / (time.perf_counter() - t0), 1)
+        out["bboxcc_sort_nstreams"] = n
+        out["tracking_sample"] = (f"{frames_per_stream} sparse-blob 68x120 masks per stream; regionprops = C oracle, SORT = the C++ port "
+                                  "behind the C-ABI (maxage 60, minhits 30, iou 0.1), Python glue included")
+    except Exception as e:
+        out["tracking_error"] = repr(e)[:200]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ extra legs (rank 0)
+def timed_steps(ctx, fn, steps, warmup=5):
+    for _ in range(warmup):
+        fn()
+    ctx.sync()
+    ctx.timer_start(2)
+    for _ in range(steps):
+        fn()
+    ctx.timer_stop(2)
+    return ctx.timer_ms(2) / steps
+
+
+def extra_legs(ctx, flat, steps):
+    """Other configurations, each on a model of its own on this rank's GPU.  Run BEFORE the main model is loaded (a ctx
+    holds one model)."""
+    from cova_amd import synth, weights as W
+    from cova_amd.elements import BlobNetInfer
+    out = {}
+    # BASELINE configs[1]: BlobNet forward only, b = 32, 120x68x4, fp16
+    net = BlobNetInfer(ctx, flat, H_MB, W_MB, max_batch=32)
+    st = synth.stacked_batch(32, H_MB, W_MB, seed=5, streams=4)
+    d_st, d_mask = ctx.malloc(st.nbytes), ctx.malloc(32 * H_MB * W_MB)
+    ctx.h2d(d_st, st)
+    ms = timed_steps(ctx, lambda: net.infer_device(d_st, 32, None, d_mask), steps)
+    out["config_blobnet_only_b32_68x120"] = {"frames_per_s": round(32 / ms * 1e3, 1), "ms_per_step": round(ms, 4)}
+    ctx.free(d_st); ctx.free(d_mask)
+    # the reference's own default: 720p grid 45x80, batch 512 (model/tasks.py:44-49)
+    net = BlobNetInfer(ctx, flat, 45, 80, max_batch=512)
+    st = synth.stacked_batch(512, 45, 80, seed=6, streams=8)
+    d_st, d_b, d_c = ctx.malloc(st.nbytes), ctx.malloc(512 * 920 * 20), ctx.malloc(512 * 4)
+    ctx.h2d(d_st, st)
+    ms = timed_steps(ctx, lambda: net.filter_device(d_st, 512, CC_THRESHOLD, d_b, d_c, 920), steps)
+    out["config_filter_b512_45x80"] = {"frames_per_s": round(512 / ms * 1e3, 1), "ms_per_step": round(ms, 4)}
+    for p in (d_st, d_b, d_c):
+        ctx.free(p)
+    # mixed-sign BN gammas: the ALLPOS=false kernel variants a trained model with a negative gamma takes
+    wts = W.unflatten(flat.copy())
+    for i in range(4):
+        wts[f"enc{i}.bn.gamma"][::2] *= -1.0
+    net = BlobNetInfer(ctx, W.flatten(wts), H_MB, W_MB, max_batch=BATCH)
+    st = synth.stacked_batch(BATCH, H_MB, W_MB, seed=7, streams=8)
+    d_st, d_b, d_c = ctx.malloc(st.nbytes), ctx.malloc(BATCH * MAX_BOXES * 20), ctx.malloc(BATCH * 4)
+    ctx.h2d(d_st, st)
+    ms = timed_steps(ctx, lambda: net.filter_device(d_st, BATCH, CC_THRESHOLD, d_b, d_c, MAX_BOXES), steps)
+    out["gamma_sign_mixed_b256_68x120"] = {"frames_per_s": round(BATCH / ms * 1e3, 1), "ms_per_step": round(ms, 4)}
+    for p in (d_st, d_b, d_c):
+        ctx.free(p)
+    return out
+
+
+def pipelined_host_rate(net, frames, index, steps):
+    """PCIe-inclusive, carrier frames in / packed boxes out through covahip_pipe (pinned slots, three HIP streams)."""
+    from cova_amd.elements import FilterPipe
+    B, nf = index.shape[0], frames.shape[0]
+    pipe = FilterPipe(net, max_batch=B, max_frames=nf, max_boxes=MAX_BOXES, n_slots=3)
+    res = {}
+    for fill in (False, True):
+        slots = []
+        for _ in range(3):                     # every slot holds the batch once; warms the plan and the speculative copy size
+            slot, pf, pi = pipe.acquire()
+            pf[:nf] = frames; pi[:B] = index
+            pipe.submit(slot, nf, B, CC_THRESHOLD)
+            slots.append(slot)
+        for slot in slots:
+            pipe.collect(slot)
+        t0 = time.perf_counter()
+        inflight = []
+        for _ in range(steps):
+            acq = pipe.acquire()
+            while acq is None:
+                pipe.collect(inflight.pop(0))
+                acq = pipe.acquire()
+            slot, pf, pi = acq
+            if fill:
+                pf[:nf] = frames; pi[:B] = index
+            pipe.submit(slot, nf, B, CC_THRESHOLD)
+            inflight.append(slot)
+        for slot in inflight:
+            pipe.collect(slot)
+        res["with_host_fill_one_thread" if fill else "slots_prefilled"] = round(steps * B / (time.perf_counter() - t0), 1)
+    pipe.acquire()   # releases the held result views
+    pipe.close()
+    return res
+
+
+def element_rate():
+    """frames/s through the GStreamer batching element (tools/element_bench.sh; a child process with its own ctx)."""
+    try:
+        r = subprocess.run(["bash", os.path.join(ROOT, "tools", "element_bench.sh"), "4000", "8", str(CC_THRESHOLD)],
+                           capture_output=True, text=True, timeout=180)
+        for line in r.stdout.splitlines():
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"error": (r.stderr or r.stdout)[-200:]}
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,7 +325,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="only the timed workload (profiling runs)")
     args = ap.parse_args()
+
+    # ---- host-only legs first, before this process loads the HIP library: the GStreamer element bench (a child
+    # process with a GPU context of its own) and the CPU tracking baseline (forked workers)
+    pre = {}
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        if not args.no_extra_legs:
+            pre["through_gstreamer_elements"] = element_rate()
+        if not args.no_cpu_baseline:
+            pre["cpu_tracking"] = cpu_tracking_baseline()
 
     from cova_amd.multigpu import Group
     grp = Group()            # torch.distributed (RCCL) only when WORLD_SIZE > 1: rendezvous/barrier/MAX
@@ -165,9 +347,13 @@ def main():
     ctx = Context(local_rank)
     B = args.batch
     flat = W.random_init(1234)
+    extras = {}
+    if rank == 0 and not args.no_extra_legs:
+        extras = extra_legs(ctx, flat, max(20, args.steps // 4))
     net = BlobNetInfer(ctx, flat, H_MB, W_MB, max_batch=B)
     # synthetic metapreprocess output: 8 independent streams interleaved, distinct per rank
-    stack = synth.stacked_batch(B, H_MB, W_MB, seed=0xC07A + 1000 * rank, streams=8)
+    seed = 0xC07A + 1000 * rank
+    stack = synth.stacked_batch(B, H_MB, W_MB, seed=seed, streams=8)
     d_stack = ctx.malloc(stack.nbytes)
     ctx.h2d(d_stack, stack)
     d_boxes = ctx.malloc(B * MAX_BOXES * 20)
@@ -191,7 +377,7 @@ def main():
     prof = ctx.profile_read()
     ctx.profile(False)
     per_kernel_us = {k: t / n * 1e3 for k, (t, n) in prof.items()}
-    blob_kernels = {k: v for k, v in per_kernel_us.items() if k not in ("bboxcc_kernel", "dec3_bboxcc_fused")}
+    blob_kernels = {k: v for k, v in per_kernel_us.items() if k not in ("bboxcc_kernel", "bboxcc_wave_kernel", "dec3_bboxcc_fused")}
     dominant = max(blob_kernels, key=blob_kernels.get)
 
     for _ in range(args.warmup):
@@ -210,53 +396,68 @@ def main():
     dom_ms, dom_n = ctx.profile_read()[dominant]
     ctx.profile(False)
 
-    # ---- bboxcc roofline (outside the timed region): inside the hot path bboxcc runs in the same launch as
-    # the last decoder block, so it is timed as the standalone kernel (covahip_bboxcc on device pointers) on
-    # the masks the last step left in HBM -- the same frames, the same LDS algorithm plus the mask load.
+    # ---- bboxcc roofline (outside the timed region).  Inside the hot path bboxcc runs in the same launch as the last
+    # decoder block; standalone it is timed (a) on the masks the last step left in HBM (b = 256: one frame per CU,
+    # latency bound) and (b) at B = 65,536 sparse-blob masks, where the byte rate of the wave-per-frame kernel shows.
     from cova_amd.elements import BboxCc
     cc = BboxCc(ctx, CC_THRESHOLD, MAX_BOXES)
     d_boxes2 = ctx.malloc(B * MAX_BOXES * 20)
     d_counts2 = ctx.malloc(B * 4)
-    for _ in range(3):
-        cc.regionprops_device(d_mask, B, H_MB, W_MB, d_boxes2, d_counts2)
-    ctx.profile(True, only="bboxcc_kernel")
-    for _ in range(args.steps):
-        cc.regionprops_device(d_mask, B, H_MB, W_MB, d_boxes2, d_counts2)
-    ctx.sync()
-    cc_ms, cc_n = ctx.profile_read()["bboxcc_kernel"]
-    ctx.profile(False)
+    cc_ms = timed_steps(ctx, lambda: cc.regionprops_device(d_mask, B, H_MB, W_MB, d_boxes2, d_counts2), args.steps, 3)
     counts2 = np.zeros(B, dtype=np.int32)
     ctx.d2h(counts2, d_counts2)
-
-    # sanity on the outputs of the last step
     counts = np.zeros(B, dtype=np.int32)
     ctx.d2h(counts, d_counts)
     assert (counts == counts2).all(), "fused decoder tail and standalone bboxcc disagree"
+    ctx.free(d_boxes2); ctx.free(d_counts2)
 
-    # ---- PCIe-inclusive rate (never `value`): host stack in, boxes/counts out, a few steps
-    pcie_fps = None
-    if rank == 0:
+    rank0 = {}
+    if rank == 0 and not args.no_extra_legs:
+        # bboxcc at large batch (SURVEY.md section 8d asks for the sweep; tools/bboxcc_sweep.py has all of it)
+        from tools.bboxcc_sweep import make_masks
+        BB = 65536
+        masks = np.tile(make_masks("blobs", 256), (BB // 256, 1, 1))
+        d_m, d_b, d_c = ctx.malloc(masks.nbytes), ctx.malloc(BB * 64 * 20), ctx.malloc(BB * 4)
+        ctx.h2d(d_m, masks)
+        cc64 = BboxCc(ctx, CC_THRESHOLD, 64)
+        ms = timed_steps(ctx, lambda: cc64.regionprops_device(d_m, BB, H_MB, W_MB, d_b, d_c), 5, 2)
+        rank0["bboxcc_B65536_sparse_blobs"] = {"ns_per_frame": round(ms * 1e6 / BB, 2), "GBps": round(BB * H_MB * W_MB / ms / 1e6, 1),
+                                               "frac_of_8TBs": round(BB * H_MB * W_MB / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        for p in (d_m, d_b, d_c):
+            ctx.free(p)
+        # carrier-frame entry point on the SAME 256 stacks (stacking = index gather on the GPU)
+        frames, index = synth.carrier_batch(B, H_MB, W_MB, seed=seed, streams=8)
+        assert np.array_equal(np.concatenate([frames[index[:, k]] for k in range(T)], axis=1), stack)
+        d_frames = ctx.malloc(frames.nbytes)
+        ctx.h2d(d_frames, frames)
+        ms = timed_steps(ctx, lambda: net.filter_frames_device(d_frames, frames.shape[0], index, B, CC_THRESHOLD, d_boxes, d_counts,
+                                                              MAX_BOXES, d_mask), args.steps)
+        ctx.d2h(counts2, d_counts)
+        assert (counts == counts2).all(), "carrier-frame entry and stacked entry disagree"
+        rank0["carrier_frame_entry"] = {"frames_per_s": round(B / ms * 1e3, 1), "ms_per_step": round(ms, 4),
+                                        "carrier_frames_per_step": int(frames.shape[0]), "input_bytes_per_step": int(frames.nbytes),
+                                        "stacked_input_bytes_per_step": int(stack.nbytes)}
+        ctx.free(d_frames)
+        # PCIe-inclusive rates (never `value`)
         net.filter(stack, CC_THRESHOLD, max_boxes=MAX_BOXES)        # warm the staging buffers
         t1 = time.perf_counter()
         for _ in range(5):
             net.filter(stack, CC_THRESHOLD, max_boxes=MAX_BOXES)
-        pcie_fps = 5 * B / (time.perf_counter() - t1)
+        rank0["frames_per_s_pcie_inclusive_host_buffers"] = round(5 * B / (time.perf_counter() - t1), 1)
+        rank0["frames_per_s_pcie_inclusive_pipelined_carrier_frames"] = pipelined_host_rate(net, frames, index, args.steps)
 
     elapsed = grp.max(elapsed)
 
     if rank == 0:
         macs = kernel_macs_per_frame()
         dom_s = dom_ms / dom_n * 1e-3
-        dom_flop = 2.0 * macs[dominant] * B
-        ach_tflops = dom_flop / dom_s / 1e12
-        cc_s = cc_ms / cc_n * 1e-3
+        cc_s = cc_ms * 1e-3
         cc_gbs = B * H_MB * W_MB / cc_s / 1e9
         total_flop = 2.0 * net.macs_per_frame * B
         step_s = elapsed / args.steps
-        launches_per_step = max(1, round(dom_n / args.steps))      # 2 when the half-batch overlap is on
-        dom_flop /= launches_per_step
+        dom_flop = 2.0 * macs[dominant] * B
         ach_tflops = dom_flop / dom_s / 1e12
-        dom_bytes = kernel_bytes_per_frame()[dominant] * B / launches_per_step
+        dom_bytes = kernel_bytes_per_frame()[dominant] * B
         dom_traffic, dom_traffic_src = committed_traffic(dominant) if B == BATCH else (None, None)
         cc_traffic, _ = committed_traffic("bboxcc_kernel") if B == BATCH else (None, None)
         line = {
@@ -293,17 +494,22 @@ def main():
                                 "traffic": cc_traffic, "algorithmic_bytes_per_launch": B * H_MB * W_MB,
                                 "avg_launch_us": round(cc_s * 1e6, 2),
                                 "note": "standalone kernel on the step's masks (in the hot path bboxcc runs inside the last "
-                                        "decoder block's launch); b=256 masks are 2.09 MB: latency bound, see DESIGN.md batch sweep"},
+                                        "decoder block's launch); b=256 masks are 2.09 MB: latency bound -- the byte rate is "
+                                        "bboxcc_B65536_sparse_blobs"},
             "blobnet_mfma_util_whole_net": round(total_flop / step_s / 1e12 / MFMA_PEAK_TFLOPS, 4),
             "blobnet_mfma_util_note": "algorithmic BlobNet FLOP over the WHOLE step time (bboxcc included: it shares a launch)",
             "per_kernel_us": {k: round(v, 2) for k, v in sorted(per_kernel_us.items())},
             "hip_event_ms_per_step_rank0": round(ev_ms / args.steps, 4),
-            "frames_per_s_pcie_inclusive_host_buffers": round(pcie_fps, 1),
             "boxes_per_frame_mean": float(counts.mean()),
             "device": ctx.info(),
         }
-        if not args.no_cpu_baseline:
+        line.update(rank0)
+        line.update(extras)
+        if "through_gstreamer_elements" in pre:
+            line["through_gstreamer_elements"] = pre["through_gstreamer_elements"]
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(flat, stack)
+            line["cpu_baseline"].update(pre.get("cpu_tracking", {}))
             line["gpu_over_cpu"] = round(line["value"] / world / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
 
