@@ -45,6 +45,13 @@ assert BBOX_DTYPE.itemsize == 56
 
 AU_OUT_DTYPE = np.dtype([("id", "<u8"), ("pts", "<u8"), ("flags", "<u4"), ("list", "<u4")])
 
+H264_INFO_DTYPE = np.dtype([(n, "<i4") for n in ("width_mbs", "height_mbs", "n_samples", "profile_idc", "level_idc", "entropy_cabac",
+                                                "transform_8x8", "num_ref_frames", "frame_mbs_only", "weighted_pred",
+                                                "weighted_bipred", "poc_type")])
+H264_SLICE_DTYPE = np.dtype([("nal_offset", "<u8"), ("nal_bytes", "<u4"), ("data_bit_offset", "<u4")] +
+                            [(n, "<i4") for n in ("nal_type", "slice_type", "first_mb", "frame_num", "idr", "poc_lsb", "qp",
+                                                  "cabac_init_idc", "num_ref_l0", "num_ref_l1", "direct_spatial")] + [("_pad", "<u4")])
+
 KERNEL_TIME_DTYPE = np.dtype([("name", "S48"), ("total_ms", "<f8"), ("launches", "<i8")])
 
 
@@ -112,6 +119,13 @@ PROTOTYPES = {
     "covahip_assoc_push_dnn_text": (C.c_int, [_P, C.c_char_p, _SZ]),
     "covahip_assoc_terminate": (C.c_int, [_P]),
     "covahip_assoc_csv": (_SZ, [_P, C.c_int, _P, _SZ, C.POINTER(C.c_int)]),
+    "covahip_h264_open_mp4": (C.c_int, [_P, _SZ, C.POINTER(_P)]),
+    "covahip_h264_close": (None, [_P]),
+    "covahip_h264_get_info": (C.c_int, [_P, _P]),
+    "covahip_h264_sample": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
+    "covahip_h264_sample_slices": (C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
+    "covahip_h264_decode_records": (C.c_int, [_P, C.c_int, _P, _SZ]),
+    "covahip_carrier_write_records": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _SZ]),
     "covahip_stack_new": (C.c_int, [_SZ, C.c_uint, C.c_uint, C.POINTER(_P)]),
     "covahip_stack_free": (None, [_P]),
     "covahip_stack_push": (C.c_int, [_P, _P, _SZ, _P, _SZ, C.POINTER(C.c_int)]),

@@ -1,0 +1,423 @@
+// Entropy-decode front end, container and header layer.
+//
+// The reference feeds its filter from a patched FFmpeg `avdec_h264` that stops after entropy decoding and writes one
+// 4-byte record [mb_type, mv_x, mv_y, -] per macroblock into the first bytes of its I420 output frame (README.md:94-114,
+// pipeline/cova/pipeline.py:84-99; consumers: metapreprocess/imp.rs:233,311-312, tfrecordsink/imp.rs:105-112).  That
+// decoder is an un-vendored submodule.  What is built here is the part of such a front end that can be verified in this
+// image against the reference's own demo/1m.mp4:
+//   * ISO-BMFF demux of the video track (avcC, stsz / stsc / stco / co64 / stss): access units with their key-frame flag,
+//   * NAL unit split (length prefixed), emulation-prevention removal,
+//   * SPS / PPS parse, slice header parse up to the first bit of slice_data() (ITU-T H.264 7.3.2.1, 7.3.2.2, 7.3.3),
+//   * the carrier layout writer (covahip_carrier_write_records).
+// NOT built: macroblock-layer parsing.  demo/1m.mp4 is High profile with CABAC (entropy_coding_mode_flag = 1, 8x8
+// transform, B slices, weighted prediction); a CABAC parser needs the 1,024 x 4 context-initialisation pairs of the
+// standard's tables 9-12 .. 9-33, and nothing in this image (no libavcodec, no x264, no network) holds them to check a
+// transcription against -- one wrong value silently desynchronises the arithmetic decoder.  covahip_h264_decode_records
+// therefore returns COVAHIP_ERR_UNSUPPORTED for CABAC streams, loudly, instead of emitting unverified records.
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "covahip.h"
+
+namespace {
+
+struct BitReader {
+    const uint8_t *p;
+    size_t n, pos = 0;   // bit position
+    bool bad = false;
+    BitReader(const uint8_t *d, size_t len) : p(d), n(len * 8) {}
+    uint32_t u(int bits) {
+        uint32_t v = 0;
+        for (int i = 0; i < bits; i++) {
+            if (pos >= n) { bad = true; return 0; }
+            v = (v << 1) | ((p[pos >> 3] >> (7 - (pos & 7))) & 1);
+            pos++;
+        }
+        return v;
+    }
+    uint32_t ue() {
+        int z = 0;
+        while (!bad && u(1) == 0 && z < 32) z++;
+        if (z >= 32) { bad = true; return 0; }
+        return z ? ((1u << z) - 1 + u(z)) : 0;
+    }
+    int32_t se() {
+        const uint32_t k = ue();
+        return (k & 1) ? (int32_t)((k + 1) / 2) : -(int32_t)(k / 2);
+    }
+};
+
+std::vector<uint8_t> unescape(const uint8_t *d, size_t n) {   // 7.4.1: drop emulation_prevention_three_byte
+    std::vector<uint8_t> o;
+    o.reserve(n);
+    for (size_t i = 0; i < n; i++) {
+        if (i + 2 < n && d[i] == 0 && d[i + 1] == 0 && d[i + 2] == 3) {
+            o.push_back(0); o.push_back(0);
+            i += 2;
+        } else {
+            o.push_back(d[i]);
+        }
+    }
+    return o;
+}
+
+struct Sps {
+    int profile = 0, level = 0, chroma_format = 1, log2_max_frame_num = 4, poc_type = 0, log2_max_poc_lsb = 4;
+    int delta_pic_order_always_zero = 0, num_ref_frames = 0, width_mbs = 0, height_map_units = 0, frame_mbs_only = 1, mbaff = 0;
+    int direct_8x8 = 0;
+    bool ok = false;
+};
+struct Pps {
+    int entropy_cabac = 0, bottom_field_pic_order = 0, num_slice_groups = 1, num_ref_l0 = 1, num_ref_l1 = 1, weighted_pred = 0,
+        weighted_bipred = 0, pic_init_qp = 26, deblocking_control = 0, redundant_pic_cnt = 0, transform_8x8 = 0;
+    bool ok = false;
+};
+
+bool parse_sps(const std::vector<uint8_t> &rbsp, Sps &s) {
+    BitReader r(rbsp.data() + 1, rbsp.size() - 1);
+    s.profile = (int)r.u(8); r.u(8); s.level = (int)r.u(8);
+    r.ue();   // seq_parameter_set_id
+    if (s.profile == 100 || s.profile == 110 || s.profile == 122 || s.profile == 244 || s.profile == 44 || s.profile == 83 ||
+        s.profile == 86 || s.profile == 118 || s.profile == 128) {
+        s.chroma_format = (int)r.ue();
+        if (s.chroma_format == 3) r.u(1);
+        r.ue(); r.ue(); r.u(1);
+        if (r.u(1)) return false;   // seq_scaling_matrix_present_flag: not handled
+    }
+    s.log2_max_frame_num = (int)r.ue() + 4;
+    s.poc_type = (int)r.ue();
+    if (s.poc_type == 0) s.log2_max_poc_lsb = (int)r.ue() + 4;
+    else if (s.poc_type == 1) {
+        s.delta_pic_order_always_zero = (int)r.u(1);
+        r.se(); r.se();
+        const uint32_t n = r.ue();
+        for (uint32_t i = 0; i < n && !r.bad; i++) r.se();
+    }
+    s.num_ref_frames = (int)r.ue();
+    r.u(1);
+    s.width_mbs = (int)r.ue() + 1;
+    s.height_map_units = (int)r.ue() + 1;
+    s.frame_mbs_only = (int)r.u(1);
+    if (!s.frame_mbs_only) s.mbaff = (int)r.u(1);
+    s.direct_8x8 = (int)r.u(1);
+    s.ok = !r.bad;
+    return s.ok;
+}
+
+bool parse_pps(const std::vector<uint8_t> &rbsp, Pps &p) {
+    BitReader r(rbsp.data() + 1, rbsp.size() - 1);
+    r.ue(); r.ue();
+    p.entropy_cabac = (int)r.u(1);
+    p.bottom_field_pic_order = (int)r.u(1);
+    p.num_slice_groups = (int)r.ue() + 1;
+    if (p.num_slice_groups > 1) return false;   // FMO: not handled
+    p.num_ref_l0 = (int)r.ue() + 1;
+    p.num_ref_l1 = (int)r.ue() + 1;
+    p.weighted_pred = (int)r.u(1);
+    p.weighted_bipred = (int)r.u(2);
+    p.pic_init_qp = (int)r.se() + 26;
+    r.se(); r.se();
+    p.deblocking_control = (int)r.u(1);
+    r.u(1);
+    p.redundant_pic_cnt = (int)r.u(1);
+    // more_rbsp_data(): something besides the trailing bits is left
+    size_t last = rbsp.size() - 1;
+    while (last > 0 && rbsp[last] == 0) last--;
+    int tz = 0;
+    while (tz < 8 && !((rbsp[last] >> tz) & 1)) tz++;
+    const size_t end_bits = (last - 1) * 8 + (7 - tz);   // bits of payload before rbsp_stop_one_bit, relative to byte 1
+    if (r.pos < end_bits) p.transform_8x8 = (int)r.u(1);
+    p.ok = !r.bad;
+    return p.ok;
+}
+
+struct Sample { uint64_t off; uint32_t size; bool sync; };
+
+uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+uint64_t be64(const uint8_t *p) { return ((uint64_t)be32(p) << 32) | be32(p + 4); }
+
+}  // namespace
+
+struct covahip_h264 {
+    const uint8_t *data = nullptr;
+    size_t len = 0;
+    int nal_len_size = 4;
+    Sps sps;
+    Pps pps;
+    std::vector<Sample> samples;
+};
+
+namespace {
+
+// Finds box `type` directly inside [off, end); returns payload range.
+bool find_box(const uint8_t *d, size_t off, size_t end, const char *type, size_t &pb, size_t &pe) {
+    while (off + 8 <= end) {
+        uint64_t sz = be32(d + off);
+        size_t hdr = 8;
+        if (sz == 1) { if (off + 16 > end) return false; sz = be64(d + off + 8); hdr = 16; }
+        if (sz == 0) sz = end - off;
+        if (sz < hdr || off + sz > end) return false;
+        if (std::memcmp(d + off + 4, type, 4) == 0) { pb = off + hdr; pe = off + sz; return true; }
+        off += sz;
+    }
+    return false;
+}
+
+int parse_slice_header(const covahip_h264 *h, const uint8_t *nal, size_t n, covahip_h264_slice *s) {
+    if (n < 2) return COVAHIP_ERR_BAD_DATA;
+    const int nal_ref_idc = (nal[0] >> 5) & 3, nal_type = nal[0] & 31;
+    // the header never needs more than a few dozen bytes; unescape a bounded prefix
+    const std::vector<uint8_t> rb = unescape(nal + 1, n - 1 < 96 ? n - 1 : 96);
+    BitReader r(rb.data(), rb.size());
+    const Sps &sp = h->sps;
+    const Pps &pp = h->pps;
+    s->nal_type = nal_type;
+    s->first_mb = (int)r.ue();
+    const int st = (int)r.ue();
+    s->slice_type = st % 5;   // 0 P, 1 B, 2 I, 3 SP, 4 SI
+    r.ue();                   // pic_parameter_set_id
+    s->frame_num = (int)r.u(sp.log2_max_frame_num);
+    if (!sp.frame_mbs_only) return COVAHIP_ERR_UNSUPPORTED;   // field / MBAFF coding
+    s->idr = nal_type == 5;
+    if (s->idr) r.ue();       // idr_pic_id
+    s->poc_lsb = 0;
+    if (sp.poc_type == 0) {
+        s->poc_lsb = (int)r.u(sp.log2_max_poc_lsb);
+        if (pp.bottom_field_pic_order) r.se();
+    } else if (sp.poc_type == 1 && !sp.delta_pic_order_always_zero) {
+        r.se();
+        if (pp.bottom_field_pic_order) r.se();
+    }
+    if (pp.redundant_pic_cnt) r.ue();
+    s->direct_spatial = 0;
+    if (s->slice_type == 1) s->direct_spatial = (int)r.u(1);
+    s->num_ref_l0 = pp.num_ref_l0;
+    s->num_ref_l1 = pp.num_ref_l1;
+    if (s->slice_type == 0 || s->slice_type == 1 || s->slice_type == 3) {
+        if (r.u(1)) {   // num_ref_idx_active_override_flag
+            s->num_ref_l0 = (int)r.ue() + 1;
+            if (s->slice_type == 1) s->num_ref_l1 = (int)r.ue() + 1;
+        }
+    }
+    // ref_pic_list_modification (7.3.3.1)
+    if (s->slice_type != 2 && s->slice_type != 4) {
+        for (int list = 0; list < (s->slice_type == 1 ? 2 : 1); list++)
+            if (r.u(1)) {
+                uint32_t op;
+                do {
+                    op = r.ue();
+                    if (op == 0 || op == 1 || op == 2) r.ue();
+                } while (op != 3 && !r.bad);
+            }
+    }
+    // pred_weight_table (7.3.3.2)
+    if ((pp.weighted_pred && (s->slice_type == 0 || s->slice_type == 3)) || (pp.weighted_bipred == 1 && s->slice_type == 1)) {
+        r.ue();
+        if (sp.chroma_format != 0) r.ue();
+        for (int list = 0; list < (s->slice_type == 1 ? 2 : 1); list++) {
+            const int cnt = list == 0 ? s->num_ref_l0 : s->num_ref_l1;
+            for (int i = 0; i < cnt && !r.bad; i++) {
+                if (r.u(1)) { r.se(); r.se(); }
+                if (sp.chroma_format != 0 && r.u(1)) { r.se(); r.se(); r.se(); r.se(); }
+            }
+        }
+    }
+    // dec_ref_pic_marking (7.3.3.3)
+    if (nal_ref_idc != 0) {
+        if (s->idr) { r.u(1); r.u(1); }
+        else if (r.u(1)) {
+            uint32_t op;
+            do {
+                op = r.ue();
+                if (op == 1 || op == 3) r.ue();
+                if (op == 2) r.ue();
+                if (op == 3 || op == 4) r.ue();
+            } while (op != 0 && !r.bad);
+        }
+    }
+    s->cabac_init_idc = -1;
+    if (pp.entropy_cabac && s->slice_type != 2 && s->slice_type != 4) s->cabac_init_idc = (int)r.ue();
+    s->qp = pp.pic_init_qp + r.se();
+    if (s->slice_type == 3 || s->slice_type == 4) {
+        if (s->slice_type == 3) r.u(1);
+        r.se();
+    }
+    if (pp.deblocking_control) {
+        const uint32_t idc = r.ue();
+        if (idc != 1) { r.se(); r.se(); }
+    }
+    if (r.bad) return COVAHIP_ERR_BAD_DATA;
+    size_t pos = r.pos;
+    if (pp.entropy_cabac) pos = (pos + 7) & ~(size_t)7;   // cabac_alignment_one_bit
+    s->data_bit_offset = (uint32_t)pos;                   // in the unescaped RBSP, after the NAL header byte
+    s->nal_bytes = (uint32_t)n;
+    return COVAHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int covahip_h264_open_mp4(const uint8_t *file, size_t len, covahip_h264 **out) {
+    if (!file || !out || len < 16) return COVAHIP_ERR_INVALID_ARG;
+    *out = nullptr;
+    size_t mb, me, tb, te, b, e;
+    if (!find_box(file, 0, len, "moov", mb, me)) return COVAHIP_ERR_BAD_DATA;
+    covahip_h264 *h = new (std::nothrow) covahip_h264();
+    if (!h) return COVAHIP_ERR_INVALID_ARG;
+    h->data = file;
+    h->len = len;
+    // the first track that carries an avcC
+    size_t toff = mb;
+    bool found = false;
+    while (!found && find_box(file, toff, me, "trak", tb, te)) {
+        toff = te;
+        size_t sb, se;
+        if (!(find_box(file, tb, te, "mdia", b, e) && find_box(file, b, e, "minf", b, e) && find_box(file, b, e, "stbl", sb, se))) continue;
+        size_t db, de;
+        if (!find_box(file, sb, se, "stsd", db, de)) continue;
+        // avcC sits inside the avc1 sample entry: search the stsd payload for its tag
+        size_t a = 0;
+        for (size_t i = db; i + 8 < de; i++)
+            if (std::memcmp(file + i, "avcC", 4) == 0) { a = i + 4; break; }
+        if (!a || a + 7 > de) continue;
+        h->nal_len_size = (file[a + 4] & 3) + 1;
+        size_t p = a + 5;
+        const int nsps = file[p++] & 31;
+        for (int k = 0; k < nsps && p + 2 <= de; k++) {
+            const size_t l = ((size_t)file[p] << 8) | file[p + 1];
+            if (p + 2 + l > de) break;
+            if (k == 0 && !parse_sps(unescape(file + p + 2, l), h->sps)) { delete h; return COVAHIP_ERR_UNSUPPORTED; }
+            p += 2 + l;
+        }
+        const int npps = p < de ? file[p++] : 0;
+        for (int k = 0; k < npps && p + 2 <= de; k++) {
+            const size_t l = ((size_t)file[p] << 8) | file[p + 1];
+            if (p + 2 + l > de) break;
+            if (k == 0 && !parse_pps(unescape(file + p + 2, l), h->pps)) { delete h; return COVAHIP_ERR_UNSUPPORTED; }
+            p += 2 + l;
+        }
+        if (!h->sps.ok || !h->pps.ok) { delete h; return COVAHIP_ERR_BAD_DATA; }
+        // sample sizes, chunk offsets, samples per chunk, sync samples
+        size_t zb, ze, cb, ce, scb, sce;
+        if (!find_box(file, sb, se, "stsz", zb, ze) || !find_box(file, sb, se, "stsc", scb, sce)) { delete h; return COVAHIP_ERR_BAD_DATA; }
+        const bool co64 = !find_box(file, sb, se, "stco", cb, ce);
+        if (co64 && !find_box(file, sb, se, "co64", cb, ce)) { delete h; return COVAHIP_ERR_BAD_DATA; }
+        const uint32_t fixed = be32(file + zb + 4), ns = be32(file + zb + 8);
+        const uint32_t nchunks = be32(file + cb + 4), nsc = be32(file + scb + 4);
+        if ((!fixed && zb + 12 + 4ull * ns > ze) || cb + 8 + (co64 ? 8ull : 4ull) * nchunks > ce || scb + 8 + 12ull * nsc > sce) { delete h; return COVAHIP_ERR_BAD_DATA; }
+        h->samples.resize(ns);
+        uint32_t si = 0;
+        for (uint32_t c = 0; c < nchunks && si < ns; c++) {
+            // samples per chunk: the last stsc entry whose first_chunk <= c + 1
+            uint32_t per = 0;
+            for (uint32_t k = 0; k < nsc; k++)
+                if (be32(file + scb + 8 + 12 * k) <= c + 1) per = be32(file + scb + 8 + 12 * k + 4);
+            uint64_t off = co64 ? be64(file + cb + 8 + 8ull * c) : be32(file + cb + 8 + 4ull * c);
+            for (uint32_t k = 0; k < per && si < ns; k++, si++) {
+                const uint32_t sz = fixed ? fixed : be32(file + zb + 12 + 4ull * si);
+                if (off + sz > len) { delete h; return COVAHIP_ERR_BAD_DATA; }
+                h->samples[si] = Sample{off, sz, false};
+                off += sz;
+            }
+        }
+        if (si != ns) { delete h; return COVAHIP_ERR_BAD_DATA; }
+        size_t yb, ye;
+        if (find_box(file, sb, se, "stss", yb, ye)) {
+            const uint32_t n = be32(file + yb + 4);
+            for (uint32_t k = 0; k < n && yb + 8 + 4ull * k + 4 <= ye; k++) {
+                const uint32_t s1 = be32(file + yb + 8 + 4ull * k);
+                if (s1 >= 1 && s1 <= ns) h->samples[s1 - 1].sync = true;
+            }
+        } else {
+            for (auto &s : h->samples) s.sync = true;
+        }
+        found = true;
+    }
+    if (!found) { delete h; return COVAHIP_ERR_BAD_DATA; }
+    *out = h;
+    return COVAHIP_OK;
+}
+
+void covahip_h264_close(covahip_h264 *h) { delete h; }
+
+int covahip_h264_get_info(const covahip_h264 *h, covahip_h264_info *info) {
+    if (!h || !info) return COVAHIP_ERR_INVALID_ARG;
+    info->width_mbs = h->sps.width_mbs;
+    info->height_mbs = h->sps.height_map_units * (2 - h->sps.frame_mbs_only);
+    info->n_samples = (int)h->samples.size();
+    info->profile_idc = h->sps.profile;
+    info->level_idc = h->sps.level;
+    info->entropy_cabac = h->pps.entropy_cabac;
+    info->transform_8x8 = h->pps.transform_8x8;
+    info->num_ref_frames = h->sps.num_ref_frames;
+    info->frame_mbs_only = h->sps.frame_mbs_only;
+    info->weighted_pred = h->pps.weighted_pred;
+    info->weighted_bipred = h->pps.weighted_bipred;
+    info->poc_type = h->sps.poc_type;
+    return COVAHIP_OK;
+}
+
+int covahip_h264_sample(const covahip_h264 *h, int sample, uint64_t *offset, uint32_t *size, int *is_sync) {
+    if (!h || sample < 0 || sample >= (int)h->samples.size()) return COVAHIP_ERR_INVALID_ARG;
+    if (offset) *offset = h->samples[sample].off;
+    if (size) *size = h->samples[sample].size;
+    if (is_sync) *is_sync = h->samples[sample].sync ? 1 : 0;
+    return COVAHIP_OK;
+}
+
+int covahip_h264_sample_slices(const covahip_h264 *h, int sample, covahip_h264_slice *out, int cap, int *n) {
+    if (!h || !n || sample < 0 || sample >= (int)h->samples.size() || (!out && cap)) return COVAHIP_ERR_INVALID_ARG;
+    const Sample &s = h->samples[sample];
+    size_t p = s.off;
+    const size_t end = s.off + s.size;
+    int cnt = 0;
+    while (p + h->nal_len_size <= end) {
+        size_t l = 0;
+        for (int k = 0; k < h->nal_len_size; k++) l = (l << 8) | h->data[p + k];
+        p += h->nal_len_size;
+        if (l == 0 || p + l > end) return COVAHIP_ERR_BAD_DATA;
+        const int t = h->data[p] & 31;
+        if (t == 1 || t == 5) {
+            if (cnt < cap) {
+                covahip_h264_slice sl;
+                std::memset(&sl, 0, sizeof sl);
+                int rc = parse_slice_header(h, h->data + p, l, &sl);
+                if (rc) return rc;
+                sl.nal_offset = (uint64_t)p;
+                out[cnt] = sl;
+            }
+            cnt++;
+        }
+        p += l;
+    }
+    if (p != end) return COVAHIP_ERR_BAD_DATA;
+    *n = cnt;
+    return cnt > cap ? COVAHIP_ERR_OVERFLOW : COVAHIP_OK;
+}
+
+int covahip_h264_decode_records(const covahip_h264 *h, int sample, uint8_t *records, size_t cap) {
+    if (!h || sample < 0 || sample >= (int)h->samples.size()) return COVAHIP_ERR_INVALID_ARG;
+    (void)records;
+    (void)cap;
+    // macroblock_layer(): CABAC is not built (see the header of this file); CAVLC streams are not accepted either, so that no
+    // caller mistakes a partial decoder for a complete one
+    return COVAHIP_ERR_UNSUPPORTED;
+}
+
+int covahip_carrier_write_records(const uint8_t *mb_type, const uint8_t *mv_x, const uint8_t *mv_y, int width_mbs, int height_mbs,
+                                  uint8_t *frame, size_t frame_bytes) {
+    if (!mb_type || !mv_x || !mv_y || !frame || width_mbs <= 0 || height_mbs <= 0) return COVAHIP_ERR_INVALID_ARG;
+    const size_t n = (size_t)width_mbs * height_mbs;
+    if (frame_bytes < n * 4) return COVAHIP_ERR_OVERFLOW;
+    for (size_t i = 0; i < n; i++) {   // byte 0 / 1 / 2 = mb_type / mv_x / mv_y (tfrecordsink/imp.rs:105-112), byte 3 unused
+        frame[4 * i] = mb_type[i];
+        frame[4 * i + 1] = mv_x[i];
+        frame[4 * i + 2] = mv_y[i];
+        frame[4 * i + 3] = 0;
+    }
+    return COVAHIP_OK;
+}
+
+}  // extern "C"

@@ -252,6 +252,40 @@ int covahip_assoc_terminate(covahip_assoc *a);   /* assoc.rs:434-467 */
 /* which: 0 track.csv, 1 dnn.csv, 2 assoc.csv, 3 stationary.csv; returns the size, copies if it fits. */
 size_t covahip_assoc_csv(covahip_assoc *a, int which, char *out, size_t cap, int *status);
 
+/* --------------------------------------------- entropy-decode front end (container + headers)
+ * What feeds `metapreprocess` in the reference is a patched FFmpeg avdec_h264 (an un-vendored submodule; README.md:94-114)
+ * that writes one record [mb_type, mv_x, mv_y, -] per macroblock into the first bytes of its output frame.  Built here:
+ * the ISO-BMFF / NAL / SPS / PPS / slice-header layer of such a front end (verified on the reference's demo/1m.mp4) and
+ * the record writer.  Macroblock-layer entropy decoding (CABAC) is NOT built: covahip_h264_decode_records returns
+ * COVAHIP_ERR_UNSUPPORTED (cova_amd/csrc/h264_front.cpp says why).  `file` must stay valid while the handle lives. */
+typedef struct covahip_h264 covahip_h264;
+typedef struct covahip_h264_info {
+    int32_t width_mbs, height_mbs, n_samples;
+    int32_t profile_idc, level_idc, entropy_cabac, transform_8x8, num_ref_frames, frame_mbs_only;
+    int32_t weighted_pred, weighted_bipred, poc_type;
+} covahip_h264_info;
+typedef struct covahip_h264_slice {
+    uint64_t nal_offset;       /* file offset of the NAL unit (its header byte) */
+    uint32_t nal_bytes;
+    uint32_t data_bit_offset;  /* first bit of slice_data() in the unescaped RBSP behind the NAL header byte */
+    int32_t nal_type;          /* 1 non-IDR, 5 IDR */
+    int32_t slice_type;        /* 0 P, 1 B, 2 I (slice_type % 5) */
+    int32_t first_mb, frame_num, idr, poc_lsb, qp, cabac_init_idc /* -1: none */, num_ref_l0, num_ref_l1, direct_spatial;
+} covahip_h264_slice;
+int covahip_h264_open_mp4(const uint8_t *file, size_t len, covahip_h264 **out);
+void covahip_h264_close(covahip_h264 *h);
+int covahip_h264_get_info(const covahip_h264 *h, covahip_h264_info *info);
+/* Access unit `sample` (decode order): where it sits in the file and whether the container marks it a sync sample. */
+int covahip_h264_sample(const covahip_h264 *h, int sample, uint64_t *offset, uint32_t *size, int *is_sync);
+/* Slice headers of the access unit (up to cap; *n = number of slice NAL units). */
+int covahip_h264_sample_slices(const covahip_h264 *h, int sample, covahip_h264_slice *out, int cap, int *n);
+/* Would fill records u8 [height_mbs][width_mbs][4]; returns COVAHIP_ERR_UNSUPPORTED (macroblock layer not built). */
+int covahip_h264_decode_records(const covahip_h264 *h, int sample, uint8_t *records, size_t cap);
+/* The carrier layout: interleaves per-macroblock mb_type / mv_x / mv_y into the first width_mbs * height_mbs * 4 bytes of
+ * `frame` (metapreprocess/imp.rs:233,311-312; tfrecordsink/imp.rs:105-112). */
+int covahip_carrier_write_records(const uint8_t *mb_type, const uint8_t *mv_x, const uint8_t *mv_y, int width_mbs, int height_mbs,
+                                  uint8_t *frame, size_t frame_bytes);
+
 /* ------------------------------------------------- metapreprocess stacking
  * Host state of the `metapreprocess` element (cova-rs/gst-plugins/src/metapreprocess/
  * imp.rs:204-332): keeps the last timestep-1 inputs, emits one stacked frame every
