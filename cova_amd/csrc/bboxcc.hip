@@ -40,23 +40,27 @@ using namespace ccbody;
 
 // ---- one 1,024-thread workgroup per frame (any shape that fits LDS; also the overflow pass of the wave kernel)
 // list == nullptr: frame = blockIdx.x.  Otherwise the launch is persistent over the *n_list frame indices in list.
-__global__ __launch_bounds__(CC_THREADS) void bboxcc_kernel(const uint8_t *__restrict__ masks, CcGeom g,
+// wg.cap > 0: the run-based body (bboxcc_wave.h, frame_wg) with worst-case capacity; else the block-based body.
+__global__ __launch_bounds__(CC_THREADS) void bboxcc_kernel(const uint8_t *__restrict__ masks, CcGeom g, ccwave::WvGeom wg,
                                                              int area_thresh, covahip_box *__restrict__ boxes,
                                                              int32_t *__restrict__ counts, int max_boxes,
                                                              const int32_t *__restrict__ list,
                                                              const int32_t *__restrict__ n_list) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    auto one = [&](int frame) {
+        const uint8_t *m = masks + (size_t)frame * g.H * g.W;
+        if (wg.cap > 0)
+            ccwave::frame_wg<CC_THREADS>(m, smem, wg, area_thresh, boxes + (size_t)frame * max_boxes, counts + frame, max_boxes, threadIdx.x);
+        else
+            bboxcc_frame(m, smem, g, area_thresh, boxes + (size_t)frame * max_boxes, counts + frame, max_boxes, threadIdx.x);
+    };
     if (!list) {
-        const int frame = blockIdx.x;
-        bboxcc_frame(masks + (size_t)frame * g.H * g.W, smem, g, area_thresh, boxes + (size_t)frame * max_boxes,
-                     counts + frame, max_boxes, threadIdx.x);
+        one(blockIdx.x);
         return;
     }
     const int n = *n_list;
     for (int k = blockIdx.x; k < n; k += gridDim.x) {
-        const int frame = list[k];
-        bboxcc_frame(masks + (size_t)frame * g.H * g.W, smem, g, area_thresh, boxes + (size_t)frame * max_boxes,
-                     counts + frame, max_boxes, threadIdx.x);
+        one(list[k]);
         __syncthreads();   // the next frame reuses the LDS region
     }
 }
@@ -110,11 +114,18 @@ int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, in
     int cap = ctx->cc_wave_cap;            // developer override: > 0 capacity, < 0 wave kernel off, 0 automatic
     // a few frames per CU: the workgroup kernel finishes a frame sooner than a single wave does (9.5 vs 13.5 us at
     // b = 256), and there is nothing to overlap it with
-    if (cap == 0) cap = (lds && batch <= 3 * num_cu) ? -1 : (lds ? 128 : nb);
+    if (cap == 0) cap = batch <= 3 * num_cu ? -1 : 128;
     cap = std::min(cap, nb);
     const bool aligned = (reinterpret_cast<uintptr_t>(d_mask) & 7) == 0 && (((size_t)h * w) & 7) == 0;
+    // the workgroup-per-frame kernel runs the run-based body too when the shape allows it (worst-case capacity)
+    ccwave::WvGeom wfull{};
+    size_t lds_wg = lds;
+    if (ctx->cc_wave_cap >= 0 && aligned && ccwave::wv_plan(h, w, nb, wfull) && (size_t)wfull.wave_bytes <= 160 * 1024 - 256)
+        lds_wg = (size_t)wfull.wave_bytes;
+    else
+        wfull.cap = 0;
     if (cap > 0 && aligned && ccwave::wv_plan(h, w, cap, wg) &&
-        (size_t)WV_WAVES * wg.wave_bytes <= 160 * 1024 - 64 && (cap >= nb || lds)) {
+        (size_t)WV_WAVES * wg.wave_bytes <= 160 * 1024 - 64 && (cap >= nb || lds_wg)) {
         const bool can_overflow = cap < nb;
         if (can_overflow) {
             int rc = covahip_ensure_buffer(ctx, &ctx->cc_ovf, &ctx->cc_ovf_bytes, ((size_t)batch + 1) * sizeof(int32_t));
@@ -132,20 +143,20 @@ int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, in
             COVAHIP_CHECK_HIP(ctx, hipGetLastError());
         }
         if (can_overflow) {
-            rc = open_lds(ctx, bboxcc_kernel, lds);
+            rc = open_lds(ctx, bboxcc_kernel, lds_wg);
             if (rc) return rc;
             ProfScope ps(ctx, "bboxcc_kernel");
-            hipLaunchKernelGGL(bboxcc_kernel, dim3(std::min(batch, 2 * num_cu)), dim3(CC_THREADS), lds, ctx->stream, d_mask, g,
+            hipLaunchKernelGGL(bboxcc_kernel, dim3(std::min(batch, 2 * num_cu)), dim3(CC_THREADS), lds_wg, ctx->stream, d_mask, g, wfull,
                                area_thresh, d_boxes, d_counts, max_boxes, (const int32_t *)ovf_list, (const int32_t *)ovf_n);
             COVAHIP_CHECK_HIP(ctx, hipGetLastError());
         }
         return COVAHIP_OK;
     }
-    if (!lds) return COVAHIP_ERR_UNSUPPORTED;
-    int rc = open_lds(ctx, bboxcc_kernel, lds);
+    if (!lds_wg) return COVAHIP_ERR_UNSUPPORTED;
+    int rc = open_lds(ctx, bboxcc_kernel, lds_wg);
     if (rc) return rc;
     ProfScope ps(ctx, "bboxcc_kernel");
-    hipLaunchKernelGGL(bboxcc_kernel, dim3(batch), dim3(CC_THREADS), lds, ctx->stream, d_mask, g, area_thresh,
+    hipLaunchKernelGGL(bboxcc_kernel, dim3(batch), dim3(CC_THREADS), lds_wg, ctx->stream, d_mask, g, wfull, area_thresh,
                        d_boxes, d_counts, max_boxes, (const int32_t *)nullptr, (const int32_t *)nullptr);
     COVAHIP_CHECK_HIP(ctx, hipGetLastError());
     return COVAHIP_OK;

@@ -61,6 +61,22 @@ __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 __device__ __forceinline__ int ctz64(uint64_t x) { return __ffsll((unsigned long long)x) - 1; }   // x != 0
+// position of the k-th (0-based) set bit of x; x has more than k set bits
+__device__ __forceinline__ int nth_set_bit64(uint64_t x, int k) {
+    uint32_t w = (uint32_t)x;
+    int pos = 0;
+    int c = __popc(w);
+    if (k >= c) { k -= c; w = (uint32_t)(x >> 32); pos = 32; }
+    c = __popc(w & 0xFFFFu);
+    if (k >= c) { k -= c; w >>= 16; pos += 16; }
+    c = __popc(w & 0xFFu);
+    if (k >= c) { k -= c; w >>= 8; pos += 8; }
+    c = __popc(w & 0xFu);
+    if (k >= c) { k -= c; w >>= 4; pos += 4; }
+    w &= 0xFu;
+    for (int i = 0; i < k; i++) w &= w - 1;   // at most three steps
+    return pos + (__ffs((int)w) - 1);
+}
 __device__ __forceinline__ uint64_t mask_upto(int e) { return e >= 63 ? ~0ull : ((2ull << e) - 1); }   // bits 0..e
 
 // One frame by the calling wave.  m: the frame's mask bytes (8-byte aligned; HBM or LDS); sm: this wave's LDS
@@ -203,6 +219,154 @@ __device__ __forceinline__ bool frame_wave(const uint8_t *m, uint8_t *sm, const 
     }
     if (lane == 0) *count_out = total;
     return true;
+}
+
+// ---- the same algorithm by ONE WORKGROUP of NTH threads per frame (the fused decoder tail: one frame per CU, the frame's
+// mask bytes already in LDS; latency matters, not LDS footprint).  Phases A, D, E spread over all threads; every wave derives
+// the row masks of phase B for itself (a few dozen instructions); in phase C wave w takes the runs w, w + NTH / 64, ... of
+// every block row.  Run capacity is the worst case (one run per block): nothing overflows.
+// m: H x W mask bytes (LDS or HBM, 8-byte aligned); sm: g.wave_bytes of LDS; called by all NTH threads.
+template <int NTH>
+__device__ __forceinline__ void frame_wg(const uint8_t *m, uint8_t *sm, const WvGeom &g, int area_thresh, covahip_box *ob,
+                                         int32_t *count_out, int max_boxes, int tid) {
+    constexpr int NWV = NTH / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t *rows = reinterpret_cast<uint32_t *>(sm);
+    uint32_t *lab = reinterpret_cast<uint32_t *>(sm + g.rows_bytes);
+    uint32_t *s_area = lab + g.cap, *s_minx = s_area + g.cap, *s_maxx = s_minx + g.cap, *s_miny = s_maxx + g.cap,
+             *s_maxy = s_miny + g.cap;
+    __shared__ uint32_t wave_tot[NWV];
+
+    // ---- A
+    for (int i = tid; i < g.rows_bytes / 4; i += NTH) rows[i] = 0;
+    __syncthreads();
+    const int npieces = g.H * g.NXB;
+    for (int q = tid; q < npieces; q += NTH) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(m + (size_t)q * 8);
+        if ((v.x | v.y) == 0) continue;
+        const int y = g.mNXB ? (int)__umulhi((uint32_t)q, g.mNXB) : q, xc = q - y * g.NXB;
+        const uint32_t tl = nz_bits(v.x), th = nz_bits(v.y);
+        const uint32_t e = (((tl & 0x00800080u) * 0x00800100u) >> 30) | ((((th & 0x00800080u) * 0x00800100u) >> 30) << 2);
+        const uint32_t o = (((tl & 0x80008000u) * 0x00008001u) >> 30) | ((((th & 0x80008000u) * 0x00008001u) >> 30) << 2);
+        uint32_t *rw = rows + (y + 1) * 4 + (xc >> 3);
+        const int sh = 4 * (xc & 7);
+        if (e) atomicOr(rw, e << sh);
+        if (o) atomicOr(rw + 2, o << sh);
+    }
+    __syncthreads();
+    // ---- B (every wave for itself)
+    uint64_t a = 0, b = 0, c = 0, d = 0, ue = 0, uo = 0;
+    if (lane < g.BH) {
+        const uint4 ru = reinterpret_cast<const uint4 *>(rows)[2 * lane];
+        const uint4 r0 = reinterpret_cast<const uint4 *>(rows)[2 * lane + 1];
+        const uint4 r1 = reinterpret_cast<const uint4 *>(rows)[2 * lane + 2];
+        ue = ru.x | ((uint64_t)ru.y << 32); uo = ru.z | ((uint64_t)ru.w << 32);
+        a = r0.x | ((uint64_t)r0.y << 32);  b = r0.z | ((uint64_t)r0.w << 32);
+        c = r1.x | ((uint64_t)r1.y << 32);  d = r1.z | ((uint64_t)r1.w << 32);
+    }
+    const uint64_t F = a | b | c | d;
+    const uint64_t J = (a | c) & ((b | d) << 1);
+    const uint64_t S = F & ~J;
+    const uint64_t cU = (a | b) & (ue | uo), cUL = a & (uo << 1), cUR = b & (ue >> 1);
+    const int nr = __popcll((unsigned long long)S);
+    int incl = nr;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    const int base = incl - nr;
+    const int n = __shfl(incl, 63, 64);
+    uint64_t S_up = (uint64_t)__shfl_up((unsigned long long)S, 1, 64), J_up = (uint64_t)__shfl_up((unsigned long long)J, 1, 64);
+    int base_up = __shfl_up(base, 1, 64);
+    if (lane == 0) { S_up = 0; J_up = 0; base_up = 0; }
+    for (int i = tid; i < n; i += NTH) lab[i] = (uint32_t)i;
+    __syncthreads();
+    // ---- C: wave w takes the runs w, w + NWV, ... of every block row (lane = block row): the runs of a row are spread
+    // evenly over the waves, a dense row costs ceil(runs / NWV) passes instead of one pass per run
+    for (int k = wave; __any(k < nr); k += NWV) {
+        uint64_t Tu = 0;
+        const int idx = base + k;
+        if (k < nr) {
+            const int s = nth_set_bit64(S, k);
+            const uint64_t jr = (J >> s) >> 1;
+            const int e = s + (~jr ? ctz64(~jr) : 0);
+            const uint64_t mk = mask_upto(e) & ~((1ull << s) - 1);
+            const uint64_t ra = a & mk, rb = b & mk, rc = c & mk, rd = d & mk;
+            s_area[idx] = (uint32_t)(__popcll((unsigned long long)ra) + __popcll((unsigned long long)rb) +
+                                     __popcll((unsigned long long)rc) + __popcll((unsigned long long)rd));
+            s_minx[idx] = (uint32_t)(2 * s + (((a | c) >> s) & 1 ? 0 : 1));
+            s_maxx[idx] = (uint32_t)(2 * e + (((b | d) >> e) & 1 ? 1 : 0));
+            s_miny[idx] = (uint32_t)(2 * lane + ((ra | rb) ? 0 : 1));
+            s_maxy[idx] = (uint32_t)(2 * lane + ((rc | rd) ? 1 : 0));
+            Tu = (cU & mk) | ((cUL & mk) >> 1) | ((cUR & mk) << 1);
+        }
+        while (__any(Tu != 0)) {
+            if (Tu) {
+                const int p = ctz64(Tu);
+                const int rank = __popcll((unsigned long long)(S_up << (63 - p))) - 1;
+                const uint64_t jr = (J_up >> p) >> 1;
+                const int e_up = p + (~jr ? ctz64(~jr) : 0);
+                Tu &= ~mask_upto(e_up);
+                ccbody::uf_union(lab, (uint32_t)idx, (uint32_t)(base_up + rank));
+            }
+        }
+    }
+    __syncthreads();
+    // ---- D
+    for (int i = tid; i < n; i += NTH) {
+        const uint32_t root = ccbody::uf_find(lab, (uint32_t)i);
+        if (root != (uint32_t)i) {
+            lab[i] = root;
+            atomicAdd(&s_area[root], s_area[i]);
+            atomicMin(&s_minx[root], s_minx[i]);
+            atomicMax(&s_maxx[root], s_maxx[i]);
+            atomicMin(&s_miny[root], s_miny[i]);
+            atomicMax(&s_maxy[root], s_maxy[i]);
+        }
+    }
+    __syncthreads();
+    // ---- E: ordered compaction, `per` consecutive runs per thread
+    const int per = (n + NTH - 1) / NTH;
+    const int i0 = tid * per;
+    uint32_t cnt = 0;
+    for (int k = 0; k < per; k++) {
+        const int i = i0 + k;
+        if (i < n && lab[i] == (uint32_t)i && (int)s_area[i] >= area_thresh) cnt++;
+    }
+    uint32_t inc2 = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc2, o, 64);
+        if (lane >= o) inc2 += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc2;
+    __syncthreads();
+    uint32_t pbase = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < NWV; k++) {
+        const uint32_t t = wave_tot[k];
+        if (k < wave) pbase += t;
+        total += t;
+    }
+    uint32_t pos = pbase + inc2 - cnt;
+    for (int k = 0; k < per; k++) {
+        const int i = i0 + k;
+        if (i < n && lab[i] == (uint32_t)i && (int)s_area[i] >= area_thresh) {
+            if ((int)pos < max_boxes) {
+                covahip_box bx;
+                bx.left = (int32_t)s_minx[i];
+                bx.top = (int32_t)s_miny[i];
+                bx.width = (int32_t)(s_maxx[i] - s_minx[i] + 1);
+                bx.height = (int32_t)(s_maxy[i] - s_miny[i] + 1);
+                bx.area_px = (int32_t)s_area[i];
+                ob[pos] = bx;
+            }
+            pos++;
+        }
+    }
+    if (tid == 0) *count_out = (int32_t)total;
+    __syncthreads();   // wave_tot and the frame's LDS region are free for the next frame
 }
 
 }  // namespace ccwave

@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "bboxcc_body.h"
+#include "bboxcc_wave.h"
 #include "blobnet.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -1468,6 +1469,8 @@ __global__ __launch_bounds__(((FINAL ? 1 : 4 * COUT / 32) > 4 ? 4 * COUT / 32 : 
 struct Dec3ccArgs {
     DecArgs d;                 // the last block's arguments (up, skip, logits, mask, weights, geometry, nbands)
     ccbody::CcGeom g;
+    ccwave::WvGeom wg;         // run-based bboxcc (bboxcc_wave.h) when the frame's shape allows it (use_wv)
+    int use_wv;
     covahip_box *boxes;        // [B][max_boxes]
     int32_t *counts;           // [B]
     int area_thresh, max_boxes;
@@ -1475,6 +1478,9 @@ struct Dec3ccArgs {
     int mfull_off, cc_off;     // LDS offsets of the frame's mask bytes and of bboxcc's region
 };
 
+// WV: the run-based bboxcc body (bboxcc_wave.h) instead of the block-based one (bboxcc_body.h); one body per instantiation, so
+// that the kernel's single register allocation of 128 VGPRs (16 waves per CU) holds the tile loop and ONE bboxcc.
+template <bool WV>
 __global__ __launch_bounds__(ccbody::CC_THREADS) void dec3cc_mfma(Dec3ccArgs q) {
     constexpr int C1 = 16, C2 = 16, C = 32, NW = ccbody::CC_THREADS / 64;
     constexpr int KC = C / 16, KSTEPS = 4 * KC, CPP = C / 8, PS = C * 2;
@@ -1484,13 +1490,14 @@ __global__ __launch_bounds__(ccbody::CC_THREADS) void dec3cc_mfma(Dec3ccArgs q) 
     const int TC = p.Wi + 2;
     const int GW = p.Wi + 1, GH = p.Hi + 1;
     const int kh = lane >> 5;
-    half8 wf[KSTEPS];
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ks++) wf[ks] = p.wfrag[ks * 64 + lane];
     const float fbias = p.epi[0];
     uint8_t *const mfull = smem + q.mfull_off;
 
     for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+        // the weight fragments are (re)loaded per frame: their registers are free again while bboxcc runs
+        half8 wf[KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ks++) wf[ks] = p.wfrag[ks * 64 + lane];
         auto stage = [&](int band, uint8_t *buf) {   // LDS-DMA of concat(up, skip[t=0]) rows u0-1 .. u1-1
             const int u0 = band * GH / p.nbands, u1 = (band + 1) * GH / p.nbands;
             const int RC = TC * CPP;
@@ -1568,8 +1575,12 @@ __global__ __launch_bounds__(ccbody::CC_THREADS) void dec3cc_mfma(Dec3ccArgs q) 
                 for (int i = tid; i < nbytes; i += NW * 64) dst[i] = mfull[i];
             }
         }
-        ccbody::bboxcc_frame(mfull, smem + q.cc_off, q.g, q.area_thresh, q.boxes + (size_t)b * q.max_boxes, q.counts + b,
-                             q.max_boxes, tid);
+        if constexpr (WV)
+            ccwave::frame_wg<ccbody::CC_THREADS>(mfull, smem + q.cc_off, q.wg, q.area_thresh, q.boxes + (size_t)b * q.max_boxes,
+                                                 q.counts + b, q.max_boxes, tid);
+        else
+            ccbody::bboxcc_frame(mfull, smem + q.cc_off, q.g, q.area_thresh, q.boxes + (size_t)b * q.max_boxes, q.counts + b,
+                                 q.max_boxes, tid);
     }
 }
 
@@ -2262,7 +2273,10 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const BnInput &in
                        // last block + bboxcc in one launch when the frame's LDS plan fits: two band buffers (which
                        // bboxcc's region reuses) + the frame's mask bytes
                        Dec3ccArgs t;
-                       const size_t cc_bytes = ccbody::cc_plan(out.H, out.W, t.g);
+                       size_t cc_bytes = ccbody::cc_plan(out.H, out.W, t.g);
+                       // the run-based body (bboxcc_wave.h) when the shape allows it: worst-case run capacity, nothing overflows
+                       t.use_wv = ctx->cc_wave_cap >= 0 && ccwave::wv_plan(out.H, out.W, ((out.H + 1) / 2) * ((out.W + 1) / 2), t.wg) ? 1 : 0;
+                       if (t.use_wv) cc_bytes = (size_t)t.wg.wave_bytes;
                        if (!cc_bytes) return false;
                        const size_t mfull = ((size_t)out.H * out.W + 15) & ~(size_t)15;
                        int best_nb = 0;
@@ -2289,9 +2303,10 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const BnInput &in
                        t.tile_bytes = (int)tb; t.cc_off = 0;
                        t.mfull_off = (int)std::max((best_nb == 1 ? 1 : 2) * tb, cc_bytes);
                        const size_t tl = (size_t)t.mfull_off + mfull;
-                       if (set_lds(ctx, dec3cc_mfma, tl)) return false;
+                       if (t.use_wv ? set_lds(ctx, dec3cc_mfma<true>, tl) : set_lds(ctx, dec3cc_mfma<false>, tl)) return false;
                        ProfScope ps(ctx, "dec3_bboxcc_fused");
-                       LAUNCH(dec3cc_mfma, dim3(std::min(batch, 2 * num_cu)), dim3(ccbody::CC_THREADS), tl, ctx->stream, t);
+                       if (t.use_wv) LAUNCH(dec3cc_mfma<true>, dim3(std::min(batch, 2 * num_cu)), dim3(ccbody::CC_THREADS), tl, ctx->stream, t);
+                       else LAUNCH(dec3cc_mfma<false>, dim3(std::min(batch, 2 * num_cu)), dim3(ccbody::CC_THREADS), tl, ctx->stream, t);
                        return true;
                    }()) {
             if (cc_done) *cc_done = true;
