@@ -242,7 +242,7 @@ __device__ __forceinline__ void frame_wg(const uint8_t *m, uint8_t *sm, const Wv
     __syncthreads();
     const int npieces = g.H * g.NXB;
     for (int q = tid; q < npieces; q += NTH) {
-        const uint2 v = *reinterpret_cast<const uint2 *>(m + (size_t)q * 8);
+        const uint2 v = *reinterpret_cast<const uint2 *>(__builtin_assume_aligned(m + (size_t)q * 8, 8));   // one 8-byte load, LDS or HBM
         if ((v.x | v.y) == 0) continue;
         const int y = g.mNXB ? (int)__umulhi((uint32_t)q, g.mNXB) : q, xc = q - y * g.NXB;
         const uint32_t tl = nz_bits(v.x), th = nz_bits(v.y);
