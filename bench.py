@@ -1,19 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- compressed-domain frames/sec (BlobNet + bboxcc) at 1080p, b=256, N GPUs.
 
-One "step" = one pass of the hot path (covahip_filter_forward: BlobNet forward ->
-threshold -> bboxcc) over one batch of 256 synthetic 68x120 macroblock-grid stacks that
-are already resident in HBM (BASELINE.json configs[2]).  With --gpus N every rank runs
-the same batch size on its own GPU (frames/streams are independent: no collective on the
-data path), the timed region is bracketed by barrier + synchronize on both sides, the
-MAX over ranks is taken and rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path (temporal stacking -> BlobNet forward -> threshold -> bboxcc) that
+produces the boxes of 256 frames of a synthetic 68x120 macroblock grid, inputs already resident in HBM
+(BASELINE.json configs[2]).  Default entry point: covahip_filter_forward_frames -- the carrier frames of 8 streams
+(8 x 35 frames of [mb_type, mv_x, mv_y] records) plus the table of which four frames make up each of the 256
+stacks; metapreprocess' stacking is an index gather on the GPU and the first encoder level runs once per carrier
+frame.  `--entry stack` times covahip_filter_forward on the 256 pre-stacked tensors instead (round 1's workload;
+the same 256 stacks, bit-identical results); whichever is not timed is reported as an extra key.  With --gpus N
+every rank runs the same batch size on its own GPU (frames/streams are independent: no collective on the data
+path), the timed region is bracketed by barrier + synchronize on both sides, the MAX over ranks is taken and
+rank 0 prints ONE JSON line.
 
     python bench.py                       # N=1, defaults finish in a few minutes
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Beside `value` (the stacked entry point, as in round 1) the line carries, as extra keys measured outside the
-timed region on rank 0: the carrier-frame entry point (stacking as a GPU gather, level 0 once per carrier frame),
+Beside `value` the line carries, as extra keys measured outside the timed region on rank 0: the other entry point,
 the PCIe-inclusive rates (pageable host call, pinned pipelined covahip_pipe, through the GStreamer batching
 element), BASELINE configs[1] (BlobNet only, b=32) and the reference's default geometry (45x80, b=512), a leg with
 mixed-sign BN gammas (the ALLPOS=false kernel variants), and the CPU baselines of SURVEY.md section 8(d).
@@ -79,17 +82,18 @@ def kernel_bytes_per_frame():
     return out
 
 
-PMC_KERNEL_KEYS = {"enc0_mfma": "enc0_mfma", "enc1_mfma": "enc_mfma<16, 32", "enc2_mfma": "enc_mfma<32, 64",
+PMC_KERNEL_KEYS = {"enc0_mfma": "enc0_mfma", "enc0p_mfma": "enc0p_mfma", "enc1t_mfma": "enc_mfma<16, 32", "enc1_mfma": "enc_mfma<16, 32", "enc2_mfma": "enc_mfma<32, 64",
                    "enc3_mfma": "enc_mfma<64, 128", "dec0_mfma": "dec_mfma<0, 128", "dec1_mfma": "dec_mfma<64, 64",
                    "dec2_mfma": "dec_mfma<32, 32", "dec3_final_mfma": "dec_mfma<16, 16", "dec3_bboxcc_fused": "dec3cc_mfma",
                    "bboxcc_kernel": "bboxcc_kernel"}
 
 
-def committed_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
-    (profiles/r*/traffic.json, FETCH_SIZE/WRITE_SIZE passes of tools/collect_profiles.sh, b=256)."""
+def committed_traffic(kernel, entry="stack"):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/r*/traffic.json for
+    the stacked entry, traffic_frames.json for the carrier-frame entry: FETCH_SIZE/WRITE_SIZE passes of
+    tools/collect_profiles.sh, b=256)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_frames.json" if entry == "frames" else "traffic.json")))
     if not files or kernel not in PMC_KERNEL_KEYS:
         return None, None
     data = json.load(open(files[-1]))
@@ -324,6 +328,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--entry", choices=["frames", "stack"], default="frames",
+                    help="entry point of the timed step: carrier frames + stack table (default) or pre-stacked tensors")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="only the timed workload (profiling runs)")
     args = ap.parse_args()
@@ -360,8 +366,20 @@ def main():
     d_counts = ctx.malloc(B * 4)
     d_mask = ctx.malloc(B * H_MB * W_MB)
 
-    def step():
+    # the same 256 stacks as carrier frames + table
+    frames, index = synth.carrier_batch(B, H_MB, W_MB, seed=seed, streams=8)
+    assert np.array_equal(np.concatenate([frames[index[:, k]] for k in range(T)], axis=1), stack)
+    d_frames = ctx.malloc(frames.nbytes)
+    ctx.h2d(d_frames, frames)
+
+    def step_stack():
         net.filter_device(d_stack, B, CC_THRESHOLD, d_boxes, d_counts, MAX_BOXES, d_mask)
+
+    def step_frames():
+        net.filter_frames_device(d_frames, frames.shape[0], index, B, CC_THRESHOLD, d_boxes, d_counts, MAX_BOXES, d_mask)
+
+    step = step_frames if args.entry == "frames" else step_stack
+    other = step_stack if args.entry == "frames" else step_frames
 
     def barrier():
         ctx.sync()           # the ctx's own HIP stream
@@ -425,19 +443,14 @@ def main():
                                                "frac_of_8TBs": round(BB * H_MB * W_MB / ms / 1e6 / HBM_PEAK_GBS, 4)}
         for p in (d_m, d_b, d_c):
             ctx.free(p)
-        # carrier-frame entry point on the SAME 256 stacks (stacking = index gather on the GPU)
-        frames, index = synth.carrier_batch(B, H_MB, W_MB, seed=seed, streams=8)
-        assert np.array_equal(np.concatenate([frames[index[:, k]] for k in range(T)], axis=1), stack)
-        d_frames = ctx.malloc(frames.nbytes)
-        ctx.h2d(d_frames, frames)
-        ms = timed_steps(ctx, lambda: net.filter_frames_device(d_frames, frames.shape[0], index, B, CC_THRESHOLD, d_boxes, d_counts,
-                                                              MAX_BOXES, d_mask), args.steps)
+        # the other entry point on the SAME 256 stacks
+        ms = timed_steps(ctx, other, args.steps)
         ctx.d2h(counts2, d_counts)
         assert (counts == counts2).all(), "carrier-frame entry and stacked entry disagree"
-        rank0["carrier_frame_entry"] = {"frames_per_s": round(B / ms * 1e3, 1), "ms_per_step": round(ms, 4),
-                                        "carrier_frames_per_step": int(frames.shape[0]), "input_bytes_per_step": int(frames.nbytes),
-                                        "stacked_input_bytes_per_step": int(stack.nbytes)}
-        ctx.free(d_frames)
+        rank0["stacked_entry" if args.entry == "frames" else "carrier_frame_entry"] = {
+            "frames_per_s": round(B / ms * 1e3, 1), "ms_per_step": round(ms, 4),
+            "carrier_frames_per_step": int(frames.shape[0]), "carrier_input_bytes_per_step": int(frames.nbytes),
+            "stacked_input_bytes_per_step": int(stack.nbytes)}
         # PCIe-inclusive rates (never `value`)
         net.filter(stack, CC_THRESHOLD, max_boxes=MAX_BOXES)        # warm the staging buffers
         t1 = time.perf_counter()
@@ -450,6 +463,14 @@ def main():
 
     if rank == 0:
         macs = kernel_macs_per_frame()
+        kbytes = kernel_bytes_per_frame()
+        hs, ws = level_dims()
+        # carrier path: level 0 up to the pool once per carrier frame; level 1 + level 0's temporal MLP + the gather per stack
+        nfr = frames.shape[0]
+        macs["enc0p_mfma"] = hs[0] * ws[0] * 9 * 3 * 16 * nfr / B
+        kbytes["enc0p_mfma"] = (hs[0] * ws[0] * 4 + hs[1] * ws[1] * 16 * 2) * nfr / B
+        macs["enc1t_mfma"] = macs["enc1_mfma"] + hs[1] * ws[1] * 16 * 32
+        kbytes["enc1t_mfma"] = kbytes["enc1_mfma"] + hs[1] * ws[1] * 16 * 2
         dom_s = dom_ms / dom_n * 1e-3
         cc_s = cc_ms * 1e-3
         cc_gbs = B * H_MB * W_MB / cc_s / 1e9
@@ -457,9 +478,9 @@ def main():
         step_s = elapsed / args.steps
         dom_flop = 2.0 * macs[dominant] * B
         ach_tflops = dom_flop / dom_s / 1e12
-        dom_bytes = kernel_bytes_per_frame()[dominant] * B
-        dom_traffic, dom_traffic_src = committed_traffic(dominant) if B == BATCH else (None, None)
-        cc_traffic, _ = committed_traffic("bboxcc_kernel") if B == BATCH else (None, None)
+        dom_bytes = kbytes[dominant] * B
+        dom_traffic, dom_traffic_src = committed_traffic(dominant, args.entry) if B == BATCH else (None, None)
+        cc_traffic, _ = committed_traffic("bboxcc_kernel", "stack") if B == BATCH else (None, None)
         line = {
             "metric": "compressed-domain frames/sec (BlobNet+bboxcc) at 1080p b=256",
             "value": round(world * B * args.steps / elapsed, 1),
@@ -473,8 +494,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f16",
             "data": "synthetic",
-            "config": {"workload": "BlobNet + bboxcc fused (covahip_filter_forward), 1080p macroblock grid 68x120, "
-                                   "T=4, inputs resident in HBM",
+            "config": {"workload": ("temporal stacking as a GPU gather + BlobNet + bboxcc fused (covahip_filter_forward_frames): carrier "
+                                    "frames of 8 streams + stack table, 256 output frames, 1080p macroblock grid 68x120, T=4, inputs "
+                                    "resident in HBM" if args.entry == "frames" else
+                                    "BlobNet + bboxcc fused (covahip_filter_forward) on 256 pre-stacked tensors, 1080p macroblock grid "
+                                    "68x120, T=4, inputs resident in HBM"),
+                       "entry": args.entry,
                        "batch_per_gpu": B, "grid_mb": [H_MB, W_MB], "timestep": T, "cc_threshold": CC_THRESHOLD,
                        "parallelism": f"{world} x independent per-GPU batches, no collective"},
             # SURVEY.md section 8(d) prices the BlobNet kernels against the MFMA roof; the same launch against

@@ -14,7 +14,7 @@ from collections import defaultdict
 
 tag = sys.argv[1]
 dst = sys.argv[2] if len(sys.argv) > 2 else f"profiles/{tag}"
-prefix = sys.argv[3] if len(sys.argv) > 3 else ""        # "frames_": the carrier-frame passes of collect_profiles.sh
+prefix = sys.argv[3] if len(sys.argv) > 3 else "stack_"   # "frames_" / "stack_": the entry point's passes of collect_profiles.sh
 src = f"gpurun_out/{tag}"
 
 
@@ -38,5 +38,5 @@ for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
     out[k] = {"FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
               "hbm_bytes_per_launch": int(2 * f * 1024 + w * 1024)}
-json.dump(out, open(f"{dst}/traffic{('_' + prefix.rstrip('_')) if prefix else ''}.json", "w"), indent=1)
+json.dump(out, open(f"{dst}/traffic{'_frames' if prefix == 'frames_' else ''}.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
