@@ -75,6 +75,7 @@ struct Pps {
 };
 
 bool parse_sps(const std::vector<uint8_t> &rbsp, Sps &s) {
+    if (rbsp.size() < 5) return false;
     BitReader r(rbsp.data() + 1, rbsp.size() - 1);
     s.profile = (int)r.u(8); r.u(8); s.level = (int)r.u(8);
     r.ue();   // seq_parameter_set_id
@@ -101,11 +102,13 @@ bool parse_sps(const std::vector<uint8_t> &rbsp, Sps &s) {
     s.frame_mbs_only = (int)r.u(1);
     if (!s.frame_mbs_only) s.mbaff = (int)r.u(1);
     s.direct_8x8 = (int)r.u(1);
-    s.ok = !r.bad;
+    s.ok = !r.bad && s.log2_max_frame_num <= 16 && s.log2_max_poc_lsb <= 16 && s.width_mbs <= 1024 && s.height_map_units <= 1024 &&
+           s.chroma_format <= 3 && s.num_ref_frames <= 16;
     return s.ok;
 }
 
 bool parse_pps(const std::vector<uint8_t> &rbsp, Pps &p) {
+    if (rbsp.size() < 3) return false;
     BitReader r(rbsp.data() + 1, rbsp.size() - 1);
     r.ue(); r.ue();
     p.entropy_cabac = (int)r.u(1);
@@ -123,12 +126,12 @@ bool parse_pps(const std::vector<uint8_t> &rbsp, Pps &p) {
     p.redundant_pic_cnt = (int)r.u(1);
     // more_rbsp_data(): something besides the trailing bits is left
     size_t last = rbsp.size() - 1;
-    while (last > 0 && rbsp[last] == 0) last--;
+    while (last > 1 && rbsp[last] == 0) last--;
     int tz = 0;
-    while (tz < 8 && !((rbsp[last] >> tz) & 1)) tz++;
+    while (tz < 7 && !((rbsp[last] >> tz) & 1)) tz++;
     const size_t end_bits = (last - 1) * 8 + (7 - tz);   // bits of payload before rbsp_stop_one_bit, relative to byte 1
     if (r.pos < end_bits) p.transform_8x8 = (int)r.u(1);
-    p.ok = !r.bad;
+    p.ok = !r.bad && p.num_ref_l0 <= 32 && p.num_ref_l1 <= 32;
     return p.ok;
 }
 
@@ -157,7 +160,7 @@ bool find_box(const uint8_t *d, size_t off, size_t end, const char *type, size_t
         size_t hdr = 8;
         if (sz == 1) { if (off + 16 > end) return false; sz = be64(d + off + 8); hdr = 16; }
         if (sz == 0) sz = end - off;
-        if (sz < hdr || off + sz > end) return false;
+        if (sz < hdr || sz > end - off) return false;
         if (std::memcmp(d + off + 4, type, 4) == 0) { pb = off + hdr; pe = off + sz; return true; }
         off += sz;
     }
@@ -199,6 +202,7 @@ int parse_slice_header(const covahip_h264 *h, const uint8_t *nal, size_t n, cova
             s->num_ref_l0 = (int)r.ue() + 1;
             if (s->slice_type == 1) s->num_ref_l1 = (int)r.ue() + 1;
         }
+        if (s->num_ref_l0 < 1 || s->num_ref_l0 > 32 || s->num_ref_l1 < 1 || s->num_ref_l1 > 32) return COVAHIP_ERR_BAD_DATA;
     }
     // ref_pic_list_modification (7.3.3.1)
     if (s->slice_type != 2 && s->slice_type != 4) {
@@ -281,7 +285,7 @@ int covahip_h264_open_mp4(const uint8_t *file, size_t len, covahip_h264 **out) {
         size_t a = 0;
         for (size_t i = db; i + 8 < de; i++)
             if (std::memcmp(file + i, "avcC", 4) == 0) { a = i + 4; break; }
-        if (!a || a + 7 > de) continue;
+        if (!a || a + 8 > de) continue;
         h->nal_len_size = (file[a + 4] & 3) + 1;
         size_t p = a + 5;
         const int nsps = file[p++] & 31;
@@ -304,8 +308,10 @@ int covahip_h264_open_mp4(const uint8_t *file, size_t len, covahip_h264 **out) {
         if (!find_box(file, sb, se, "stsz", zb, ze) || !find_box(file, sb, se, "stsc", scb, sce)) { delete h; return COVAHIP_ERR_BAD_DATA; }
         const bool co64 = !find_box(file, sb, se, "stco", cb, ce);
         if (co64 && !find_box(file, sb, se, "co64", cb, ce)) { delete h; return COVAHIP_ERR_BAD_DATA; }
+        if (zb + 12 > ze || cb + 8 > ce || scb + 8 > sce) { delete h; return COVAHIP_ERR_BAD_DATA; }
         const uint32_t fixed = be32(file + zb + 4), ns = be32(file + zb + 8);
         const uint32_t nchunks = be32(file + cb + 4), nsc = be32(file + scb + 4);
+        if (ns > (1u << 26) || nchunks > (1u << 26) || nsc > (1u << 20)) { delete h; return COVAHIP_ERR_BAD_DATA; }
         if ((!fixed && zb + 12 + 4ull * ns > ze) || cb + 8 + (co64 ? 8ull : 4ull) * nchunks > ce || scb + 8 + 12ull * nsc > sce) { delete h; return COVAHIP_ERR_BAD_DATA; }
         h->samples.resize(ns);
         uint32_t si = 0;
@@ -317,14 +323,14 @@ int covahip_h264_open_mp4(const uint8_t *file, size_t len, covahip_h264 **out) {
             uint64_t off = co64 ? be64(file + cb + 8 + 8ull * c) : be32(file + cb + 8 + 4ull * c);
             for (uint32_t k = 0; k < per && si < ns; k++, si++) {
                 const uint32_t sz = fixed ? fixed : be32(file + zb + 12 + 4ull * si);
-                if (off + sz > len) { delete h; return COVAHIP_ERR_BAD_DATA; }
+                if (off > len || sz > len - off) { delete h; return COVAHIP_ERR_BAD_DATA; }
                 h->samples[si] = Sample{off, sz, false};
                 off += sz;
             }
         }
         if (si != ns) { delete h; return COVAHIP_ERR_BAD_DATA; }
         size_t yb, ye;
-        if (find_box(file, sb, se, "stss", yb, ye)) {
+        if (find_box(file, sb, se, "stss", yb, ye) && yb + 8 <= ye) {
             const uint32_t n = be32(file + yb + 4);
             for (uint32_t k = 0; k < n && yb + 8 + 4ull * k + 4 <= ye; k++) {
                 const uint32_t s1 = be32(file + yb + 8 + 4ull * k);

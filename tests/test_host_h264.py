@@ -97,3 +97,28 @@ def test_carrier_record_layout():
     np.testing.assert_array_equal(rec[..., 2].reshape(-1), my)
     assert not rec[..., 3].any() and (frame[w * h * 4:] == 0xAA).all()
     assert lib.covahip_carrier_write_records(mt.ctypes.data, mx.ctypes.data, my.ctypes.data, w, h, frame.ctypes.data, 10) == 7
+
+
+def test_corrupted_headers_never_crash(demo):
+    """The parser reads untrusted bytes: random corruption of the moov box / parameter sets / slice headers must end in
+    an error status or in parsed values, never in a fault (the loop runs in this process: a fault would kill the run)."""
+    lib, _, data = demo
+    rng = np.random.default_rng(1)
+    moov = int(np.flatnonzero((data[:-4] == ord("m")) & (data[1:-3] == ord("o")) & (data[2:-2] == ord("o")) & (data[3:-1] == ord("v")))[-1])
+    sl = np.zeros(4, dtype=L.H264_SLICE_DTYPE)
+    n = C.c_int()
+    opened = 0
+    for trial in range(300):
+        d = data.copy()
+        for _ in range(int(rng.integers(1, 12))):
+            d[moov + int(rng.integers(0, data.size - moov))] = rng.integers(0, 256)      # inside moov (sample tables, avcC)
+        if trial % 3 == 0:
+            for _ in range(64):
+                d[int(rng.integers(48, 200000))] = rng.integers(0, 256)                  # inside the first access units
+        h = C.c_void_p()
+        if lib.covahip_h264_open_mp4(d.ctypes.data, d.size, C.byref(h)) == 0:
+            opened += 1
+            for s in (0, 1, 2, 250, 1801):
+                lib.covahip_h264_sample_slices(h, s, sl.ctypes.data, 4, C.byref(n))
+            lib.covahip_h264_close(h)
+    assert opened > 0
