@@ -312,7 +312,7 @@ def pipelined_host_rate(net, frames, index, steps):
 def element_rate():
     """frames/s through the GStreamer batching element (tools/element_bench.sh; a child process with its own ctx)."""
     try:
-        r = subprocess.run(["bash", os.path.join(ROOT, "tools", "element_bench.sh"), "4000", "8", str(CC_THRESHOLD)],
+        r = subprocess.run(["bash", os.path.join(ROOT, "tools", "element_bench.sh"), "20000", "8", str(CC_THRESHOLD)],
                            capture_output=True, text=True, timeout=180)
         for line in r.stdout.splitlines():
             if line.startswith("{"):

@@ -246,21 +246,37 @@ static int run_mux(const char *desc, int n_pads, const char *caps, const char *i
 }
 
 /* ---- muxbench: blobnetfilter fed by one thread per stream with in-memory carrier frames; prints frames/s ---- */
-typedef struct { GstPad *src; GstBuffer **bufs; int n_bufs, n_frames; } bench_feed_t;
+typedef struct { GstPad *src; GstBuffer **bufs; int n_bufs, n_frames, first, eos; } bench_feed_t;
 static gpointer bench_feeder(gpointer data) {
     bench_feed_t *f = data;
-    for (int i = 0; i < f->n_frames; i++) {
+    gint64 tp = 0;
+    for (int i = f->first; i < f->first + f->n_frames; i++) {
         GstBuffer *b = gst_buffer_copy(f->bufs[i % f->n_bufs]);   /* shares the memory, own metadata */
         GST_BUFFER_PTS(b) = (GstClockTime)i * (GST_SECOND / 30);
-        if (gst_pad_push(f->src, b) != GST_FLOW_OK) break;
+        const gint64 t0 = g_get_monotonic_time();
+        const GstFlowReturn fr = gst_pad_push(f->src, b);
+        tp += g_get_monotonic_time() - t0;
+        if (fr != GST_FLOW_OK) break;
     }
-    gst_pad_push_event(f->src, gst_event_new_eos());
+    if (getenv("FEED_TIMING")) fprintf(stderr, "feeder: %d frames, %lld us inside gst_pad_push\n", f->n_frames, (long long)tp);
+    if (f->eos) gst_pad_push_event(f->src, gst_event_new_eos());
     return NULL;
 }
+/* per src pad: count, order check and an order-sensitive checksum of (PTS, bytes); a pad is pushed to by one thread at a time */
+typedef struct { guint64 n, sum; GstClockTime last_pts; int in_order; int check; } bench_out_t;
 static GstFlowReturn bench_chain(GstPad *pad, GstObject *parent, GstBuffer *b) {
-    g_mutex_lock(&mux_lock);
-    mux_bufs++;
-    g_mutex_unlock(&mux_lock);
+    bench_out_t *o = gst_pad_get_element_private(pad);
+    if (o->n && GST_BUFFER_PTS(b) <= o->last_pts) o->in_order = 0;
+    o->last_pts = GST_BUFFER_PTS(b);
+    o->n++;
+    if (o->check) {
+        GstMapInfo m;
+        guint64 h = o->sum ^ GST_BUFFER_PTS(b);
+        gst_buffer_map(b, &m, GST_MAP_READ);
+        for (gsize i = 0; i < m.size; i++) h = (h ^ m.data[i]) * 1099511628211ull;
+        gst_buffer_unmap(b, &m);
+        o->sum = h * 1099511628211ull + 1;
+    }
     gst_buffer_unref(b);
     return GST_FLOW_OK;
 }
@@ -268,6 +284,8 @@ static int run_muxbench(const char *desc, int n_pads, int w_px, int h_px, int fr
     GError *err = NULL;
     GstElement *e = gst_parse_launch(desc, &err);
     bench_feed_t feeds[64];
+    static bench_out_t outs[64];
+    const int same = getenv("MUXBENCH_SAME") != NULL;   /* every stream carries the same frames: the per-pad checksums must agree */
     GThread *th[64];
     gchar *caps = g_strdup_printf("video/x-raw,format=I420,width=%d,height=%d,framerate=30/1", w_px, h_px);
     const gsize fb = (gsize)(w_px / 16) * (h_px / 16) * 4;
@@ -285,12 +303,16 @@ static int run_muxbench(const char *desc, int n_pads, int w_px, int h_px, int fr
         feeds[i].bufs = g_new(GstBuffer *, 16);
         for (int k = 0; k < 16; k++) {
             GstMapInfo m;
-            unsigned x = 777u * (unsigned)(i * 16 + k + 1);
+            unsigned x = 777u * (unsigned)((same ? 0 : i) * 16 + k + 1);
             feeds[i].bufs[k] = gst_buffer_new_allocate(NULL, fb, NULL);
             gst_buffer_map(feeds[i].bufs[k], &m, GST_MAP_WRITE);
             for (gsize q = 0; q < fb; q++) { x = x * 1664525u + 1013904223u; m.data[q] = (x >> 24) < 40 ? (x >> 16) % 7 : 0; }
             gst_buffer_unmap(feeds[i].bufs[k], &m);
         }
+        outs[i].in_order = 1;
+        outs[i].check = same;
+        outs[i].sum = 14695981039346656037ull;
+        gst_pad_set_element_private(tsink, &outs[i]);
         gst_pad_set_chain_function(tsink, bench_chain);
         gst_pad_set_event_function(tsink, mux_sink_event);
         gst_pad_set_active(tsink, TRUE);
@@ -298,22 +320,33 @@ static int run_muxbench(const char *desc, int n_pads, int w_px, int h_px, int fr
     }
     gst_element_set_state(e, GST_STATE_PLAYING);
     for (int i = 0; i < n_pads; i++) { gchar *sid = g_strdup_printf("s%d", i); start_pad(feeds[i].src, sid, caps); g_free(sid); }
-    {   /* model load and pipe creation happen with the first frame: push one warm-up frame per stream before the clock starts */
-        for (int i = 0; i < n_pads; i++) {
-            GstBuffer *b = gst_buffer_copy(feeds[i].bufs[0]);
-            GST_BUFFER_PTS(b) = 0;
-            gst_pad_push(feeds[i].src, b);
-        }
+    {   /* model load and pipe creation happen with the first frame, code-object load and the scratch allocations with the
+         * first batches: a few batches go through before the clock starts */
+        const int warm = getenv("MUXBENCH_WARM") ? atoi(getenv("MUXBENCH_WARM")) : 1024 / n_pads + 8;
+        for (int i = 0; i < n_pads; i++) { feeds[i].first = 0; feeds[i].n_frames = warm; feeds[i].eos = 0; }
+        for (int i = 0; i < n_pads; i++) th[i] = g_thread_new("feed", bench_feeder, &feeds[i]);
+        for (int i = 0; i < n_pads; i++) g_thread_join(th[i]);
+        g_usleep(200000);
+        { gchar *tm = NULL; g_object_get(e, "timing", &tm, NULL); fprintf(stderr, "timing after warm-up: %s\n", tm ? tm : "?"); g_free(tm); }
+        for (int i = 0; i < n_pads; i++) { feeds[i].first = warm; feeds[i].n_frames = frames_per_pad; feeds[i].eos = 1; }
     }
     const gint64 t0 = g_get_monotonic_time();
     for (int i = 0; i < n_pads; i++) th[i] = g_thread_new("feed", bench_feeder, &feeds[i]);
     for (int i = 0; i < n_pads; i++) g_thread_join(th[i]);
     const gint64 t1 = g_get_monotonic_time();
     g_object_get(e, "batches", &batches, NULL);
+    { gchar *tm = NULL; g_object_get(e, "timing", &tm, NULL); fprintf(stderr, "timing at the end:   %s\n", tm ? tm : "?"); g_free(tm); }
     g_mutex_lock(&mux_lock);
-    printf("{\"frames_per_s_through_elements\": %.1f, \"streams\": %d, \"frames_in\": %d, \"buffers_out\": %d, \"eos\": %d, \"batches\": %llu, \"seconds\": %.4f}\n",
-           (double)n_pads * frames_per_pad / ((t1 - t0) * 1e-6), n_pads, n_pads * frames_per_pad, mux_bufs, mux_eos,
-           (unsigned long long)batches, (t1 - t0) * 1e-6);
+    {
+        guint64 n_out = 0;
+        int in_order = 1, agree = 1;
+        for (int i = 0; i < n_pads; i++) { n_out += outs[i].n; in_order &= outs[i].in_order; agree &= outs[i].sum == outs[0].sum && outs[i].n == outs[0].n; }
+        printf("{\"frames_per_s_through_elements\": %.1f, \"streams\": %d, \"frames_in\": %d, \"buffers_out\": %llu, \"eos\": %d, \"batches\": %llu, \"seconds\": %.4f, \"in_order\": %s",
+               (double)n_pads * frames_per_pad / ((t1 - t0) * 1e-6), n_pads, n_pads * frames_per_pad, (unsigned long long)n_out, mux_eos,
+               (unsigned long long)batches, (t1 - t0) * 1e-6, in_order ? "true" : "false");
+        if (same) printf(", \"pads_agree\": %s, \"pad0_sum\": \"%016llx\"", agree ? "true" : "false", (unsigned long long)outs[0].sum);
+        printf("}\n");
+    }
     g_mutex_unlock(&mux_lock);
     gst_element_set_state(e, GST_STATE_NULL);
     g_free(caps);

@@ -40,23 +40,30 @@ typedef struct {
 } BfPad;
 
 typedef struct { guint pad; GstClockTime pts, duration; } BfMeta;
-typedef struct { int slot; int n_stacks; BfMeta *meta; } BfFlight;
+typedef struct {   /* one batch on its way: filled slot -> submitter -> collector -> the pusher threads */
+    int slot;
+    int n_frames, n_stacks;
+    guint cc_threshold;
+    BfMeta *meta;
+    const int32_t *counts, *offsets;   /* the slot's results (valid until the slot is released) */
+    const covahip_box *boxes;
+    volatile gint shares_left;         /* pusher threads that have not pushed their share yet: the last one releases the slot */
+} BfFlight;
 #define BF_PUSHERS 8
 typedef struct _GstBlobNetFilter GstBlobNetFilter;
-typedef struct {   /* one share of a finished batch: the stacks of the src pads with pad % BF_PUSHERS == group */
-    GstBlobNetFilter *s;
-    BfFlight *fl;
-    const int32_t *counts, *offsets;
-    const covahip_box *boxes;
-    guint group;
-} BfPushTask;
+typedef struct { GstBlobNetFilter *s; guint group; GAsyncQueue *q; GThread *th; } BfPusher;
 
 struct _GstBlobNetFilter {
     GstElement parent;
-    GMutex lock, push_lock;
+    GMutex lock;
     GCond cond, flush_cond;
-    gboolean flushing;        /* a flush has dropped the lock to push results: the slot pointers are in flux */
-    gint pending;             /* streaming threads still copying their frame into the slot being filled (lock not held) */
+    /* Reservation word of the slot being filled: frames taken (bits 0-20), stacks taken (21-41), a generation that
+     * changes with every slot (42-62) and the "flush under way" bit (63).  A streaming thread takes its positions with one
+     * compare-and-swap; a sleeping mutex there is a convoy (measured: 250 k frames/s with 4 to 64 threads alike) and a
+     * spin lock still costs 5 us per frame with 8 threads on it. */
+    guint64 state __attribute__((aligned(64)));
+    guint64 done __attribute__((aligned(64)));   /* frames whose bytes (and table rows) are in the slot; a flush waits for done == frames taken */
+    gboolean flushing __attribute__((aligned(64)));   /* lock held: same as the bit in `state`, for the threads that wait on flush_cond */
     gchar *weights;
     guint gpu_id, batch_size, cc_threshold, max_boxes;
     guint64 timeout_us;
@@ -69,23 +76,36 @@ struct _GstBlobNetFilter {
     int slot;
     uint8_t *pf;
     int32_t *pi;
-    int n_frames, n_stacks, max_frames;
+    int max_frames;
     BfMeta *meta;
     gint64 first_us;
+    GMutex pipe_lock;         /* covahip_pipe_* calls (acquire / submit / collect / release) are one at a time */
+    GQueue submit_q;          /* BfFlight*: filled batches waiting for the submitter thread */
+    GThread *submitter;
     GQueue flights;           /* BfFlight*, oldest first: submitted, not yet taken by the collector */
     guint in_flight;          /* submitted batches whose results have not all been pushed yet */
     GCond slot_cond;          /* a slot was released / a flight was queued / all flights are done */
-    GCond push_cond;          /* with push_lock: the last share of a batch has been pushed */
     GThread *timer, *collector;
-    GThreadPool *pushers;
-    gint push_left;           /* shares of the current batch still being pushed */
+    BfPusher pusher[BF_PUSHERS];   /* src pad i is served by pusher i % BF_PUSHERS, batches in order */
+    volatile gint pushers_us;
     GstFlowReturn push_ret;
     gboolean stop, failed;
     guint64 batches, frames_out;
+    gint64 slot_wait_us, gpu_wait_us, push_us;   /* where the time goes (read-only property "timing") */
+    volatile gint chain_slow_us, chain_flush_us, chain_slow_n;   /* summed over the streaming threads (slow paths only) */
 };
 typedef struct { GstElementClass parent_class; } GstBlobNetFilterClass;
 G_DEFINE_TYPE(GstBlobNetFilter, gst_blobnetfilter, GST_TYPE_ELEMENT)
-enum { BF_PROP_0, BF_PROP_WEIGHTS, BF_PROP_GPU, BF_PROP_BATCH, BF_PROP_TIMEOUT, BF_PROP_CC, BF_PROP_MAXBOXES, BF_PROP_BATCHES };
+enum { BF_PROP_0, BF_PROP_WEIGHTS, BF_PROP_GPU, BF_PROP_BATCH, BF_PROP_TIMEOUT, BF_PROP_CC, BF_PROP_MAXBOXES, BF_PROP_BATCHES, BF_PROP_TIMING };
+
+#define BF_ST_BITS 21
+#define BF_ST_MASK ((1ull << BF_ST_BITS) - 1)
+#define BF_ST_FRAMES(x) ((int)((x) & BF_ST_MASK))
+#define BF_ST_STACKS(x) ((int)(((x) >> BF_ST_BITS) & BF_ST_MASK))
+#define BF_ST_ONE_STACK (1ull << BF_ST_BITS)
+#define BF_ST_ONE_GEN (1ull << (2 * BF_ST_BITS))
+#define BF_ST_FLUSH (1ull << 63)
+static inline guint64 bf_state(GstBlobNetFilter *s) { return __atomic_load_n(&s->state, __ATOMIC_ACQUIRE); }
 
 static BfPad *bf_pad_of(GstBlobNetFilter *s, GstPad *sink) { return (BfPad *)gst_pad_get_element_private(sink); }
 
@@ -107,8 +127,7 @@ static gboolean bf_ensure_model(GstBlobNetFilter *s) {   /* lock held */
     }
     rc = covahip_blobnet_load(s->ctx, blob, len, s->h_mb, s->w_mb, BF_TIMESTEP, (int)s->batch_size);
     g_free(blob);
-    s->max_frames = BF_TIMESTEP * (int)s->batch_size;
-    if (rc == COVAHIP_OK) rc = covahip_pipe_create(s->ctx, (int)s->batch_size, s->max_frames, (int)s->max_boxes, BF_SLOTS, 0, &s->pipe);
+    if (rc == COVAHIP_OK) rc = covahip_pipe_create(s->ctx, (int)s->batch_size, BF_TIMESTEP * (int)s->batch_size, (int)s->max_boxes, BF_SLOTS, 0, &s->pipe);
     if (rc == COVAHIP_OK) rc = covahip_pipe_acquire(s->pipe, &s->slot, &s->pf, &s->pi);
     if (rc != COVAHIP_OK) {
         GST_ELEMENT_ERROR(s, LIBRARY, INIT, ("covahip: %s (%s)", covahip_strerror(rc), covahip_last_hip_error(s->ctx)), (NULL));
@@ -116,26 +135,27 @@ static gboolean bf_ensure_model(GstBlobNetFilter *s) {   /* lock held */
     }
     s->meta = g_new0(BfMeta, s->batch_size);
     s->failed = FALSE;
+    __atomic_store_n(&s->done, 0, __ATOMIC_RELEASE);
+    __atomic_store_n(&s->state, 0, __ATOMIC_RELEASE);
+    __atomic_store_n(&s->max_frames, BF_TIMESTEP * (int)s->batch_size, __ATOMIC_RELEASE);   /* last: opens the lock-free path */
     return TRUE;
 }
 
-/* One share of a finished batch: the boxes of every stack of this share's src pads as bincode Vec<Bbox> buffers with
- * the frame's PTS (bboxcc/imp.rs:232-272).  A src pad is served by exactly one pusher thread, batches are pushed one
- * after the other: buffers leave every pad in order. */
-static void bf_push_share(gpointer data, gpointer user) {
-    BfPushTask *t = data;
-    GstBlobNetFilter *s = t->s;
+/* One share of a finished batch: the boxes of every stack of this pusher's src pads as bincode Vec<Bbox> buffers with
+ * the frame's PTS (bboxcc/imp.rs:232-272).  A src pad is served by exactly one pusher thread and every pusher takes the
+ * batches in order: buffers leave every pad in order.  Whoever pushes the last share of a batch releases its slot. */
+static void bf_push_share(GstBlobNetFilter *s, BfFlight *fl, guint group, covahip_bbox *bb) {
     GstFlowReturn ret = GST_FLOW_OK;
-    covahip_bbox *bb = g_new(covahip_bbox, s->max_boxes ? s->max_boxes : 1);
-    for (int i = 0; i < t->fl->n_stacks; i++) {
-        const BfMeta *mt = &t->fl->meta[i];
-        if (mt->pad % BF_PUSHERS != t->group) continue;
-        const int n = t->offsets[i + 1] - t->offsets[i];
+    const gint64 t0 = g_get_monotonic_time();
+    for (int i = 0; i < fl->n_stacks; i++) {
+        const BfMeta *mt = &fl->meta[i];
+        if (mt->pad % BF_PUSHERS != group) continue;
+        const int n = fl->offsets[i + 1] - fl->offsets[i];
         int st = 0;
         GstMapInfo m;
         BfPad *p = g_ptr_array_index(s->pads, mt->pad);
-        if (t->counts[i] > n) GST_WARNING_OBJECT(s, "frame with %d boxes truncated to max-boxes = %d", t->counts[i], n);
-        covahip_boxes_to_bbox(t->boxes + t->offsets[i], n, bb);                /* Bbox::new, process.rs:47 */
+        if (fl->counts[i] > n) GST_WARNING_OBJECT(s, "frame with %d boxes truncated to max-boxes = %d", fl->counts[i], n);
+        covahip_boxes_to_bbox(fl->boxes + fl->offsets[i], n, bb);                /* Bbox::new, process.rs:47 */
         const gsize len = covahip_bbox_serialize_vec(bb, (size_t)n, NULL, 0, NULL);
         GstBuffer *b = gst_buffer_new_allocate(NULL, len, NULL);
         gst_buffer_map(b, &m, GST_MAP_WRITE);
@@ -146,12 +166,68 @@ static void bf_push_share(gpointer data, gpointer user) {
         const GstFlowReturn r = gst_pad_push(p->src, b);
         if (r != GST_FLOW_OK && r != GST_FLOW_NOT_LINKED && ret == GST_FLOW_OK) ret = r;
     }
+    g_atomic_int_add(&s->pushers_us, (gint)(g_get_monotonic_time() - t0));
+    const gboolean last = g_atomic_int_dec_and_test(&fl->shares_left);
+    if (last) {
+        g_mutex_lock(&s->pipe_lock);
+        covahip_pipe_release(s->pipe, fl->slot);
+        g_mutex_unlock(&s->pipe_lock);
+    }
+    if (last || ret != GST_FLOW_OK) {
+        g_mutex_lock(&s->lock);
+        if (ret != GST_FLOW_OK) s->push_ret = ret;
+        if (last) {
+            s->frames_out += (guint64)fl->n_stacks;
+            s->in_flight--;
+            g_cond_broadcast(&s->slot_cond);
+        }
+        g_mutex_unlock(&s->lock);
+    }
+    if (last) {
+        g_free(fl->meta);
+        g_free(fl);
+    }
+}
+static gpointer bf_pusher(gpointer data) {
+    BfPusher *pu = data;
+    GstBlobNetFilter *s = pu->s;
+    covahip_bbox *bb = g_new(covahip_bbox, s->max_boxes ? s->max_boxes : 1);
+    gpointer item;
+    while ((item = g_async_queue_pop(pu->q)) != (gpointer)pu)   /* the pusher's own address is the stop token */
+        bf_push_share(s, item, pu->group, bb);
     g_free(bb);
-    g_mutex_lock(&s->push_lock);
-    if (ret != GST_FLOW_OK) s->push_ret = ret;
-    if (--s->push_left == 0) g_cond_broadcast(&s->push_cond);
-    g_mutex_unlock(&s->push_lock);
-    g_free(t);
+    return NULL;
+}
+
+/* Submitter thread: enqueues the GPU work of the filled batches, in order. */
+static gpointer bf_submitter(gpointer data) {
+    GstBlobNetFilter *s = data;
+    g_mutex_lock(&s->lock);
+    while (TRUE) {
+        BfFlight *fl;
+        int rc;
+        while (!s->stop && g_queue_is_empty(&s->submit_q)) g_cond_wait(&s->slot_cond, &s->lock);
+        if (g_queue_is_empty(&s->submit_q)) break;   /* stop */
+        fl = g_queue_pop_head(&s->submit_q);
+        g_mutex_unlock(&s->lock);
+        g_mutex_lock(&s->pipe_lock);
+        rc = covahip_pipe_submit(s->pipe, fl->slot, fl->n_frames, fl->n_stacks, (int)fl->cc_threshold);
+        g_mutex_unlock(&s->pipe_lock);
+        if (rc != COVAHIP_OK)
+            GST_ELEMENT_ERROR(s, LIBRARY, FAILED, ("covahip_pipe_submit: %s (%s)", covahip_strerror(rc), covahip_last_hip_error(s->ctx)), (NULL));
+        g_mutex_lock(&s->lock);
+        if (rc != COVAHIP_OK) {   /* nothing will come back for this batch */
+            s->push_ret = GST_FLOW_ERROR;
+            s->in_flight--;
+            g_free(fl->meta);
+            g_free(fl);
+        } else {
+            g_queue_push_tail(&s->flights, fl);
+        }
+        g_cond_broadcast(&s->slot_cond);
+    }
+    g_mutex_unlock(&s->lock);
+    return NULL;
 }
 
 /* Collector thread: takes the submitted batches in order, waits for their results (the GPU works on the next batch
@@ -164,36 +240,32 @@ static gpointer bf_collector(gpointer data) {
         const int32_t *counts = NULL, *offsets = NULL;
         const covahip_box *boxes = NULL;
         int rc;
-        while (!s->stop && g_queue_is_empty(&s->flights)) g_cond_wait(&s->slot_cond, &s->lock);
-        if (g_queue_is_empty(&s->flights)) break;   /* stop */
+        while (g_queue_is_empty(&s->flights) && !(s->stop && s->in_flight == 0)) g_cond_wait(&s->slot_cond, &s->lock);
+        if (g_queue_is_empty(&s->flights)) break;   /* stop, and nothing queued or being submitted any more */
         fl = g_queue_pop_head(&s->flights);
         g_mutex_unlock(&s->lock);
+        const gint64 tw0 = g_get_monotonic_time();
         rc = covahip_pipe_wait(s->pipe, fl->slot);   /* blocks on the D2H event only: no pipe state is touched */
-        g_mutex_lock(&s->lock);
+        const gint64 tw1 = g_get_monotonic_time();
+        g_mutex_lock(&s->pipe_lock);
         if (rc == COVAHIP_OK) rc = covahip_pipe_collect(s->pipe, fl->slot, &counts, &offsets, &boxes, NULL);
-        g_mutex_unlock(&s->lock);
-        if (rc == COVAHIP_OK) {
-            g_mutex_lock(&s->push_lock);
-            s->push_left = BF_PUSHERS;
-            g_mutex_unlock(&s->push_lock);
-            for (guint g = 0; g < BF_PUSHERS; g++) {
-                BfPushTask *t = g_new(BfPushTask, 1);
-                t->s = s; t->fl = fl; t->counts = counts; t->offsets = offsets; t->boxes = boxes; t->group = g;
-                g_thread_pool_push(s->pushers, t, NULL);
-            }
-            g_mutex_lock(&s->push_lock);
-            while (s->push_left > 0) g_cond_wait(&s->push_cond, &s->push_lock);
-            g_mutex_unlock(&s->push_lock);
-        } else {
-            GST_ELEMENT_ERROR(s, LIBRARY, FAILED, ("covahip_pipe_collect: %s", covahip_strerror(rc)), (NULL));
-        }
+        g_mutex_unlock(&s->pipe_lock);
+        if (rc != COVAHIP_OK) GST_ELEMENT_ERROR(s, LIBRARY, FAILED, ("covahip_pipe_collect: %s", covahip_strerror(rc)), (NULL));
         g_mutex_lock(&s->lock);
-        if (rc == COVAHIP_OK) covahip_pipe_release(s->pipe, fl->slot);
-        s->frames_out += (guint64)fl->n_stacks;
-        s->in_flight--;
-        g_cond_broadcast(&s->slot_cond);
-        g_free(fl->meta);
-        g_free(fl);
+        s->gpu_wait_us += tw1 - tw0;
+        s->push_us += g_get_monotonic_time() - tw1;
+        if (rc == COVAHIP_OK) {
+            /* the pusher threads take it from here; this thread goes on to wait for the next batch */
+            fl->counts = counts; fl->offsets = offsets; fl->boxes = boxes;
+            g_atomic_int_set(&fl->shares_left, BF_PUSHERS);
+            for (guint g = 0; g < BF_PUSHERS; g++) g_async_queue_push(s->pusher[g].q, fl);
+        } else {
+            s->push_ret = GST_FLOW_ERROR;
+            s->in_flight--;
+            g_cond_broadcast(&s->slot_cond);
+            g_free(fl->meta);
+            g_free(fl);
+        }
     }
     g_mutex_unlock(&s->lock);
     return NULL;
@@ -206,67 +278,124 @@ static void bf_wait_idle(GstBlobNetFilter *s) {
 }
 /* Submits the batch being filled (if any) and opens the next slot.  Lock held; it is dropped while results of
  * older batches are pushed downstream, `flushing` keeps every other thread away from the slot state meanwhile. */
-static GstFlowReturn bf_flush_locked(GstBlobNetFilter *s);
 static GstFlowReturn bf_flush(GstBlobNetFilter *s) {   /* caller: lock held, s->flushing false (bf_wait_idle) */
-    GstFlowReturn ret;
-    s->flushing = TRUE;
-    while (g_atomic_int_get(&s->pending) > 0) g_thread_yield();   /* frames of this batch still being copied in (microseconds) */
-    ret = bf_flush_locked(s);
-    s->flushing = FALSE;
-    g_cond_broadcast(&s->flush_cond);
-    return ret;
-}
-static GstFlowReturn bf_flush_locked(GstBlobNetFilter *s) {
+    GstFlowReturn ret = GST_FLOW_OK;
     int rc;
-    if (s->n_stacks > 0) {
+    /* from here on nobody reserves in this slot; the frames taken so far are the batch */
+    guint64 st = __atomic_fetch_or(&s->state, BF_ST_FLUSH, __ATOMIC_ACQ_REL) & ~BF_ST_FLUSH;
+    s->flushing = TRUE;
+    while (__atomic_load_n(&s->done, __ATOMIC_ACQUIRE) != (guint64)BF_ST_FRAMES(st)) g_thread_yield();   /* copies still running (microseconds) */
+    if (BF_ST_STACKS(st) > 0 && s->slot >= 0) {
+        /* hand the filled slot to the submitter thread: the HIP calls of a submission (copies, a dozen launches) take
+         * ~0.2 ms and must not hold up the streaming threads */
         BfFlight *fl = g_new0(BfFlight, 1);
-        rc = covahip_pipe_submit(s->pipe, s->slot, s->n_frames, s->n_stacks, (int)s->cc_threshold);
-        if (rc != COVAHIP_OK) {
-            g_free(fl);
-            GST_ELEMENT_ERROR(s, LIBRARY, FAILED, ("covahip_pipe_submit: %s (%s)", covahip_strerror(rc), covahip_last_hip_error(s->ctx)), (NULL));
-            return GST_FLOW_ERROR;
-        }
         fl->slot = s->slot;
-        fl->n_stacks = s->n_stacks;
-        fl->meta = g_memdup(s->meta, sizeof(BfMeta) * (guint)s->n_stacks);
-        g_queue_push_tail(&s->flights, fl);
+        fl->n_frames = BF_ST_FRAMES(st);
+        fl->n_stacks = BF_ST_STACKS(st);
+        fl->cc_threshold = s->cc_threshold;
+        fl->meta = g_memdup(s->meta, sizeof(BfMeta) * (guint)fl->n_stacks);
+        g_queue_push_tail(&s->submit_q, fl);
         s->in_flight++;
         s->batches++;
         s->slot = -1;
         g_cond_broadcast(&s->slot_cond);
-    } else if (s->slot >= 0) {
-        return GST_FLOW_OK;   /* frames without a complete stack yet (stream start): keep filling the same slot */
     }
-    /* the next slot: when all of them are in flight, wait for the collector to release one (the lock is dropped in the
-     * wait; `flushing` keeps the other streaming threads out meanwhile) */
-    while (s->slot < 0) {
+    /* the next slot: when all of them are in flight, wait for a pusher to release one (the lock is dropped in the wait;
+     * `flushing` keeps the other streaming threads out meanwhile).  Frames without a complete stack yet (stream start)
+     * stay where they are and the same slot goes on being filled. */
+    while (s->slot < 0 && ret == GST_FLOW_OK) {
+        g_mutex_lock(&s->pipe_lock);
         rc = covahip_pipe_acquire(s->pipe, &s->slot, &s->pf, &s->pi);
-        if (rc == COVAHIP_ERR_OVERFLOW) {
+        g_mutex_unlock(&s->pipe_lock);
+        if (rc == COVAHIP_OK) {
+            for (guint i = 0; i < s->pads->len; i++) {
+                BfPad *p = g_ptr_array_index(s->pads, i);
+                for (int k = 0; k < BF_TIMESTEP - 1; k++) p->hist_pos[k] = -1;
+            }
+            __atomic_store_n(&s->done, 0, __ATOMIC_RELEASE);
+            st = (st + BF_ST_ONE_GEN) & ~(BF_ST_ONE_GEN - 1) & ~BF_ST_FLUSH;   /* next generation, nothing taken */
+        } else if (rc == COVAHIP_ERR_OVERFLOW) {
             s->slot = -1;
-            if (s->stop) return GST_FLOW_FLUSHING;
-            g_cond_wait(&s->slot_cond, &s->lock);
-        } else if (rc != COVAHIP_OK) {
-            return GST_FLOW_ERROR;
+            if (s->stop) ret = GST_FLOW_FLUSHING;
+            else {
+                const gint64 t0 = g_get_monotonic_time();
+                g_cond_wait(&s->slot_cond, &s->lock);
+                s->slot_wait_us += g_get_monotonic_time() - t0;
+            }
+        } else {
+            ret = GST_FLOW_ERROR;
         }
     }
-    s->n_frames = s->n_stacks = 0;
-    for (guint i = 0; i < s->pads->len; i++) {
-        BfPad *p = g_ptr_array_index(s->pads, i);
-        for (int k = 0; k < BF_TIMESTEP - 1; k++) p->hist_pos[k] = -1;
-    }
-    return s->push_ret;
+    /* without a slot the flush bit stays: every frame takes the slow path and tries again from here */
+    __atomic_store_n(&s->state, s->slot >= 0 ? st : (st | BF_ST_FLUSH), __ATOMIC_RELEASE);
+    s->flushing = FALSE;
+    g_cond_broadcast(&s->flush_cond);
+    return ret != GST_FLOW_OK ? ret : s->push_ret;
 }
 
-/* One carrier frame of one stream.  Positions in the slot are reserved under the lock; the 32 KB copies into the pinned
- * slot run outside it, so the streaming threads of the N decoder branches copy in parallel. */
+/* Takes the slot positions of one frame (and of the history frames its stack needs that the slot does not hold yet) with
+ * one compare-and-swap, then fills in what it owns: the stack's table row and meta entry, the stream's history.  FALSE:
+ * no room, batch full, or a flush under way -- the caller takes the slow path.  `taken` frames are to be added to
+ * s->done once their bytes are in the slot. */
+static gboolean bf_try_reserve(GstBlobNetFilter *s, BfPad *p, GstBuffer *buf, uint8_t **pf, int *pos, GstBuffer **need,
+                               int *need_pos, gboolean *full, int *taken) {
+    const gboolean complete = p->n_seen >= BF_TIMESTEP - 1;
+    guint64 st = bf_state(s);
+    int extra, next;
+    while (TRUE) {
+        if ((st & BF_ST_FLUSH) || BF_ST_FRAMES(st) + BF_TIMESTEP > __atomic_load_n(&s->max_frames, __ATOMIC_ACQUIRE) || BF_ST_STACKS(st) >= (int)s->batch_size) return FALSE;
+        /* the history positions are this stream's own; a flush resets them, but then the swap below fails (generation) */
+        extra = 0;
+        if (complete) for (int k = 0; k < BF_TIMESTEP - 1; k++) extra += p->hist_pos[k] < 0;
+        if (__atomic_compare_exchange_n(&s->state, &st, st + (guint64)(1 + extra) + (complete ? BF_ST_ONE_STACK : 0), FALSE,
+                                        __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) break;
+    }
+    *pf = s->pf;
+    *pos = BF_ST_FRAMES(st);
+    *taken = 1 + extra;
+    next = *pos + 1;
+    if (complete) {
+        /* a complete stack: T = 0 is this frame, T = k the frame k steps back (metapreprocess/imp.rs:307-320) */
+        const int ns = BF_ST_STACKS(st);
+        int32_t *row = s->pi + (gsize)ns * BF_TIMESTEP;
+        row[0] = *pos;
+        for (int k = 0; k < BF_TIMESTEP - 1; k++) {
+            if (p->hist_pos[k] < 0) {   /* first use in this slot: the frame came with an earlier batch */
+                p->hist_pos[k] = next++;
+                need[k] = gst_buffer_ref(p->hist[k]);
+                need_pos[k] = p->hist_pos[k];
+            }
+            row[k + 1] = p->hist_pos[k];
+        }
+        s->meta[ns].pad = p->idx;
+        s->meta[ns].pts = GST_BUFFER_PTS(buf);
+        s->meta[ns].duration = GST_BUFFER_DURATION(buf);
+        if (ns == 0) {
+            __atomic_store_n(&s->first_us, g_get_monotonic_time(), __ATOMIC_RELEASE);
+            if (s->timeout_us) g_cond_signal(&s->cond);   /* the timeout thread starts its clock for this batch */
+        }
+        *full = ns + 1 >= (int)s->batch_size;
+    }
+    /* history: newest first; the element keeps references, the frame bytes are copied once, into the slot */
+    if (p->hist[BF_TIMESTEP - 2]) gst_buffer_unref(p->hist[BF_TIMESTEP - 2]);
+    for (int k = BF_TIMESTEP - 2; k > 0; k--) { p->hist[k] = p->hist[k - 1]; p->hist_pos[k] = p->hist_pos[k - 1]; }
+    p->hist[0] = buf;                 /* takes over the reference the chain function was given */
+    p->hist_pos[0] = *pos;
+    p->n_seen++;
+    return TRUE;
+}
+
+/* One carrier frame of one stream.  The streaming threads of the N decoder branches take their slot positions without a
+ * lock and copy their 32 KB into the pinned slot in parallel; the element's mutex is for the rest: loading the model,
+ * submitting a batch, waiting for a free slot. */
 static GstFlowReturn bf_chain(GstPad *pad, GstObject *parent, GstBuffer *buf) {
     GstBlobNetFilter *s = (GstBlobNetFilter *)parent;
     BfPad *p = bf_pad_of(s, pad);
     GstFlowReturn ret = GST_FLOW_OK;
     GstBuffer *need[BF_TIMESTEP - 1] = {NULL, NULL, NULL};   /* history frames this slot does not hold yet */
     int need_pos[BF_TIMESTEP - 1] = {0, 0, 0};
-    uint8_t *pf;
-    int pos;
+    uint8_t *pf = NULL;
+    int pos = 0, taken = 0;
     gboolean full = FALSE;
     if (gst_buffer_get_size(buf) < s->frame_bytes || !s->frame_bytes) {
         GST_ELEMENT_ERROR(s, STREAM, FORMAT, ("carrier frame of %" G_GSIZE_FORMAT " bytes, need %" G_GSIZE_FORMAT " (caps set?)",
@@ -274,57 +403,34 @@ static GstFlowReturn bf_chain(GstPad *pad, GstObject *parent, GstBuffer *buf) {
         gst_buffer_unref(buf);
         return GST_FLOW_ERROR;
     }
-    g_mutex_lock(&s->lock);
-    bf_wait_idle(s);
-    if (!bf_ensure_model(s)) ret = GST_FLOW_ERROR;
-    /* room for this frame and, at worst, three history frames of its stream; a full batch whose last copier has not
-     * come back yet is flushed by whoever arrives first */
-    while (ret == GST_FLOW_OK && (s->n_frames + BF_TIMESTEP > s->max_frames || s->n_stacks >= (int)s->batch_size)) {
-        if (s->n_stacks == 0) break;   /* nothing to submit: the streams' warm-up frames alone fill the slot */
-        ret = bf_flush(s);
-        bf_wait_idle(s);
-    }
-    if (ret == GST_FLOW_OK && s->n_frames + BF_TIMESTEP > s->max_frames) {
-        GST_ELEMENT_ERROR(s, CORE, FAILED, ("batch-size %u is too small for %u streams", s->batch_size, s->pads->len), (NULL));
-        ret = GST_FLOW_ERROR;
-    }
-    if (ret != GST_FLOW_OK) {
-        g_mutex_unlock(&s->lock);
-        gst_buffer_unref(buf);
-        return ret;
-    }
-    pf = s->pf;
-    pos = s->n_frames++;
-    if (p->n_seen >= BF_TIMESTEP - 1) {
-        /* a complete stack: T = 0 is this frame, T = k the frame k steps back (metapreprocess/imp.rs:307-320) */
-        int32_t *row = s->pi + (gsize)s->n_stacks * BF_TIMESTEP;
-        row[0] = pos;
-        for (int k = 0; k < BF_TIMESTEP - 1; k++) {
-            if (p->hist_pos[k] < 0) {   /* first use in this slot: the frame came with an earlier batch */
-                p->hist_pos[k] = s->n_frames++;
-                need[k] = gst_buffer_ref(p->hist[k]);
-                need_pos[k] = p->hist_pos[k];
+    if (!bf_try_reserve(s, p, buf, &pf, &pos, need, need_pos, &full, &taken)) {
+        /* ---- slow path */
+        const gint64 ts0 = g_get_monotonic_time();
+        g_mutex_lock(&s->lock);
+        while (TRUE) {
+            guint64 st;
+            bf_wait_idle(s);
+            if (!bf_ensure_model(s)) { ret = GST_FLOW_ERROR; break; }
+            if (bf_try_reserve(s, p, buf, &pf, &pos, need, need_pos, &full, &taken)) break;
+            st = bf_state(s);
+            if (!(st & BF_ST_FLUSH) && BF_ST_STACKS(st) == 0) {
+                /* no room for this frame and at worst three history frames of its stream, and nothing to submit: the
+                 * streams' warm-up frames alone fill the slot */
+                GST_ELEMENT_ERROR(s, CORE, FAILED, ("batch-size %u is too small for %u streams", s->batch_size, s->pads->len), (NULL));
+                ret = GST_FLOW_ERROR;
+                break;
             }
-            row[k + 1] = p->hist_pos[k];
+            /* a full batch whose last copier has not come back yet is flushed by whoever arrives first */
+            if ((ret = bf_flush(s)) != GST_FLOW_OK) break;
         }
-        s->meta[s->n_stacks].pad = p->idx;
-        s->meta[s->n_stacks].pts = GST_BUFFER_PTS(buf);
-        s->meta[s->n_stacks].duration = GST_BUFFER_DURATION(buf);
-        if (s->n_stacks == 0) {
-            s->first_us = g_get_monotonic_time();
-            if (s->timeout_us) g_cond_signal(&s->cond);   /* the timeout thread starts its clock for this batch */
+        g_mutex_unlock(&s->lock);
+        g_atomic_int_add(&s->chain_slow_us, (gint)(g_get_monotonic_time() - ts0));
+        g_atomic_int_inc(&s->chain_slow_n);
+        if (ret != GST_FLOW_OK) {
+            gst_buffer_unref(buf);
+            return ret;
         }
-        s->n_stacks++;
-        full = s->n_stacks >= (int)s->batch_size;
     }
-    /* history: newest first; the element keeps references, the frame bytes are copied once, into the slot */
-    if (p->hist[BF_TIMESTEP - 2]) gst_buffer_unref(p->hist[BF_TIMESTEP - 2]);
-    for (int k = BF_TIMESTEP - 2; k > 0; k--) { p->hist[k] = p->hist[k - 1]; p->hist_pos[k] = p->hist_pos[k - 1]; }
-    p->hist[0] = buf;                 /* takes over the reference the chain function was given */
-    p->hist_pos[0] = pos;
-    p->n_seen++;
-    g_atomic_int_inc(&s->pending);
-    g_mutex_unlock(&s->lock);
 
     gst_buffer_extract(buf, 0, pf + (gsize)pos * s->frame_bytes, s->frame_bytes);   /* metapreprocess copies the same bytes (imp.rs:311-312) */
     for (int k = 0; k < BF_TIMESTEP - 1; k++)
@@ -332,13 +438,15 @@ static GstFlowReturn bf_chain(GstPad *pad, GstObject *parent, GstBuffer *buf) {
             gst_buffer_extract(need[k], 0, pf + (gsize)need_pos[k] * s->frame_bytes, s->frame_bytes);
             gst_buffer_unref(need[k]);
         }
+    __atomic_fetch_add(&s->done, (guint64)taken, __ATOMIC_RELEASE);
 
-    g_atomic_int_add(&s->pending, -1);
     if (full) {   /* the frame that completed the batch submits it, unless a later arrival has done so already */
+        const gint64 tf0 = g_get_monotonic_time();
         g_mutex_lock(&s->lock);
         bf_wait_idle(s);
-        if (s->n_stacks >= (int)s->batch_size) ret = bf_flush(s);
+        if (BF_ST_STACKS(bf_state(s)) >= (int)s->batch_size) ret = bf_flush(s);
         g_mutex_unlock(&s->lock);
+        g_atomic_int_add(&s->chain_flush_us, (gint)(g_get_monotonic_time() - tf0));
     }
     return ret;
 }
@@ -348,8 +456,8 @@ static gpointer bf_timer(gpointer data) {
     GstBlobNetFilter *s = data;
     g_mutex_lock(&s->lock);
     while (!s->stop) {
-        if (s->pipe && s->n_stacks > 0 && s->timeout_us > 0) {
-            const gint64 due = s->first_us + (gint64)s->timeout_us;
+        if (s->pipe && BF_ST_STACKS(bf_state(s)) > 0 && s->timeout_us > 0) {
+            const gint64 due = __atomic_load_n(&s->first_us, __ATOMIC_ACQUIRE) + (gint64)s->timeout_us;
             if (s->flushing) bf_wait_idle(s);
             else if (g_get_monotonic_time() >= due) bf_flush(s);
             else g_cond_wait_until(&s->cond, &s->lock, due);
@@ -441,14 +549,21 @@ static GstStateChangeReturn bf_change_state(GstElement *e, GstStateChange t) {
         g_mutex_lock(&s->lock);
         s->stop = FALSE;
         s->push_ret = GST_FLOW_OK;
-        if (!s->pushers) s->pushers = g_thread_pool_new(bf_push_share, s, BF_PUSHERS, FALSE, NULL);
+        for (guint g = 0; g < BF_PUSHERS; g++)
+            if (!s->pusher[g].th) {
+                s->pusher[g].s = s;
+                s->pusher[g].group = g;
+                if (!s->pusher[g].q) s->pusher[g].q = g_async_queue_new();
+                s->pusher[g].th = g_thread_new("blobnetfilter-push", bf_pusher, &s->pusher[g]);
+            }
         if (!s->timer) s->timer = g_thread_new("blobnetfilter-timeout", bf_timer, s);
+        if (!s->submitter) s->submitter = g_thread_new("blobnetfilter-submit", bf_submitter, s);
         if (!s->collector) s->collector = g_thread_new("blobnetfilter-collect", bf_collector, s);
         g_mutex_unlock(&s->lock);
     }
     r = GST_ELEMENT_CLASS(gst_blobnetfilter_parent_class)->change_state(e, t);
     if (t == GST_STATE_CHANGE_PAUSED_TO_READY) {
-        GThread *th, *tc;
+        GThread *th, *tc, *ts;
         g_mutex_lock(&s->lock);
         s->stop = TRUE;
         g_cond_broadcast(&s->cond);
@@ -456,11 +571,18 @@ static GstStateChangeReturn bf_change_state(GstElement *e, GstStateChange t) {
         g_cond_broadcast(&s->flush_cond);
         th = s->timer;
         tc = s->collector;
-        s->timer = s->collector = NULL;
+        ts = s->submitter;
+        s->timer = s->collector = s->submitter = NULL;
         g_mutex_unlock(&s->lock);
         if (th) g_thread_join(th);
-        if (tc) g_thread_join(tc);   /* drains the batches still queued */
-        if (s->pushers) { g_thread_pool_free(s->pushers, FALSE, TRUE); s->pushers = NULL; }
+        if (ts) g_thread_join(ts);   /* submits what is still queued ... */
+        if (tc) g_thread_join(tc);   /* ... and the collector drains it */
+        for (guint g = 0; g < BF_PUSHERS; g++)
+            if (s->pusher[g].th) {
+                g_async_queue_push(s->pusher[g].q, &s->pusher[g]);   /* stop token, behind whatever is still queued */
+                g_thread_join(s->pusher[g].th);
+                s->pusher[g].th = NULL;
+            }
     }
     return r;
 }
@@ -489,6 +611,13 @@ static void bf_get_property(GObject *o, guint id, GValue *v, GParamSpec *ps) {
     case BF_PROP_CC: g_value_set_uint(v, s->cc_threshold); break;
     case BF_PROP_MAXBOXES: g_value_set_uint(v, s->max_boxes); break;
     case BF_PROP_BATCHES: g_value_set_uint64(v, s->batches); break;
+    case BF_PROP_TIMING: {
+        gchar *t = g_strdup_printf("slot_wait_us=%" G_GINT64_FORMAT " gpu_wait_us=%" G_GINT64_FORMAT " collect_us=%" G_GINT64_FORMAT
+                                   " pushers_us=%d chain_slow_us=%d(n=%d) chain_flush_us=%d",
+                                   s->slot_wait_us, s->gpu_wait_us, s->push_us, s->pushers_us, s->chain_slow_us, s->chain_slow_n, s->chain_flush_us);
+        g_value_take_string(v, t);
+        break;
+    }
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(o, id, ps);
     }
 }
@@ -496,6 +625,8 @@ static void bf_finalize(GObject *o) {
     GstBlobNetFilter *s = (GstBlobNetFilter *)o;
     BfFlight *fl;
     while ((fl = g_queue_pop_head(&s->flights)) != NULL) { g_free(fl->meta); g_free(fl); }
+    while ((fl = g_queue_pop_head(&s->submit_q)) != NULL) { g_free(fl->meta); g_free(fl); }
+    g_mutex_clear(&s->pipe_lock);
     if (s->pipe) covahip_pipe_destroy(s->pipe);
     if (s->ctx) covahip_ctx_destroy(s->ctx);
     for (guint i = 0; i < s->pads->len; i++) {
@@ -508,21 +639,20 @@ static void bf_finalize(GObject *o) {
     g_free(s->meta);
     g_free(s->weights);
     g_mutex_clear(&s->lock);
-    g_mutex_clear(&s->push_lock);
     g_cond_clear(&s->cond);
     g_cond_clear(&s->flush_cond);
     g_cond_clear(&s->slot_cond);
-    g_cond_clear(&s->push_cond);
+    for (guint g = 0; g < BF_PUSHERS; g++) if (s->pusher[g].q) g_async_queue_unref(s->pusher[g].q);
     G_OBJECT_CLASS(gst_blobnetfilter_parent_class)->finalize(o);
 }
 static void gst_blobnetfilter_init(GstBlobNetFilter *s) {
     g_mutex_init(&s->lock);
-    g_mutex_init(&s->push_lock);
     g_cond_init(&s->cond);
     g_cond_init(&s->flush_cond);
     g_cond_init(&s->slot_cond);
-    g_cond_init(&s->push_cond);
     g_queue_init(&s->flights);
+    g_queue_init(&s->submit_q);
+    g_mutex_init(&s->pipe_lock);
     s->pads = g_ptr_array_new();
     s->batch_size = 128;       /* experiment/cova/config.yaml:30-35 */
     s->timeout_us = 40000;     /* nvstreammux batched-push-timeout of the reference pipeline (pipeline.py:146-164) */
@@ -552,6 +682,9 @@ static void gst_blobnetfilter_class_init(GstBlobNetFilterClass *k) {
         "Connected component with area smaller than the threshold is ignored", 0, G_MAXUINT, 30, G_PARAM_READWRITE | GST_PARAM_MUTABLE_PLAYING));
     g_object_class_install_property(g, BF_PROP_MAXBOXES, g_param_spec_uint("max-boxes", "Max boxes",
         "Boxes kept per frame (more are dropped with a warning)", 1, 65536, 256, G_PARAM_READWRITE | GST_PARAM_MUTABLE_READY));
+    g_object_class_install_property(g, BF_PROP_TIMING, g_param_spec_string("timing", "Timing",
+        "Accumulated microseconds: streaming threads waiting for a free slot, collector waiting for the GPU, collecting + pushing results",
+        NULL, G_PARAM_READABLE));
     g_object_class_install_property(g, BF_PROP_BATCHES, g_param_spec_uint64("batches", "Batches", "GPU batches submitted so far", 0,
         G_MAXUINT64, 0, G_PARAM_READABLE));
     gst_element_class_set_static_metadata(e, "BlobNet compressed-domain filter (batched)", "Filter/Video",

@@ -308,3 +308,31 @@ def test_blobnetfilter_batching_element(tmp_path, weights_flat, batch_size, time
             total += int(counts[j])
     assert total > 0
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_streams,batch_size,timeout_us", [(16, 48, 0), (24, 128, 300), (3, 16, 0)])
+def test_blobnetfilter_concurrent_streams(tmp_path, weights_flat, n_streams, batch_size, timeout_us):
+    """One streaming thread per sink pad, all pushing at once (the element's lock-free reservation, the flush hand-over
+    and the ordered pusher threads under contention): every stream carries the same frames, so every src pad must
+    deliver, in PTS order, byte for byte what a stream gets when it runs through the element alone."""
+    from cova_amd import weights as W
+    wpath = tmp_path / "weights.bin"
+    wpath.write_bytes(W.to_bytes(weights_flat))
+    n, warm = 900, 40
+
+    def run(streams, bs, to):
+        env = _env(tmp_path)
+        env.update(MUXBENCH_SAME="1", MUXBENCH_WARM=str(warm))
+        r = subprocess.run([DRIVER, "muxbench", f"blobnetfilter model-weights-file={wpath} batch-size={bs} "
+                            f"batched-push-timeout={to} cc-threshold=2 max-boxes=1024", str(streams), "1280", "720", str(n)],
+                           env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    alone = run(1, 64, 0)
+    assert alone["buffers_out"] == n + warm - 3 and alone["in_order"]
+    many = run(n_streams, batch_size, timeout_us)
+    assert many["buffers_out"] == n_streams * (n + warm - 3) and many["eos"] == n_streams
+    assert many["in_order"] and many["pads_agree"]
+    assert many["pad0_sum"] == alone["pad0_sum"]
