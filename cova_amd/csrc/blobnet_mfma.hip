@@ -98,7 +98,11 @@ __device__ __forceinline__ float pool4(float a0, float a1, float a2, float a3, f
         const float sel = e1 >= 0.f ? mx : mn;
         // an explicit fma: every kernel that shares this epilogue must round the same way whatever the compiler
         // would otherwise contract (the carrier-frame and the stacked path are compared bit for bit)
-        return __builtin_fmaf(fmaxf(sel + e0, 0.f), e1, e2);
+        float r = __builtin_fmaf(fmaxf(sel + e0, 0.f), e1, e2);
+        // ... and an opaque result: wherever the caller converts it to fp16, hipcc must not fold this fma and the
+        // conversion into one v_fma_mixlo_f16 (ONE rounding) in some instantiations and not in others
+        asm volatile("" : "+v"(r));
+        return r;
     }
 }
 
@@ -110,7 +114,7 @@ __device__ __forceinline__ float pool4(float a0, float a1, float a2, float a3, f
 // (row lane%4 of W^T) are per-lane constants.  Inputs of the products are rounded to fp16 (like
 // every other MFMA operand here).
 struct TmixW {
-    half4 a1, a2;
+    half4 a1, a2, id;   // id: row lane%4 of the 4x4 identity (brings the residual into the accumulator, see tmix_core)
 };
 __device__ __forceinline__ TmixW load_tmix(const float *tm, int lane) {
     const int i = lane & 3;
@@ -119,25 +123,55 @@ __device__ __forceinline__ TmixW load_tmix(const float *tm, int lane) {
     for (int t = 0; t < BN_T; t++) {
         w.a1[t] = (_Float16)tm[t * BN_T + i];
         w.a2[t] = (_Float16)tm[16 + t * BN_T + i];
+        w.id[t] = (_Float16)(t == i ? 1.f : 0.f);
     }
     return w;
 }
 // The pooled values are rounded to fp16 ONCE, before both uses (product operand and residual): the carrier-frame
 // path keeps them as an fp16 tensor between its level-0 kernel and this MLP, and both paths compute identical bits.
-__device__ __forceinline__ void tmix4h(const TmixW &w, const half4 pb, half4 &o) {
-    const f32x4 pv = __builtin_convertvector(pb, f32x4);
+// The MLP is bound by vector-ALU instructions, not by the matrix pipe, so everything that can run on the matrix pipe
+// does: the residual p enters as the accumulator of the second product, and it gets there as I * p (exact) instead of
+// four conversions and two packed adds.  N independent elements go through the three products phase by phase: a
+// 4x4x4 product has a handful of cycles of latency that the next element's instructions fill.
+template <int N>
+__device__ __forceinline__ void tmix_core(const TmixW &w, const half4 (&pb)[N], f32x4 (&sum)[N], f32x4 (&pvf)[N]) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     const half4 hz = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
-    const f32x4 u = __builtin_amdgcn_mfma_f32_4x4x4f16(w.a1, pb, z, 0, 0, 0);
-    // relu after the rounding to fp16 (same value as rounding after the relu; packed max)
-    const half4 ub = __builtin_elementwise_max(__builtin_convertvector(u, half4), hz);
-    const f32x4 v = __builtin_amdgcn_mfma_f32_4x4x4f16(w.a2, ub, z, 0, 0, 0);
-    // relu(relu(v) + p) = max(v + p, p, 0)
-    const f32x4 sum = v + pv;
-    f32x4 r;
+    f32x4 u[N];
 #pragma unroll
-    for (int t = 0; t < BN_T; t++) r[t] = fmaxf(fmaxf(sum[t], pv[t]), 0.f);
-    o = __builtin_convertvector(r, half4);
+    for (int e = 0; e < N; e++) u[e] = __builtin_amdgcn_mfma_f32_4x4x4f16(w.a1, pb[e], z, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < N; e++) pvf[e] = __builtin_amdgcn_mfma_f32_4x4x4f16(w.id, pb[e], z, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < N; e++) {
+        // relu after the rounding to fp16 (same value as rounding after the relu; packed max)
+        const half4 ub = __builtin_elementwise_max(__builtin_convertvector(u[e], half4), hz);
+        sum[e] = __builtin_amdgcn_mfma_f32_4x4x4f16(w.a2, ub, pvf[e], 0, 0, 0);
+    }
+}
+// relu(relu(v) + p) = max(v + p, p, 0), taken in fp32 at every call site (one finish everywhere: the stacked, the fused and
+// the carrier-frame kernels are compared bit for bit)
+template <int N>
+__device__ __forceinline__ void tmix4f(const TmixW &w, const half4 (&pb)[N], f32x4 (&r)[N]) {
+    f32x4 sum[N], pvf[N];
+    tmix_core<N>(w, pb, sum, pvf);
+#pragma unroll
+    for (int e = 0; e < N; e++)
+#pragma unroll
+        for (int t = 0; t < BN_T; t++) r[e][t] = fmaxf(fmaxf(sum[e][t], pvf[e][t]), 0.f);
+}
+template <int N>
+__device__ __forceinline__ void tmix4h(const TmixW &w, const half4 (&pb)[N], half4 (&o)[N]) {
+    f32x4 r[N];
+    tmix4f<N>(w, pb, r);
+#pragma unroll
+    for (int e = 0; e < N; e++) o[e] = __builtin_convertvector(r[e], half4);
+}
+__device__ __forceinline__ void tmix4h(const TmixW &w, const half4 pb, half4 &o) {
+    const half4 pbs[1] = {pb};
+    half4 os[1];
+    tmix4h<1>(w, pbs, os);
+    o = os[0];
 }
 __device__ __forceinline__ void tmix4(const TmixW &w, const float (&p)[BN_T], half4 &o) {
     const f32x4 pv = {p[0], p[1], p[2], p[3]};
@@ -189,15 +223,22 @@ __device__ __forceinline__ int swz_eval(const Swz &w, int xx, int yy) {
 struct ItemPlan {
     int paired;            // 0: round robin
     int cnt[2];            // bands per frame of the first / second workgroup of a pair
-    unsigned char band[2][8];
+    // the bands of the two roles, one byte each.  Packed into a scalar on purpose: an array in the kernel arguments
+    // indexed at run time becomes a vector load followed by s_waitcnt vmcnt(0), and that wait also covers every store
+    // of the item just finished (measured: ~2 us per item at level 1)
+    unsigned long long band[2];
 };
 struct ItemIter {
     int b, band;           // current item
     int k, j, role, half;  // state
+    int my_cnt;
+    unsigned long long my_bands;
     __device__ __forceinline__ bool start(const ItemPlan &pl, int B, int nbands) {
         k = 0; j = 0;
         half = (int)gridDim.x >> 1;
         role = pl.paired && (int)blockIdx.x >= half;
+        my_cnt = role ? pl.cnt[1] : pl.cnt[0];
+        my_bands = role ? pl.band[1] : pl.band[0];
         return next(pl, B, nbands);
     }
     __device__ __forceinline__ bool next(const ItemPlan &pl, int B, int nbands) {
@@ -209,10 +250,11 @@ struct ItemIter {
             band = item - b * nbands;
             return true;
         }
-        if (j >= pl.cnt[role]) { j = 0; k++; }
+        if (j >= my_cnt) { j = 0; k++; }
         b = ((int)blockIdx.x - role * half) + k * half;
         if (b >= B) return false;
-        band = pl.band[role][j++];
+        band = (int)((my_bands >> (8 * j)) & 0xFF);
+        j++;
         return true;
     }
 };
@@ -400,10 +442,19 @@ __global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
             const uint32_t tstride = (uint32_t)(p.Ho * p.Wo * 16);
             __half *const ob = p.out + (size_t)b * BN_T * tstride;   // wave-uniform; lanes add a 32-bit offset
             uint8_t *const scr = smem + p.scr_off + wave * 1024;
+            half4 pb2[2], o2[2];
 #pragma unroll
             for (int q = 0; q < 2; q++) {
-                half4 o;
-                tmix4(tm, pooled[q], o);
+                // opaque fp32 values: the BN multiply-add must round to fp32 and THEN to fp16, as enc0p_mfma does (hipcc
+                // would otherwise fuse both into one v_fma_mixlo_f16 and the two entry points would differ in the last bit)
+#pragma unroll
+                for (int t = 0; t < BN_T; t++) asm volatile("" : "+v"(pooled[q][t]));
+                pb2[q] = __builtin_convertvector((f32x4){pooled[q][0], pooled[q][1], pooled[q][2], pooled[q][3]}, half4);
+            }
+            tmix4h<2>(tm, pb2, o2);
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const half4 o = o2[q];
                 _Float16 *sw = reinterpret_cast<_Float16 *>(scr + (2 * g + q) * 32) + co;
 #pragma unroll
                 for (int t = 0; t < BN_T; t++) sw[t * 128] = o[t];
@@ -553,24 +604,45 @@ __global__ __launch_bounds__(WG0, 4) void enc0p_mfma(Enc0pArgs p) {
 // ------------------------------------------------------------------ enc levels 1..3
 // conv3x3 CIN -> COUT on v_mfma_f32_32x32x16_f16.  Wave roles: N-tile = wave % NT,
 // M-group = wave / NT.  One K-step = one tap x 16 input channels.
+#ifdef PHASE_TIMING
+// developer build only (tools/phase_timing.sh): wall-clock ticks (s_memrealtime, 100 MHz) per phase of the item loop,
+// summed over the workgroups' wave 0
+__device__ unsigned long long g_phase[64];
+#define PHASE_MARK(i)                                                     \
+    do {                                                                  \
+        const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+        ph_[i] += now_ - last_;                                           \
+        last_ = now_;                                                     \
+    } while (0)
+#else
+#define PHASE_MARK(i) do { } while (0)
+#endif
 template <int CIN, int COUT, int TPAR, int OCC, int NWV, bool WIDE, bool ALLPOS, bool PRE = false>
 __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     constexpr int WGS = NWV * 64;
     constexpr int NT = COUT / 32, MG = NWV / NT, KC = CIN / 16, KSTEPS = 9 * KC;
     constexpr int CPP = CIN / 8, PS = CIN * 2;
+    constexpr int AD = CIN == 16 ? 0 : CIN == 32 ? 8 : 0;   // depth of the A-fragment ring (see the tile loop): what the register budget allows
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntile = wave % NT, mgroup = wave / NT;
     const int TR = p.TR, TC = p.TC;
     const int tsz = TR * TC * PS;
 
+#ifdef PHASE_TIMING
+    unsigned long long ph_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     half8 bf[KSTEPS];
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ks++) bf[ks] = p.wfrag[(ntile * KSTEPS + ks) * 64 + lane];
     const int co = ntile * 32 + (lane & 31);
     const float e0 = p.epi[co], e1 = p.epi[COUT + co], e2 = p.epi[2 * COUT + co];   // see pool4
     const TmixW tm = load_tmix(p.epi + 3 * COUT, lane);
-
+#ifdef PHASE_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PHASE_MARK(8);   // weight fragments and epilogue constants in registers
+#endif
     ItemIter it;
     for (bool more = it.start(p.plan, p.B, p.nbands); more; more = it.next(p.plan, p.B, p.nbands)) {
         const int b = it.b, band = it.band;
@@ -582,7 +654,23 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
         // lane-only index math out of the item loop -- see enc01_mfma
         int ll = lane;
         asm volatile("" : "+v"(ll));
+        PHASE_MARK(0);   // item bookkeeping (and, first item, the weight loads)
+        // the weights of the level below's temporal MLP: fetched here so that the loads are in flight together with the
+        // band's (they are waited for with it), not on their own between two barriers
+        TmixW tmp;
+        int fidx[BN_T] = {0, 1, 2, 3};   // frame that holds T slice t: the stack's row of the table (PRE) or the stack's own slices
+        if constexpr (PRE) {
+            tmp = load_tmix(p.tm_pre, ll);
+            // a SCALAR load (constant address space; the table is uploaded before the launch and never written by a
+            // kernel): a vector load here would sit behind the previous item's stores in vmcnt order, and the LDS-DMA
+            // below could not be issued before those have drained
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            typedef const __attribute__((address_space(4))) i32x4 *const_i32x4_ptr;
+            const i32x4 row = *(const_i32x4_ptr)(uintptr_t)(p.pidx + b * BN_T);
+            fidx[0] = row[0]; fidx[1] = row[1]; fidx[2] = row[2]; fidx[3] = row[3];
+        }
         lds_barrier();
+        PHASE_MARK(1);   // waiting for the workgroup's other waves to finish the previous item
         // ---- stage the band with LDS-DMA: the tile is swept linearly in 16-byte chunks (64 per
         // wave-instruction); chunk -> (row, col, physical chunk) -> swizzled source chunk; halo
         // columns / out-of-image rows read the zero buffer.  The decomposition is done once per chunk
@@ -594,7 +682,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
             const uint8_t *fbase = reinterpret_cast<const uint8_t *>(p.in) + (PRE ? 0 : (size_t)b * BN_T * tplane);
             size_t foff[BN_T];   // byte offset of the frame that holds T slice t
 #pragma unroll
-            for (int t = 0; t < BN_T; t++) foff[t] = PRE ? (size_t)p.pidx[b * BN_T + t] * tplane : t * tplane;
+            for (int t = 0; t < BN_T; t++) foff[t] = (size_t)fidx[t] * tplane;
             for (int s0 = wave * 64; s0 < nchunk; s0 += WGS) {
                 const int sidx = s0 + ll;
                 if (sidx < nchunk) {
@@ -610,30 +698,36 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
                 }
             }
         }
+        PHASE_MARK(2);   // issuing the band's LDS-DMA
         wait_vmem();
         lds_barrier();
+        PHASE_MARK(3);   // the band landing
         if constexpr (PRE) {
             // ---- temporal MLP of the level below, in place: a lane takes one 16-byte piece (8 channels of a pixel) of
             // all four T slices; the MLP does not depend on the channel, so the swizzle is irrelevant here.  Zero
             // padding stays zero (no bias).
-            const TmixW tmp = load_tmix(p.tm_pre, ll);
             const int nchunk = n2 * TC * CPP;
             for (int sidx = tid; sidx < nchunk; sidx += WGS) {
                 half8 v[BN_T], o[BN_T];
 #pragma unroll
                 for (int t = 0; t < BN_T; t++) v[t] = *reinterpret_cast<const half8 *>(smem + t * tsz + sidx * 16);
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const half4 pb = {v[0][j], v[1][j], v[2][j], v[3][j]};
-                    half4 r;
-                    tmix4h(tmp, pb, r);
+                for (int j0 = 0; j0 < 8; j0 += 4) {
+                    half4 pb[4];
+                    f32x4 r[4];
 #pragma unroll
-                    for (int t = 0; t < BN_T; t++) o[t][j] = r[t];
+                    for (int j = 0; j < 4; j++) pb[j] = half4{v[0][j0 + j], v[1][j0 + j], v[2][j0 + j], v[3][j0 + j]};
+                    tmix4f<4>(tmp, pb, r);
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int t = 0; t < BN_T; t++) o[t][j0 + j] = (_Float16)r[j][t];
                 }
 #pragma unroll
                 for (int t = 0; t < BN_T; t++) *reinterpret_cast<half8 *>(smem + t * tsz + sidx * 16) = o[t];
             }
             lds_barrier();
+            PHASE_MARK(4);   // temporal MLP in place
             // ---- T = 0 slice of the band's own rows -> skip tensor (the last band also owns the odd last row)
             const int ya = y0, yb = (band == p.nbands - 1) ? p.H : y0 + rows;
             const int npc = (yb - ya) * p.W * CPP;
@@ -646,6 +740,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
                 *reinterpret_cast<uint4 *>(sk + ((size_t)(ya + ry) * p.W + x) * CIN + ch * 8) = v;
             }
         }
+        PHASE_MARK(5);   // skip slice out
         // ---- compute
         const int nwin = (rows / 2) * p.Wp;
         const int ntiles = (nwin + 7) / 8;
@@ -656,64 +751,119 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
             const int yy0 = 2 * wy + ((m >> 1) & 1), xx0 = 2 * wx + (m & 1);
             // TPAR T-slices are accumulated at a time (register budget); the pooled values of all
             // four slices are kept for the temporal MLP.
-            float pooled4[BN_T][4];
+            half4 pb4[4];   // the pooled values of window g, T = 0..3, already as the temporal MLP's fp16 operand
+            // The A fragments come through a ring of AD registers, AD MFMAs ahead of their use, across taps and across the
+            // T groups: left to itself hipcc schedules "ds_read_b128; s_waitcnt lgkmcnt(0); v_mfma" with one fragment
+            // register, and with two to four waves per SIMD the matrix pipe then idles for most of every LDS latency.
+            // sched_group_barrier (below the loop) pins that issue order.
+            constexpr int NSG = 9 * KC * TPAR;            // MFMAs per T group
+            constexpr int NS = NSG * (BN_T / TPAR);       // MFMAs per tile
+            auto frag = [&](int s) -> half8 {
+                const int grp = s / NSG, r = s % NSG;
+                const int tap = r / (KC * TPAR), kc = (r / TPAR) % KC, t = r % TPAR;
+                const int yy = yy0 + tap / 3, xx = xx0 + tap % 3;
+                const int pbase = (yy * TC + xx) * PS;
+                const int sw = swz_eval<CPP>(p.swz, xx, yy);
+                return *reinterpret_cast<const half8 *>(smem + (grp * TPAR + t) * tsz + pbase + (((kc * 2 + kh) ^ sw) * 16));
+            };
+            if constexpr (AD > 0) {
+                half8 ab[AD > 0 ? AD : 1];
 #pragma unroll
-            for (int t0 = 0; t0 < BN_T; t0 += TPAR) {
+                for (int s = 0; s < AD; s++) ab[s] = frag(s);
                 f32x16 acc[TPAR];
 #pragma unroll
-                for (int t = 0; t < TPAR; t++)
+                for (int s = 0; s < NS; s++) {
+                    const int grp = s / NSG, r = s % NSG, t = r % TPAR;
+                    if (r < TPAR) {
 #pragma unroll
-                    for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+                        for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
+                    }
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab[s % AD], bf[r / TPAR], acc[t], 0, 0, 0);
+                    if (s + AD < NS) ab[s % AD] = frag(s + AD);
+                    if (r == NSG - 1) {
+                        // reg q -> row (q&3) + 8*(q>>2) + 4*kh -> window 2*(q>>2)+kh, position q&3
 #pragma unroll
-                for (int ky = 0; ky < 3; ky++)
+                        for (int tt = 0; tt < TPAR; tt++)
 #pragma unroll
-                    for (int kx = 0; kx < 3; kx++) {
-                        const int yy = yy0 + ky, xx = xx0 + kx;
-                        const int pbase = (yy * TC + xx) * PS;
-                        const int s = swz_eval<CPP>(p.swz, xx, yy);
+                            for (int g = 0; g < 4; g++)
+                                pb4[g][grp * TPAR + tt] = (_Float16)pool4<ALLPOS>(acc[tt][4 * g], acc[tt][4 * g + 1], acc[tt][4 * g + 2],
+                                                                                  acc[tt][4 * g + 3], e0, e1, e2);
+                    }
+                }
+                // the issue order of the matrix and LDS-read instructions above: AD reads, then one read behind every MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, AD, 0);
 #pragma unroll
-                        for (int kc = 0; kc < KC; kc++) {
-                            const int off = pbase + (((kc * 2 + kh) ^ s) * 16);
+                for (int s = 0; s < NS; s++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (s + AD < NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            } else {
+                // (level 3: 144 weight registers leave no room for a ring; the compiler's own order, one fragment at a time)
 #pragma unroll
-                            for (int t = 0; t < TPAR; t++) {
-                                const half8 a = *reinterpret_cast<const half8 *>(smem + (t0 + t) * tsz + off);
-                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[(ky * 3 + kx) * KC + kc], acc[t],
-                                                                                0, 0, 0);
+                for (int grp = 0; grp < BN_T / TPAR; grp++) {
+                    f32x16 acc[TPAR];
+#pragma unroll
+                    for (int t = 0; t < TPAR; t++)
+#pragma unroll
+                        for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++) {
+                            const int yy = yy0 + ky, xx = xx0 + kx;
+                            const int pbase = (yy * TC + xx) * PS;
+                            const int sw = swz_eval<CPP>(p.swz, xx, yy);
+#pragma unroll
+                            for (int kc = 0; kc < KC; kc++) {
+                                const int off = pbase + (((kc * 2 + kh) ^ sw) * 16);
+#pragma unroll
+                                for (int t = 0; t < TPAR; t++) {
+                                    const half8 a = *reinterpret_cast<const half8 *>(smem + (grp * TPAR + t) * tsz + off);
+                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[(ky * 3 + kx) * KC + kc], acc[t], 0, 0, 0);
+                                }
                             }
                         }
-                    }
-                // reg r -> row (r&3) + 8*(r>>2) + 4*kh -> window 2*(r>>2)+kh, position r&3
 #pragma unroll
-                for (int t = 0; t < TPAR; t++)
+                    for (int tt = 0; tt < TPAR; tt++)
 #pragma unroll
-                    for (int g = 0; g < 4; g++)
-                        pooled4[t0 + t][g] = pool4<ALLPOS>(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2],
-                                                   acc[t][4 * g + 3], e0, e1, e2);
+                        for (int g = 0; g < 4; g++)
+                            pb4[g][grp * TPAR + tt] = (_Float16)pool4<ALLPOS>(acc[tt][4 * g], acc[tt][4 * g + 1], acc[tt][4 * g + 2],
+                                                                              acc[tt][4 * g + 3], e0, e1, e2);
+                }
             }
-            // Materialise all 16 pooled values here (empty asm = opaque use): the accumulators die
-            // before the epilogue starts.  Without this point hipcc interleaves the pooling of later
-            // T-slices with the epilogue and the 64->128 level spills >150 registers.
+            // Materialise the pooled values here (empty asm = opaque use): the accumulators die before the epilogue
+            // starts.  Without this point hipcc interleaves the pooling of later T-slices with the epilogue and the
+            // 64->128 level spills >150 registers.
 #pragma unroll
-            for (int t = 0; t < BN_T; t++)
-#pragma unroll
-                for (int g = 0; g < 4; g++) asm volatile("" : "+v"(pooled4[t][g]));
+            for (int g = 0; g < 4; g++) {
+                typedef int i32x2 __attribute__((ext_vector_type(2)));
+                i32x2 bits = __builtin_bit_cast(i32x2, pb4[g]);
+                asm volatile("" : "+v"(bits));
+                pb4[g] = __builtin_bit_cast(half4, bits);
+            }
+            PHASE_MARK(6);   // tiles: matrix part (A fragments, MFMAs, pooling)
             // ---- epilogue: temporal MLP + residual per pooled window, then store
             const uint32_t tstride = (uint32_t)(p.Ho * p.Wo * COUT);
-            __half *const ob = p.out + (size_t)b * p.To * tstride;   // wave-uniform; lanes add a 32-bit offset
+            // the last level feeds the decoder, which takes T = 0 only (To == 1 there; the host sets it so): a constant
+            // lets the other three outputs of the temporal MLP and their stores fall away at compile time
+            const int To = COUT == 128 ? 1 : p.To;
+            __half *const ob = p.out + (size_t)b * To * tstride;   // wave-uniform; lanes add a 32-bit offset
             if constexpr (WIDE) {
                 // wave-private LDS transpose (see enc0_mfma): S[t][window][32 channels], two 16-byte
                 // pieces per lane -> two global_store_dwordx4 per tile instead of sixteen 2-byte stores
                 uint8_t *const scr = smem + p.scr_off + wave * 2048;
+                half4 o4[4];
+                if constexpr (CIN == 64) {   // 144 weight registers: one element at a time
+#pragma unroll
+                    for (int g = 0; g < 4; g++) tmix4h(tm, pb4[g], o4[g]);
+                } else {
+                    tmix4h<4>(tm, pb4, o4);
+                }
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    float pooled[BN_T];
-                    half4 o;
-#pragma unroll
-                    for (int t = 0; t < BN_T; t++) pooled[t] = pooled4[t][g];
-                    tmix4(tm, pooled, o);
                     _Float16 *sw = reinterpret_cast<_Float16 *>(scr + (2 * g + kh) * 64) + (ll & 31);
 #pragma unroll
-                    for (int t = 0; t < BN_T; t++) sw[t * 256] = o[t];
+                    for (int t = 0; t < BN_T; t++) sw[t * 256] = o4[g][t];
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -726,20 +876,23 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
 #pragma unroll
                     for (int j = 0; j < 2; j++) {
                         const int t = 2 * j + (ll >> 5);
-                        if (t < p.To) {
+                        if (t < To) {
                             const uint4 v = *reinterpret_cast<const uint4 *>(scr + (j * 64 + ll) * 16);
                             *reinterpret_cast<uint4 *>(ob + t * tstride + eo) = v;
                         }
                     }
                 }
             } else {
+                half4 o4[4];
+                if constexpr (CIN == 64) {   // 144 weight registers: one element at a time
+#pragma unroll
+                    for (int g = 0; g < 4; g++) tmix4h(tm, pb4[g], o4[g]);
+                } else {
+                    tmix4h<4>(tm, pb4, o4);
+                }
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    float pooled[BN_T];
-                    half4 o;
-#pragma unroll
-                    for (int t = 0; t < BN_T; t++) pooled[t] = pooled4[t][g];
-                    tmix4(tm, pooled, o);
+                    const half4 o = o4[g];
                     const int owin = tile * 8 + 2 * g + kh;
                     if (owin < nwin) {
                         const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
@@ -747,12 +900,18 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
                         const uint32_t eo = (uint32_t)((gy * p.Wo + gx) * COUT + co);
 #pragma unroll
                         for (int t = 0; t < BN_T; t++)
-                            if (t < p.To) reinterpret_cast<_Float16 *>(ob + t * tstride)[eo] = o[t];
+                            if (t < To) reinterpret_cast<_Float16 *>(ob + t * tstride)[eo] = o[t];
                     }
                 }
             }
+            PHASE_MARK(7);   // tiles: epilogue (temporal MLP, transpose, stores)
         }
+        PHASE_MARK(6);
     }
+#ifdef PHASE_TIMING
+    if (tid == 0)
+        for (int i = 0; i < 9; i++) atomicAdd(&g_phase[i + (PRE ? 0 : COUT == 64 ? 16 : COUT == 128 ? 32 : 48)], ph_[i]);
+#endif
 }
 
 // ------------------------------------------------------------------ enc levels 0 + 1 fused
@@ -1799,8 +1958,8 @@ ItemPlan make_plan(int grid, int num_cu, int wgs_per_cu, int batch, int nbands, 
     pl.paired = 1;
     pl.cnt[0] = pl.cnt[1] = nbands / 2;
     for (int k = 0; k < nbands / 2; k++) {
-        pl.band[0][k] = (unsigned char)order[k];                 // the larger bands: first (older, faster) workgroup
-        pl.band[1][k] = (unsigned char)order[nbands / 2 + k];
+        pl.band[0] |= (unsigned long long)order[k] << (8 * k);                 // the larger bands: first (older, faster) workgroup
+        pl.band[1] |= (unsigned long long)order[nbands / 2 + k] << (8 * k);
     }
     return pl;
 }
@@ -2137,7 +2296,7 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const BnInput &in
         // output transpose scratch behind the tile: 1 KB per wave at level 0, 2 KB per wave at levels 1 and 3
         // (level 2 keeps 2-byte stores: its 80 KB tile leaves no room beside a second workgroup)
         static const int enc_waves[BN_LEVELS] = {WG0 / 64, 8, 4, 8};
-        static const bool enc_wide[BN_LEVELS] = {true, true, false, true};
+        static const bool enc_wide[BN_LEVELS] = {true, true, true, true};
         const size_t scr_bytes = (i == 0) ? (size_t)enc_waves[0] * 1024 : (enc_wide[i] ? (size_t)enc_waves[i] * 2048 : 0);
         const int wgs_per_cu = (i == BN_LEVELS - 1) ? 1 : 2;
         const size_t lds_cap = (wgs_per_cu == 1 ? 150 * 1024 : 80 * 1024) - scr_bytes;
@@ -2201,11 +2360,11 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const BnInput &in
                 if (pr->allpos[i]) LAUNCH((enc_mfma<16, 32, 2, 4, 8, true, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
                 else LAUNCH((enc_mfma<16, 32, 2, 4, 8, true, false>), dim3(grid), dim3(512), lds, ctx->stream, a);
             } else if (i == 2) {
-                rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<32, 64, 4, 2, 4, false, true>, lds) : set_lds(ctx, enc_mfma<32, 64, 4, 2, 4, false, false>, lds);
+                rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<32, 64, 4, 2, 4, true, true>, lds) : set_lds(ctx, enc_mfma<32, 64, 4, 2, 4, true, false>, lds);
                 if (rc) return rc;
                 ProfScope ps(ctx, "enc2_mfma");
-                if (pr->allpos[i]) LAUNCH((enc_mfma<32, 64, 4, 2, 4, false, true>), dim3(grid), dim3(WG), lds, ctx->stream, a);
-                else LAUNCH((enc_mfma<32, 64, 4, 2, 4, false, false>), dim3(grid), dim3(WG), lds, ctx->stream, a);
+                if (pr->allpos[i]) LAUNCH((enc_mfma<32, 64, 4, 2, 4, true, true>), dim3(grid), dim3(WG), lds, ctx->stream, a);
+                else LAUNCH((enc_mfma<32, 64, 4, 2, 4, true, false>), dim3(grid), dim3(WG), lds, ctx->stream, a);
             } else {
                 rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<64, 128, 2, 2, 8, true, true>, lds) : set_lds(ctx, enc_mfma<64, 128, 2, 2, 8, true, false>, lds);
                 if (rc) return rc;
@@ -2323,3 +2482,14 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const BnInput &in
     }
     return COVAHIP_OK;
 }
+
+#ifdef PHASE_TIMING
+extern "C" int covahip_dev_phase_read(unsigned long long *out64, int reset) {
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase), sizeof(g_phase)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[64] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif

@@ -1,0 +1,38 @@
+"""Developer helper, ON THE GPU BOX with a -DPHASE_TIMING build copied over cova_amd/libcovahip.so (see tools/README.md):
+wall-clock share of each phase of enc_mfma's item loop (wave 0 of every workgroup, summed), levels 1..3."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cova_amd import synth, weights as W  # noqa: E402
+from cova_amd.elements import BlobNetInfer, Context  # noqa: E402
+from cova_amd import _lib as L  # noqa: E402
+
+B, H, Wd = 256, 68, 120
+ctx = Context(0)
+net = BlobNetInfer(ctx, W.random_init(1234), H, Wd, max_batch=B)
+frames, index = synth.carrier_batch(B, H, Wd, seed=1, streams=8)
+d_frames = ctx.malloc(frames.nbytes)
+ctx.h2d(d_frames, frames)
+d_boxes, d_counts, d_mask = ctx.malloc(B * 256 * 20), ctx.malloc(B * 4), ctx.malloc(B * H * Wd)
+lib = ctypes.CDLL(L.LIB_PATH)
+out = (ctypes.c_ulonglong * 64)()
+names = ["bookkeeping", "barrier (previous item)", "DMA issue", "band landing", "temporal MLP in place", "skip slice out", "tiles: matrix part", "tiles: epilogue", "weights into registers (kernel start)"]
+steps = 20
+for _ in range(3):
+    net.filter_frames_device(d_frames, frames.shape[0], index, B, 1, d_boxes, d_counts, 256, d_mask)
+ctx.sync()
+lib.covahip_dev_phase_read(out, 1)
+for _ in range(steps):
+    net.filter_frames_device(d_frames, frames.shape[0], index, B, 1, d_boxes, d_counts, 256, d_mask)
+ctx.sync()
+lib.covahip_dev_phase_read(out, 1)
+v = np.array(list(out), dtype=np.float64)
+for base, label in ((0, "enc1t (PRE)"), (16, "enc2"), (32, "enc3")):
+    tot = v[base:base + 9].sum()
+    print(f"{label}: {tot / steps / 100:.0f} us of workgroup time per launch (all workgroups)")
+    for i, n in enumerate(names):
+        print(f"   {n:28s} {100 * v[base + i] / tot:5.1f} %   {v[base + i] / steps / 100 / 512:7.2f} us per workgroup (512 of them)")
