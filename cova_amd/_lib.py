@@ -155,6 +155,7 @@ PROTOTYPES = {
 DEV_PROTOTYPES = {
     "covahip_blobnet_set_impl": (C.c_int, [_P, C.c_int]),
     "covahip_bboxcc_set_wave_cap": (C.c_int, [_P, C.c_int]),
+    "covahip_blobnet_set_enc_plan": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
 }
 
 _lib = None

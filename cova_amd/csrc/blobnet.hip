@@ -241,6 +241,13 @@ int covahip_blobnet_macs_per_frame(covahip_ctx *ctx, int64_t *macs) {
     return COVAHIP_OK;
 }
 
+int covahip_blobnet_set_enc_plan(covahip_ctx *ctx, int level, int nbands, int nbuf) {
+    if (!ctx || level < 1 || level > 3 || nbands < 0 || nbands > 64 || (nbands && nbuf != 1 && nbuf != 2)) return COVAHIP_ERR_INVALID_ARG;
+    ctx->enc_plan[level].nbands = nbands;
+    ctx->enc_plan[level].nbuf = nbands ? nbuf : 0;
+    return COVAHIP_OK;
+}
+
 int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl) {
     if (!ctx || !ctx->blobnet) return COVAHIP_ERR_NOT_LOADED;
     if (impl < 1 || impl > 3) return COVAHIP_ERR_INVALID_ARG;

@@ -283,6 +283,7 @@ struct EncArgs {
     const void *zero;  // >= 16 zero bytes in global memory (source of halo / padding chunks)
     Swz swz;           // LDS pixel swizzle of this launch (choose_swz)
     int scr_off;       // byte offset of the per-wave output transpose scratch (2 KB per wave) in LDS (WIDE)
+    int nbuf, buf_stride;   // LDS band buffers (1 or 2) and their distance in bytes
     ItemPlan plan;
     // PRE (level 1 of the carrier-frame path): `in` is the tensor P of enc0p_mfma, [F][H][W][CIN]; stack b takes its
     // T = 0..3 slices from frames pidx[4b .. 4b+3]; the temporal MLP of the level below (weights tm_pre) is
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     constexpr int WGS = NWV * 64;
     constexpr int NT = COUT / 32, MG = NWV / NT, KC = CIN / 16, KSTEPS = 9 * KC;
     constexpr int CPP = CIN / 8, PS = CIN * 2;
-    constexpr int AD = CIN == 16 ? 0 : CIN == 32 ? 8 : 0;   // depth of the A-fragment ring (see the tile loop): what the register budget allows
+    constexpr int AD = CIN == 32 ? 8 : 0;   // depth of the A-fragment ring (see the tile loop): what the register budget allows
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntile = wave % NT, mgroup = wave / NT;
@@ -643,8 +644,58 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PHASE_MARK(8);   // weight fragments and epilogue constants in registers
 #endif
+    // ---- stage one band with LDS-DMA: the tile is swept linearly in 16-byte chunks (64 per wave-instruction);
+    // chunk -> (row, col, physical chunk) -> swizzled source chunk; halo columns / out-of-image rows read the zero
+    // buffer.  The decomposition is done once per chunk position and reused for the four T slices (source + t * plane,
+    // LDS + t * tsz).
+    auto stage = [&](int sb, int sband, uint8_t *dst, int ll) {
+        const int sy0 = 2 * ((sband * p.Hp) / p.nbands);
+        const int sn2 = 2 * (((sband + 1) * p.Hp) / p.nbands) - sy0 + 2;
+        int fidx[BN_T] = {0, 1, 2, 3};   // frame that holds T slice t: the stack's row of the table (PRE) or the stack's own slices
+        if constexpr (PRE) {
+            // a SCALAR load (constant address space; the table is uploaded before the launch and never written by a
+            // kernel): a vector load here would sit behind the previous item's stores in vmcnt order, and the LDS-DMA
+            // below could not be issued before those have drained
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            typedef const __attribute__((address_space(4))) i32x4 *const_i32x4_ptr;
+            const i32x4 row = *(const_i32x4_ptr)(uintptr_t)(p.pidx + sb * BN_T);
+            fidx[0] = row[0]; fidx[1] = row[1]; fidx[2] = row[2]; fidx[3] = row[3];
+        }
+        const int RC = TC * CPP;  // chunks per tile row
+        const int nchunk = sn2 * RC;
+        const size_t tplane = (size_t)p.H * p.W * CIN * 2;   // bytes
+        const uint8_t *fbase = reinterpret_cast<const uint8_t *>(p.in) + (PRE ? 0 : (size_t)sb * BN_T * tplane);
+        size_t foff[BN_T];   // byte offset of the frame that holds T slice t
+#pragma unroll
+        for (int t = 0; t < BN_T; t++) foff[t] = (size_t)fidx[t] * tplane;
+        for (int s0 = wave * 64; s0 < nchunk; s0 += WGS) {
+            const int sidx = s0 + ll;
+            if (sidx < nchunk) {
+                const int r = fdiv(sidx, p.mRC), within = sidx - r * RC;
+                const int c = within / CPP, chp = within % CPP;
+                const int ch = chp ^ swz_eval<CPP>(p.swz, c, r);
+                const int y = sy0 - 1 + r, x = c - 1;
+                const bool in = y >= 0 && y < p.H && x >= 0 && x < p.W;
+                const uint8_t *src = in ? fbase + ((size_t)(y * p.W + x) * CIN + ch * 8) * 2
+                                        : reinterpret_cast<const uint8_t *>(p.zero);
+#pragma unroll
+                for (int t = 0; t < BN_T; t++) glds16(src + (in ? foff[t] : 0), dst + t * tsz + s0 * 16);
+            }
+        }
+    };
+    // Items (frame, band) of this workgroup, one after the other.  With two LDS buffers (p.nbuf == 2, when the host
+    // found room) the next item's band is in flight while this one is computed: ONE barrier per item, right after
+    // the item's own band has landed -- every wave has then left the previous item, whose buffer the next band may
+    // overwrite.  With one buffer: barrier, stage, wait, barrier.
     ItemIter it;
-    for (bool more = it.start(p.plan, p.B, p.nbands); more; more = it.next(p.plan, p.B, p.nbands)) {
+    bool more = it.start(p.plan, p.B, p.nbands);
+    const bool dbl = p.nbuf == 2;
+    int cur = 0;
+    if (more && dbl) {
+        stage(it.b, it.band, smem, lane);
+        wait_vmem();
+    }
+    while (more) {
         const int b = it.b, band = it.band;
         // balanced bands of whole pool-window rows
         const int y0 = 2 * ((band * p.Hp) / p.nbands);
@@ -654,54 +705,35 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
         // lane-only index math out of the item loop -- see enc01_mfma
         int ll = lane;
         asm volatile("" : "+v"(ll));
-        PHASE_MARK(0);   // item bookkeeping (and, first item, the weight loads)
+        uint8_t *const bandp = smem + cur * p.buf_stride;   // this item's band in LDS
+        PHASE_MARK(0);   // item bookkeeping
         // the weights of the level below's temporal MLP: fetched here so that the loads are in flight together with the
         // band's (they are waited for with it), not on their own between two barriers
         TmixW tmp;
-        int fidx[BN_T] = {0, 1, 2, 3};   // frame that holds T slice t: the stack's row of the table (PRE) or the stack's own slices
-        if constexpr (PRE) {
-            tmp = load_tmix(p.tm_pre, ll);
-            // a SCALAR load (constant address space; the table is uploaded before the launch and never written by a
-            // kernel): a vector load here would sit behind the previous item's stores in vmcnt order, and the LDS-DMA
-            // below could not be issued before those have drained
-            typedef int i32x4 __attribute__((ext_vector_type(4)));
-            typedef const __attribute__((address_space(4))) i32x4 *const_i32x4_ptr;
-            const i32x4 row = *(const_i32x4_ptr)(uintptr_t)(p.pidx + b * BN_T);
-            fidx[0] = row[0]; fidx[1] = row[1]; fidx[2] = row[2]; fidx[3] = row[3];
+        if constexpr (PRE) tmp = load_tmix(p.tm_pre, ll);
+        if (!dbl) {
+            lds_barrier();
+            PHASE_MARK(1);   // waiting for the workgroup's other waves to finish the previous item
+            stage(b, band, bandp, ll);
+            PHASE_MARK(2);   // issuing the band's LDS-DMA
+            wait_vmem();
         }
         lds_barrier();
-        PHASE_MARK(1);   // waiting for the workgroup's other waves to finish the previous item
-        // ---- stage the band with LDS-DMA: the tile is swept linearly in 16-byte chunks (64 per
-        // wave-instruction); chunk -> (row, col, physical chunk) -> swizzled source chunk; halo
-        // columns / out-of-image rows read the zero buffer.  The decomposition is done once per chunk
-        // position and reused for the four T slices (source + t * plane, LDS + t * tsz).
-        {
-            const int RC = TC * CPP;  // chunks per tile row
-            const int nchunk = n2 * RC;
-            const size_t tplane = (size_t)p.H * p.W * CIN * 2;   // bytes
-            const uint8_t *fbase = reinterpret_cast<const uint8_t *>(p.in) + (PRE ? 0 : (size_t)b * BN_T * tplane);
-            size_t foff[BN_T];   // byte offset of the frame that holds T slice t
-#pragma unroll
-            for (int t = 0; t < BN_T; t++) foff[t] = (size_t)fidx[t] * tplane;
-            for (int s0 = wave * 64; s0 < nchunk; s0 += WGS) {
-                const int sidx = s0 + ll;
-                if (sidx < nchunk) {
-                    const int r = fdiv(sidx, p.mRC), within = sidx - r * RC;
-                    const int c = within / CPP, chp = within % CPP;
-                    const int ch = chp ^ swz_eval<CPP>(p.swz, c, r);
-                    const int y = y0 - 1 + r, x = c - 1;
-                    const bool in = y >= 0 && y < p.H && x >= 0 && x < p.W;
-                    const uint8_t *src = in ? fbase + ((size_t)(y * p.W + x) * CIN + ch * 8) * 2
-                                            : reinterpret_cast<const uint8_t *>(p.zero);
-#pragma unroll
-                    for (int t = 0; t < BN_T; t++) glds16(src + (in ? foff[t] : 0), smem + t * tsz + s0 * 16);
-                }
-            }
+        PHASE_MARK(3);   // the band landing / the other waves leaving the previous item
+        more = it.next(p.plan, p.B, p.nbands);
+        // Two buffers: the next band is requested now and waited for (vmcnt(0), in `landed()`) right before this item's
+        // first global store -- NOT at the top of the next item: the counter is in order, and a wait placed behind the
+        // epilogue's stores is a wait for those stores to be acknowledged (measured: 1.6 us per item).  At the
+        // first store the youngest outstanding operation is the request itself, one MLP pass or one tile old.
+        bool in_flight = false;
+        if (dbl) {
+            if (more) { stage(it.b, it.band, smem + (cur ^ 1) * p.buf_stride, ll); in_flight = true; }
+            cur ^= 1;
+            PHASE_MARK(2);
         }
-        PHASE_MARK(2);   // issuing the band's LDS-DMA
-        wait_vmem();
-        lds_barrier();
-        PHASE_MARK(3);   // the band landing
+        auto landed = [&]() {
+            if (in_flight) { wait_vmem(); in_flight = false; }
+        };
         if constexpr (PRE) {
             // ---- temporal MLP of the level below, in place: a lane takes one 16-byte piece (8 channels of a pixel) of
             // all four T slices; the MLP does not depend on the channel, so the swizzle is irrelevant here.  Zero
@@ -710,7 +742,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
             for (int sidx = tid; sidx < nchunk; sidx += WGS) {
                 half8 v[BN_T], o[BN_T];
 #pragma unroll
-                for (int t = 0; t < BN_T; t++) v[t] = *reinterpret_cast<const half8 *>(smem + t * tsz + sidx * 16);
+                for (int t = 0; t < BN_T; t++) v[t] = *reinterpret_cast<const half8 *>(bandp + t * tsz + sidx * 16);
 #pragma unroll
                 for (int j0 = 0; j0 < 8; j0 += 4) {
                     half4 pb[4];
@@ -724,10 +756,11 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
                         for (int t = 0; t < BN_T; t++) o[t][j0 + j] = (_Float16)r[j][t];
                 }
 #pragma unroll
-                for (int t = 0; t < BN_T; t++) *reinterpret_cast<half8 *>(smem + t * tsz + sidx * 16) = o[t];
+                for (int t = 0; t < BN_T; t++) *reinterpret_cast<half8 *>(bandp + t * tsz + sidx * 16) = o[t];
             }
             lds_barrier();
             PHASE_MARK(4);   // temporal MLP in place
+            landed();
             // ---- T = 0 slice of the band's own rows -> skip tensor (the last band also owns the odd last row)
             const int ya = y0, yb = (band == p.nbands - 1) ? p.H : y0 + rows;
             const int npc = (yb - ya) * p.W * CPP;
@@ -736,7 +769,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
                 const int pix = i / CPP, ch = i % CPP;
                 const int ry = pix / p.W, x = pix - ry * p.W;
                 const int r = ya - y0 + 1 + ry, c = x + 1;
-                const uint4 v = *reinterpret_cast<const uint4 *>(smem + (r * TC + c) * PS + ((ch ^ swz_eval<CPP>(p.swz, c, r)) * 16));
+                const uint4 v = *reinterpret_cast<const uint4 *>(bandp + (r * TC + c) * PS + ((ch ^ swz_eval<CPP>(p.swz, c, r)) * 16));
                 *reinterpret_cast<uint4 *>(sk + ((size_t)(ya + ry) * p.W + x) * CIN + ch * 8) = v;
             }
         }
@@ -764,7 +797,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
                 const int yy = yy0 + tap / 3, xx = xx0 + tap % 3;
                 const int pbase = (yy * TC + xx) * PS;
                 const int sw = swz_eval<CPP>(p.swz, xx, yy);
-                return *reinterpret_cast<const half8 *>(smem + (grp * TPAR + t) * tsz + pbase + (((kc * 2 + kh) ^ sw) * 16));
+                return *reinterpret_cast<const half8 *>(bandp + (grp * TPAR + t) * tsz + pbase + (((kc * 2 + kh) ^ sw) * 16));
             };
             if constexpr (AD > 0) {
                 half8 ab[AD > 0 ? AD : 1];
@@ -818,7 +851,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
                                 const int off = pbase + (((kc * 2 + kh) ^ sw) * 16);
 #pragma unroll
                                 for (int t = 0; t < TPAR; t++) {
-                                    const half8 a = *reinterpret_cast<const half8 *>(smem + (grp * TPAR + t) * tsz + off);
+                                    const half8 a = *reinterpret_cast<const half8 *>(bandp + (grp * TPAR + t) * tsz + off);
                                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[(ky * 3 + kx) * KC + kc], acc[t], 0, 0, 0);
                                 }
                             }
@@ -842,6 +875,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
                 pb4[g] = __builtin_bit_cast(half4, bits);
             }
             PHASE_MARK(6);   // tiles: matrix part (A fragments, MFMAs, pooling)
+            landed();
             // ---- epilogue: temporal MLP + residual per pooled window, then store
             const uint32_t tstride = (uint32_t)(p.Ho * p.Wo * COUT);
             // the last level feeds the decoder, which takes T = 0 only (To == 1 there; the host sets it so): a constant
@@ -906,10 +940,14 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
             }
             PHASE_MARK(7);   // tiles: epilogue (temporal MLP, transpose, stores)
         }
+        landed();   // a wave without a tile in this item
         PHASE_MARK(6);
     }
 #ifdef PHASE_TIMING
-    if (tid == 0)
+#ifndef PHASE_WAVE
+#define PHASE_WAVE 0
+#endif
+    if (tid == 64 * (PHASE_WAVE < 0 ? NWV + PHASE_WAVE : PHASE_WAVE))
         for (int i = 0; i < 9; i++) atomicAdd(&g_phase[i + (PRE ? 0 : COUT == 64 ? 16 : COUT == 128 ? 32 : 48)], ph_[i]);
 #endif
 }
@@ -2297,26 +2335,37 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const BnInput &in
         // (level 2 keeps 2-byte stores: its 80 KB tile leaves no room beside a second workgroup)
         static const int enc_waves[BN_LEVELS] = {WG0 / 64, 8, 4, 8};
         static const bool enc_wide[BN_LEVELS] = {true, true, true, true};
-        const size_t scr_bytes = (i == 0) ? (size_t)enc_waves[0] * 1024 : (enc_wide[i] ? (size_t)enc_waves[i] * 2048 : 0);
-        const int wgs_per_cu = (i == BN_LEVELS - 1) ? 1 : 2;
-        const size_t lds_cap = (wgs_per_cu == 1 ? 150 * 1024 : 80 * 1024) - scr_bytes;
-        // band planner: bands of whole pool-window rows.  Workgroups are persistent (wgs_per_cu per CU)
-        // and take items round-robin, so a launch lasts ceil(items / slots) rounds of one band each;
-        // a band costs its window rows plus about one row of halo staging + barriers.  Pick the band
-        // count that fits in LDS and minimises rounds x (rows + 1).
+        int waves = enc_waves[i], nbuf = 1, wgs_per_cu = (i == BN_LEVELS - 1) ? 1 : 2;
         int nbands = 0, RB = 0;
-        const long long slots = (long long)wgs_per_cu * num_cu;
-        long long best = -1;
-        for (int nb = 1; nb <= Hp; nb++) {
-            const int rb = (Hp + nb - 1) / nb;  // max window rows per band
-            if ((size_t)BN_T * (2 * rb + 2) * TC * px_bytes > lds_cap) continue;
-            const long long rounds = ((long long)batch * nb + slots - 1) / slots;
-            const long long cost = rounds * (rb + 1);
-            if (best < 0 || cost < best) { best = cost; nbands = nb; RB = 2 * rb; }
+        size_t scr_bytes = (i == 0) ? (size_t)waves * 1024 : (enc_wide[i] ? (size_t)waves * 2048 : 0);
+        if (i >= 1 && ctx->enc_plan[i].nbands) {
+            // developer override (covahip_blobnet_set_enc_plan)
+            nbands = std::min(ctx->enc_plan[i].nbands, Hp);
+            nbuf = ctx->enc_plan[i].nbuf;
+            scr_bytes = (size_t)waves * 2048;
+            RB = 2 * ((Hp + nbands - 1) / nbands);
+            const size_t need = (size_t)nbuf * BN_T * (RB + 2) * TC * px_bytes + scr_bytes;
+            if (need > 160 * 1024 - 256) return COVAHIP_ERR_UNSUPPORTED;
+            wgs_per_cu = (i == BN_LEVELS - 1) ? 1 : (int)std::min<size_t>(2, (160 * 1024 - 256) / need);
+        } else {
+            const size_t lds_cap = (wgs_per_cu == 1 ? 150 * 1024 : 80 * 1024) - scr_bytes;
+            // band planner: bands of whole pool-window rows.  Workgroups are persistent (wgs_per_cu per CU)
+            // and take items round-robin, so a launch lasts ceil(items / slots) rounds of one band each;
+            // a band costs its window rows plus about one row of halo staging + barriers.  Pick the band
+            // count that fits in LDS and minimises rounds x (rows + 1).
+            const long long slots = (long long)wgs_per_cu * num_cu;
+            long long best = -1;
+            for (int nb = 1; nb <= Hp; nb++) {
+                const int rb = (Hp + nb - 1) / nb;  // max window rows per band
+                if ((size_t)BN_T * (2 * rb + 2) * TC * px_bytes > lds_cap) continue;
+                const long long rounds = ((long long)batch * nb + slots - 1) / slots;
+                const long long cost = rounds * (rb + 1);
+                if (best < 0 || cost < best) { best = cost; nbands = nb; RB = 2 * rb; }
+            }
+            if (!nbands) return COVAHIP_ERR_UNSUPPORTED;
         }
-        if (!nbands) return COVAHIP_ERR_UNSUPPORTED;
         const size_t tile_bytes = (((size_t)BN_T * (RB + 2) * TC * px_bytes) + 15) & ~(size_t)15;
-        const size_t lds = tile_bytes + scr_bytes;
+        const size_t lds = nbuf * tile_bytes + scr_bytes;
         if (lds > 160 * 1024 - 256) return COVAHIP_ERR_UNSUPPORTED;
         const int items = batch * nbands;
         const int grid = std::min(items, wgs_per_cu * num_cu);
@@ -2341,7 +2390,8 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const BnInput &in
             a.B = batch; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.Ho = m->lv[i + 1].H; a.Wo = m->lv[i + 1].W;
             a.oy = H & 1; a.ox = W & 1; a.To = (i == BN_LEVELS - 1) ? 1 : BN_T;
             a.RB = RB; a.nbands = nbands; a.TR = RB + 2; a.TC = TC;
-            a.mWp = magic(Wp); a.mNb = magic(nbands); a.mRC = magic(TC * (cin / 8)); a.zero = prep + pr->zero; a.scr_off = (int)tile_bytes;
+            a.mWp = magic(Wp); a.mNb = magic(nbands); a.mRC = magic(TC * (cin / 8)); a.zero = prep + pr->zero;
+            a.nbuf = nbuf; a.buf_stride = (int)tile_bytes; a.scr_off = (int)(nbuf * tile_bytes);
             a.plan = make_plan(grid, num_cu, wgs_per_cu, batch, nbands, Hp);
             a.swz = choose_swz(true, cin, W, Wp, RB / 2);
             a.pidx = inp.index; a.skip = act[1]; a.tm_pre = (const float *)(prep + pr->enc[0].epi) + 48;

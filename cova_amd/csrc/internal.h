@@ -43,6 +43,7 @@ struct covahip_ctx {
     void *cc_ovf = nullptr;
     size_t cc_ovf_bytes = 0;
     int cc_wave_cap = 0;
+    struct { int nbands, nbuf; } enc_plan[4] = {};   // developer override of the encoder band plan per level (0 = automatic)
     covahip_blobnet *blobnet = nullptr;
 };
 

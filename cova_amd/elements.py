@@ -156,6 +156,10 @@ class BlobNetInfer:
         L.check(self._lib.covahip_blobnet_load(ctx.handle, blob, len(blob), h_mb, w_mb, timestep, max_batch),
                 "covahip_blobnet_load", ctx.handle)
 
+    def set_enc_plan(self, level: int, nbands: int, nbuf: int = 1):
+        """Developer switch (include/covahip_dev.h): band plan of encoder level 1..3; nbands = 0 -> automatic."""
+        L.check(self._lib.covahip_blobnet_set_enc_plan(self.ctx.handle, level, nbands, nbuf), "covahip_blobnet_set_enc_plan")
+
     def set_impl(self, impl: str):
         """Developer switch (include/covahip_dev.h): encoder levels 0/1 as two kernels or as one."""
         L.check(self._lib.covahip_blobnet_set_impl(self.ctx.handle, {"mfma": 1, "mfma_fused01": 2, "frames_walk": 3}[impl]), "set_impl")

@@ -21,6 +21,12 @@ int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl);
  * overflow pass), cap < 0 = workgroup-per-frame kernel only, 0 = automatic (default). */
 int covahip_bboxcc_set_wave_cap(covahip_ctx *ctx, int cap);
 
+/* Encoder band plan of level 1..3 (tools/plan_sweep.sh): nbands bands of pool-window rows per frame, nbuf = 1 or 2 LDS
+ * buffers (2 = the next band is requested while this one is computed; measured no faster).  nbands = 0
+ * restores the automatic plan.  A plan that does not fit in LDS makes the next forward call return
+ * COVAHIP_ERR_UNSUPPORTED. */
+int covahip_blobnet_set_enc_plan(covahip_ctx *ctx, int level, int nbands, int nbuf);
+
 #ifdef __cplusplus
 }
 #endif

@@ -244,3 +244,27 @@ def test_carrier_frame_entry_rejects_bad_tables(ctx, weights_flat):
         net.filter_frames(frames, np.array([[3, 2, 1, -1]], dtype=np.int32), 1)
     boxes, counts, _, _ = net.filter_frames(frames, np.array([[5, 4, 3, 2], [5, 5, 5, 5]], dtype=np.int32), 1)
     assert counts.shape == (2,)
+
+
+@pytest.mark.parametrize("plans", [[(1, 9, 2)], [(2, 8, 2), (3, 2, 2)], [(1, 7, 1), (2, 3, 1), (3, 4, 1)]])
+def test_encoder_band_plans_give_identical_bits(ctx, weights_flat, plans):
+    """covahip_blobnet_set_enc_plan (developer header): other band counts and the double-buffered item loop (the next
+    band requested while this one is computed) change the schedule, not one bit of the result -- both entry points."""
+    h, w, b = 68, 120, 24
+    frames, index = synth.carrier_batch(b, h, w, seed=9, streams=2)
+    stack = synth.stacked_batch(b, h, w, seed=9, streams=2)
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=b)
+    ref_logits, _ = net.infer(stack)
+    ref = net.filter_frames(frames, index, 2, max_boxes=1024, want_mask=True, want_logits=True)
+    for level, nbands, nbuf in plans:
+        net.set_enc_plan(level, nbands, nbuf)
+    try:
+        logits, _ = net.infer(stack)
+        got = net.filter_frames(frames, index, 2, max_boxes=1024, want_mask=True, want_logits=True)
+    finally:
+        for level, _, _ in plans:
+            net.set_enc_plan(level, 0)
+    np.testing.assert_array_equal(logits, ref_logits)
+    np.testing.assert_array_equal(got[3], ref[3])
+    np.testing.assert_array_equal(got[2], ref[2])
+    np.testing.assert_array_equal(got[1], ref[1])

@@ -14,6 +14,9 @@ from cova_amd import _lib as L  # noqa: E402
 B, H, Wd = 256, 68, 120
 ctx = Context(0)
 net = BlobNetInfer(ctx, W.random_init(1234), H, Wd, max_batch=B)
+for spec in filter(None, os.environ.get("QB_PLAN", "").split(",")):      # level:nbands:nbuf
+    net.set_enc_plan(*[int(x) for x in spec.split(":")])
+NWG = {0: int(os.environ.get("NWG1", 512)), 16: 512, 32: 256}
 frames, index = synth.carrier_batch(B, H, Wd, seed=1, streams=8)
 d_frames = ctx.malloc(frames.nbytes)
 ctx.h2d(d_frames, frames)
@@ -35,4 +38,4 @@ for base, label in ((0, "enc1t (PRE)"), (16, "enc2"), (32, "enc3")):
     tot = v[base:base + 9].sum()
     print(f"{label}: {tot / steps / 100:.0f} us of workgroup time per launch (all workgroups)")
     for i, n in enumerate(names):
-        print(f"   {n:28s} {100 * v[base + i] / tot:5.1f} %   {v[base + i] / steps / 100 / 512:7.2f} us per workgroup (512 of them)")
+        print(f"   {n:40s} {100 * v[base + i] / tot:5.1f} %   {v[base + i] / steps / 100 / NWG[base]:7.2f} us per workgroup ({NWG[base]} of them)")

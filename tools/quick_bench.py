@@ -18,6 +18,8 @@ flat = W.random_init(1234)
 net = BlobNetInfer(ctx, flat, H, Wd, max_batch=B)
 if os.environ.get("QB_IMPL"):
     net.set_impl(os.environ["QB_IMPL"])
+for spec in filter(None, os.environ.get("QB_PLAN", "").split(",")):      # level:nbands:nbuf (covahip_blobnet_set_enc_plan)
+    net.set_enc_plan(*[int(x) for x in spec.split(":")])
 FRAMES = os.environ.get("QB_INPUT", "stack") == "frames"     # carrier-frame entry point instead of stacks
 if FRAMES:
     frames, index = synth.carrier_batch(B, H, Wd, seed=1, streams=8)
