@@ -644,6 +644,34 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PHASE_MARK(8);   // weight fragments and epilogue constants in registers
 #endif
+    // ---- PRE: temporal MLP of the level below, in place, on the 16-byte pieces THIS thread requested (the staging loop
+    // and this one walk the same piece indices): a thread needs nothing but its own vmcnt(0) before it, so the pass
+    // runs while other waves' pieces are still landing and no workgroup barrier separates it from the staging.  A lane
+    // takes one piece (8 channels of a pixel) of all four T slices; the MLP does not depend on the channel, so the
+    // swizzle is irrelevant here.  Zero padding stays zero (no bias).
+    auto mlp_own = [&](uint8_t *base, int band_, const TmixW &tmp) {
+        const int n2_ = 2 * (((band_ + 1) * p.Hp) / p.nbands) - 2 * ((band_ * p.Hp) / p.nbands) + 2;
+        const int nchunk = n2_ * TC * CPP;
+        for (int sidx = tid; sidx < nchunk; sidx += WGS) {
+            half8 v[BN_T], o[BN_T];
+#pragma unroll
+            for (int t = 0; t < BN_T; t++) v[t] = *reinterpret_cast<const half8 *>(base + t * tsz + sidx * 16);
+#pragma unroll
+            for (int j0 = 0; j0 < 8; j0 += 4) {
+                half4 pb[4];
+                f32x4 r[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) pb[j] = half4{v[0][j0 + j], v[1][j0 + j], v[2][j0 + j], v[3][j0 + j]};
+                tmix4f<4>(tmp, pb, r);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int t = 0; t < BN_T; t++) o[t][j0 + j] = (_Float16)r[j][t];
+            }
+#pragma unroll
+            for (int t = 0; t < BN_T; t++) *reinterpret_cast<half8 *>(base + t * tsz + sidx * 16) = o[t];
+        }
+    };
     // ---- stage one band with LDS-DMA: the tile is swept linearly in 16-byte chunks (64 per wave-instruction);
     // chunk -> (row, col, physical chunk) -> swizzled source chunk; halo columns / out-of-image rows read the zero
     // buffer.  The decomposition is done once per chunk position and reused for the four T slices (source + t * plane,
@@ -694,13 +722,13 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     if (more && dbl) {
         stage(it.b, it.band, smem, lane);
         wait_vmem();
+        if constexpr (PRE) mlp_own(smem, it.band, load_tmix(p.tm_pre, lane));
     }
     while (more) {
         const int b = it.b, band = it.band;
         // balanced bands of whole pool-window rows
         const int y0 = 2 * ((band * p.Hp) / p.nbands);
         const int rows = 2 * (((band + 1) * p.Hp) / p.nbands) - y0;
-        const int n2 = rows + 2;
         // opaque per-item copy of the lane id: keeps hipcc from hoisting (and, at level 3, spilling) the
         // lane-only index math out of the item loop -- see enc01_mfma
         int ll = lane;
@@ -717,6 +745,8 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
             stage(b, band, bandp, ll);
             PHASE_MARK(2);   // issuing the band's LDS-DMA
             wait_vmem();
+            if constexpr (PRE) mlp_own(bandp, band, tmp);
+            PHASE_MARK(4);   // own pieces landed, temporal MLP applied
         }
         lds_barrier();
         PHASE_MARK(3);   // the band landing / the other waves leaving the previous item
@@ -732,34 +762,13 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
             PHASE_MARK(2);
         }
         auto landed = [&]() {
-            if (in_flight) { wait_vmem(); in_flight = false; }
+            if (in_flight) {
+                wait_vmem();
+                if constexpr (PRE) mlp_own(smem + cur * p.buf_stride, it.band, tmp);   // `cur` already names the next item's buffer
+                in_flight = false;
+            }
         };
         if constexpr (PRE) {
-            // ---- temporal MLP of the level below, in place: a lane takes one 16-byte piece (8 channels of a pixel) of
-            // all four T slices; the MLP does not depend on the channel, so the swizzle is irrelevant here.  Zero
-            // padding stays zero (no bias).
-            const int nchunk = n2 * TC * CPP;
-            for (int sidx = tid; sidx < nchunk; sidx += WGS) {
-                half8 v[BN_T], o[BN_T];
-#pragma unroll
-                for (int t = 0; t < BN_T; t++) v[t] = *reinterpret_cast<const half8 *>(bandp + t * tsz + sidx * 16);
-#pragma unroll
-                for (int j0 = 0; j0 < 8; j0 += 4) {
-                    half4 pb[4];
-                    f32x4 r[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) pb[j] = half4{v[0][j0 + j], v[1][j0 + j], v[2][j0 + j], v[3][j0 + j]};
-                    tmix4f<4>(tmp, pb, r);
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-#pragma unroll
-                        for (int t = 0; t < BN_T; t++) o[t][j0 + j] = (_Float16)r[j][t];
-                }
-#pragma unroll
-                for (int t = 0; t < BN_T; t++) *reinterpret_cast<half8 *>(bandp + t * tsz + sidx * 16) = o[t];
-            }
-            lds_barrier();
-            PHASE_MARK(4);   // temporal MLP in place
             landed();
             // ---- T = 0 slice of the band's own rows -> skip tensor (the last band also owns the odd last row)
             const int ya = y0, yb = (band == p.nbands - 1) ? p.H : y0 + rows;
