@@ -46,6 +46,7 @@ struct covahip_blobnet {
     struct Prepared *prep = nullptr;
     int fuse_tail = 1;  // MFMA path, with bboxcc requested: last decoder block + bboxcc in one launch
     int fuse01 = 0;  // MFMA path: encoder levels 0 and 1 as one kernel (default off: measured slower)
+    int fuse_dec = 1;  // MFMA path: decoder blocks 0..2 as one launch (a frame's three input tiles side by side in LDS) when they fit
     int64_t macs_per_frame = 0;
 };
 

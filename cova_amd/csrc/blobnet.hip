@@ -250,9 +250,10 @@ int covahip_blobnet_set_enc_plan(covahip_ctx *ctx, int level, int nbands, int nb
 
 int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl) {
     if (!ctx || !ctx->blobnet) return COVAHIP_ERR_NOT_LOADED;
-    if (impl < 1 || impl > 3) return COVAHIP_ERR_INVALID_ARG;
+    if (impl < 1 || impl > 4) return COVAHIP_ERR_INVALID_ARG;
     ctx->blobnet->fuse01 = impl == 2;
     ctx->blobnet->frames_impl = impl == 3 ? 2 : 0;
+    ctx->blobnet->fuse_dec = impl != 4;
     ctx->blobnet->last_table.clear();   // the resident plan belongs to the other form
     return COVAHIP_OK;
 }

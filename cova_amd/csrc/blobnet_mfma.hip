@@ -1667,6 +1667,257 @@ __global__ __launch_bounds__(((FINAL ? 1 : 4 * COUT / 32) > 4 ? 4 * COUT / 32 : 
     }
 }
 
+// ------------------------------------------------------------------ decoder blocks 0..2 in one launch
+// Blocks 0..2 are three short launches of 9-12 us for ~4.5 us of MFMA work between them: each stages a band,
+// waits, runs a handful of tiles and writes an intermediate that the next launch reads back.  One frame's
+// intermediates are small (9x15x64, 17x30x32 at 1080p), so here ONE workgroup takes a frame through all three
+// blocks: the three input tiles live in LDS side by side, the skip halves (encoder outputs) of all of them are
+// requested at once, and block j's epilogue writes its BN'd, relu'd output straight into the "up" half of block
+// j+1's tile (with that tile's swizzle) instead of HBM.  Block 2's output leaves through the same 16-byte-store
+// transpose as in dec_mfma.  Same products in the same order, same epilogue expression: bit-identical to the
+// three launches (tests/test_gpu_blobnet.py).
+struct DecLvl {
+    int Hi, Wi, Hd, Wd, cy, cx;
+    uint32_t mGW, mRC;
+    Swz swz;
+    int tile_off;   // byte offset of the block's input tile [Hi+2][Wi+2][C] in LDS
+};
+struct Dec012Args {
+    const __half *skip[3];   // act[4] [B][1][..][128], act[3] [B][T][..][64], act[2] [B][T][..][32]: T index 0 is used
+    int Ts[3];
+    __half *out;             // dact[2] [B][Hd][Wd][16]
+    const half8 *wf[3];
+    const float *epi[3];
+    DecLvl lv[3];
+    int B, scr_off;
+    const void *zero;
+};
+
+// The border of a block's tile (the zero padding of the transposed convolution's input) is written once per launch:
+// nothing ever overwrites it, interior pixels are refilled for every frame (skip half by DMA, "up" half by the block
+// before).
+template <int C>
+__device__ __forceinline__ void dec012_zero_border(uint8_t *tile, const DecLvl &g, int tid) {
+    constexpr int CPP = C / 8;
+    const int RC = (g.Wi + 2) * CPP;
+    const int n_rows = 2 * RC, n_cols = 2 * CPP * g.Hi;   // top + bottom row; left + right pixel of the rows between
+    for (int i = tid; i < n_rows + n_cols; i += 512) {
+        int piece;
+        if (i < n_rows) {
+            piece = i < RC ? i : (g.Hi + 1) * RC + (i - RC);
+        } else {
+            const int j = i - n_rows, y = j / (2 * CPP), k = j % (2 * CPP);
+            piece = (y + 1) * RC + (k < CPP ? k : (g.Wi + 1) * CPP + (k - CPP));
+        }
+        *reinterpret_cast<uint4 *>(tile + piece * 16) = uint4{0, 0, 0, 0};
+    }
+}
+// requests the skip half of one block's tile, row by row: a wave takes whole rows (wave-uniform row arithmetic), its
+// lanes the row's interior 16-byte pieces, 64 per request; the lanes of "up" pieces sit the request out
+template <int C1, int C2>
+__device__ __forceinline__ void dec012_stage(uint8_t *tile, const __half *ss, const DecLvl &g, int wave, int lane, int first) {
+    constexpr int C = C1 + C2, CPP = C / 8;
+    const int RC = (g.Wi + 2) * CPP, NI = g.Wi * CPP;   // pieces per tile row / interior pieces per row
+    for (int y = (wave + 8 - first) & 7; y < g.Hi; y += 8) {
+        const int r = y + 1;
+        const __half *rowp = ss + (size_t)y * g.Wi * C2;
+        uint8_t *rowl = tile + (r * RC + CPP) * 16;   // the row's first interior piece
+        for (int q0 = 0; q0 < NI; q0 += 64) {
+            const int q = q0 + lane;
+            const int px = q / CPP, chp = q % CPP;
+            const int cb = (chp ^ swz_eval<CPP>(g.swz, px + 1, r)) * 8;
+            if (q < NI && cb >= C1) glds16(rowp + px * C2 + (cb - C1), rowl + q0 * 16);
+        }
+    }
+}
+
+// one block over the whole frame, eight waves.  CN > 0: output into the next block's tile (CN channels per pixel);
+// CN == 0: output to global memory.
+template <int C, int COUT>
+struct Dec012W {   // a wave's weight fragments and epilogue constants of one block
+    half8 wf[4 * (C / 16)];
+    float es[16], eb[16];
+};
+template <int C, int COUT>
+__device__ __forceinline__ void dec012_load(Dec012W<C, COUT> &w, const half8 *wfrag, const float *epi, int wave, int lane) {
+    constexpr int MT = 4 * COUT / 32, KSTEPS = 4 * (C / 16);
+    const int mtile = wave % MT, kh = lane >> 5;
+    // opaque pointers: the fragments are loaded here, per frame and per block -- hoisted out of the frame loop the three
+    // blocks' weights (320 registers) would be live together and spill
+    asm volatile("" : "+s"(wfrag), "+s"(epi));
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++) w.wf[ks] = wfrag[(mtile * KSTEPS + ks) * 64 + lane];
+    // registers 4g .. 4g+3 <-> rows n0 .. n0+3, n0 = mtile*32 + 8g + 4kh: four consecutive channels, one 16-byte load
+#pragma unroll
+    for (int gq = 0; gq < 4; gq++) {
+        const int c0 = (mtile * 32 + 8 * gq + 4 * kh) % COUT;
+        const float4 sc = *reinterpret_cast<const float4 *>(epi + c0), sh = *reinterpret_cast<const float4 *>(epi + COUT + c0);
+        w.es[4 * gq] = sc.x; w.es[4 * gq + 1] = sc.y; w.es[4 * gq + 2] = sc.z; w.es[4 * gq + 3] = sc.w;
+        w.eb[4 * gq] = sh.x; w.eb[4 * gq + 1] = sh.y; w.eb[4 * gq + 2] = sh.z; w.eb[4 * gq + 3] = sh.w;
+    }
+}
+template <int C1, int C2, int COUT, int CN>
+__device__ __forceinline__ void dec012_block(const uint8_t *tile, uint8_t *next_tile, __half *gout, uint8_t *scr_base,
+                                             const Dec012W<C1 + C2, COUT> &w, const DecLvl &g, const DecLvl &gn,
+                                             int wave, int lane) {
+    constexpr int C = C1 + C2, MT = 4 * COUT / 32, PG = 8 / MT;
+    constexpr int KC = C / 16, KSTEPS = 4 * KC, CPP = C / 8, PS = C * 2;
+    constexpr int AD = C == 128 ? 4 : 8;   // B fragments in flight ahead of their MFMA (ring, as in enc_mfma); what the registers allow
+    const int mtile = wave % MT, pgroup = wave / MT;
+    const int TC = g.Wi + 2, GW = g.Wi + 1, GH = g.Hi + 1;
+    const int kh = lane >> 5;
+    const half8 (&wf)[KSTEPS] = w.wf;
+    const float (&es)[16] = w.es, (&eb)[16] = w.eb;
+    const int npos = GH * GW;
+    const int ntiles = (npos + 31) / 32;
+    for (int tile_i = pgroup; tile_i < ntiles; tile_i += PG) {
+        const int q = tile_i * 32 + (lane & 31);
+        const int qc = min(q, npos - 1);
+        const int u = fdiv(qc, g.mGW), v = qc - u * GW;
+        // the four taps' tile offsets and swizzles, then the K steps in dec_mfma's order with their B fragments AD steps ahead
+        int pbase[4], sw[4];
+#pragma unroll
+        for (int tp = 0; tp < 4; tp++) {
+            const int yy = u + 1 - (tp >> 1), xx = v + 1 - (tp & 1);   // tile coordinates of input (u-a, v-b)
+            pbase[tp] = (yy * TC + xx) * PS;
+            sw[tp] = swz_eval<CPP>(g.swz, xx, yy);
+        }
+        auto frag = [&](int ks) -> half8 {
+            const int tp = ks / KC, kc = ks % KC;
+            return *reinterpret_cast<const half8 *>(tile + pbase[tp] + (((kc * 2 + kh) ^ sw[tp]) * 16));
+        };
+        half8 ring[AD];
+#pragma unroll
+        for (int ks = 0; ks < AD; ks++) ring[ks] = frag(ks);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ks++) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], ring[ks % AD], acc, 0, 0, 0);
+            if (ks + AD < KSTEPS) ring[ks % AD] = frag(ks + AD);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, AD, 0);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ks++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (ks + AD < KSTEPS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if constexpr (CN > 0) {
+            // reg 4g+j <-> row n0 + j, n0 = mtile*32 + 8g + 4kh: one parity, four consecutive channels
+            constexpr int CPPN = CN / 8, PSN = CN * 2;
+            const int TCN = gn.Wi + 2;
+            if (q < npos) {
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const int n0 = mtile * 32 + 8 * gq + 4 * kh;
+                    const int phase = n0 / COUT, co0 = n0 % COUT;
+                    const int Y = 2 * u + (phase >> 1) - g.cy, X = 2 * v + (phase & 1) - g.cx;
+                    if (Y >= 0 && Y < g.Hd && X >= 0 && X < g.Wd) {
+                        half4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            o[j] = (_Float16)fmaxf(acc[4 * gq + j] * es[4 * gq + j] + eb[4 * gq + j], 0.f);
+                        const int yy = Y + 1, xx = X + 1;
+                        *reinterpret_cast<half4 *>(next_tile + (yy * TCN + xx) * PSN +
+                                                   (((co0 >> 3) ^ swz_eval<CPPN>(gn.swz, xx, yy)) * 16) + (co0 & 7) * 2) = o;
+                    }
+                }
+            }
+        } else {
+            // 16-byte stores through a wave-private LDS transpose, as in dec_mfma
+            uint8_t *const scr = scr_base + wave * 2048;
+            const int pos = lane & 31;
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                half4 o;
+#pragma unroll
+                for (int j = 0; j < 4; j++) o[j] = (_Float16)fmaxf(acc[4 * gq + j] * es[4 * gq + j] + eb[4 * gq + j], 0.f);
+                *reinterpret_cast<half4 *>(scr + pos * 64 + ((gq ^ ((pos >> 2) & 3)) * 16) + kh * 8) = o;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int c = j * 64 + lane;
+                const int rp = c >> 2;
+                const int gq = (c & 3) ^ ((rp >> 2) & 3);
+                const int rq = tile_i * 32 + rp;
+                if (rq < npos) {
+                    const int ru = fdiv(rq, g.mGW), rv = rq - ru * GW;
+                    const int n0 = mtile * 32 + 8 * gq;
+                    const int phase = n0 / COUT, co0 = n0 % COUT;
+                    const int Y = 2 * ru + (phase >> 1) - g.cy, X = 2 * rv + (phase & 1) - g.cx;
+                    if (Y >= 0 && Y < g.Hd && X >= 0 && X < g.Wd)
+                        *reinterpret_cast<uint4 *>(gout + ((size_t)Y * g.Wd + X) * COUT + co0) =
+                            *reinterpret_cast<const uint4 *>(scr + c * 16);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void dec012_mfma(Dec012Args p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint8_t *const t0 = smem + p.lv[0].tile_off, *const t1 = smem + p.lv[1].tile_off, *const t2 = smem + p.lv[2].tile_off;
+#ifdef PHASE_TIMING
+    unsigned long long ph_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memrealtime();
+#endif
+    dec012_zero_border<128>(t0, p.lv[0], tid);
+    dec012_zero_border<128>(t1, p.lv[1], tid);
+    dec012_zero_border<64>(t2, p.lv[2], tid);
+    for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+        lds_barrier();   // the previous frame's last block has left its tile (first frame: the borders are written)
+        PHASE_MARK(0);
+        {
+            Dec012W<128, 64> w0;
+            dec012_load(w0, p.wf[0], p.epi[0], wave, lane);   // in flight together with the tiles
+            // (the rows of the three tiles start at different waves so that the requests spread evenly)
+            dec012_stage<0, 128>(t0, p.skip[0] + (size_t)b * p.Ts[0] * p.lv[0].Hi * p.lv[0].Wi * 128, p.lv[0], wave, lane, 0);
+            dec012_stage<64, 64>(t1, p.skip[1] + (size_t)b * p.Ts[1] * p.lv[1].Hi * p.lv[1].Wi * 64, p.lv[1], wave, lane, p.lv[0].Hi & 7);
+            dec012_stage<32, 32>(t2, p.skip[2] + (size_t)b * p.Ts[2] * p.lv[2].Hi * p.lv[2].Wi * 32, p.lv[2], wave, lane,
+                                 (p.lv[0].Hi + p.lv[1].Hi) & 7);
+            PHASE_MARK(1);   // requesting the three tiles (and block 0's weights)
+            wait_vmem();
+            lds_barrier();
+            PHASE_MARK(2);   // tiles landing
+            dec012_block<0, 128, 64, 128>(t0, t1, nullptr, nullptr, w0, p.lv[0], p.lv[1], wave, lane);
+        }
+        PHASE_MARK(3);       // block 0: tiles
+        {
+            Dec012W<128, 32> w1;
+            dec012_load(w1, p.wf[1], p.epi[1], wave, lane);
+            lds_barrier();   // block 0's output is in block 1's tile
+#ifdef PHASE_TIMING
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            PHASE_MARK(4);   // block 1: weights + barrier
+            dec012_block<64, 64, 32, 64>(t1, t2, nullptr, nullptr, w1, p.lv[1], p.lv[2], wave, lane);
+        }
+        PHASE_MARK(5);       // block 1: tiles
+        {
+            Dec012W<64, 16> w2;
+            dec012_load(w2, p.wf[2], p.epi[2], wave, lane);
+            lds_barrier();
+#ifdef PHASE_TIMING
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            PHASE_MARK(6);   // block 2: weights + barrier
+            dec012_block<32, 32, 16, 0>(t2, nullptr, p.out + (size_t)b * p.lv[2].Hd * p.lv[2].Wd * 16, smem + p.scr_off, w2,
+                                        p.lv[2], p.lv[2], wave, lane);
+        }
+        PHASE_MARK(7);       // block 2: tiles + stores
+    }
+#ifdef PHASE_TIMING
+    if (tid == 0)
+        for (int i = 0; i < 9; i++) atomicAdd(&g_phase[48 + i], ph_[i]);
+#endif
+}
+
 // ------------------------------------------------------------------ last decoder block + bboxcc fused
 // One 16-wave workgroup per frame: the last block runs band by band (double-buffered LDS-DMA of the
 // next band behind the tiles of the current one), its threshold output is assembled as the frame's
@@ -2434,8 +2685,40 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const BnInput &in
         }
         COVAHIP_CHECK_HIP(ctx, hipGetLastError());
     }
+    // ---------------- decoder blocks 0..2 in one launch when a frame's three input tiles fit in LDS together
+    int first_dec = 0;
+    if (m->fuse_dec && m->dec_ci[0] == 128 && m->dec_ci[1] == 128 && m->dec_ci[2] == 64 && m->dec_co[0] == 64 &&
+        m->dec_co[1] == 32 && m->dec_co[2] == 16) {
+        Dec012Args a;
+        size_t off = 0;
+        for (int j = 0; j < 3; j++) {
+            const BnLevelGeom in = m->lv[BN_LEVELS - j], out = m->lv[BN_LEVELS - 1 - j];
+            DecLvl &g = a.lv[j];
+            g.Hi = in.H; g.Wi = in.W; g.Hd = out.H; g.Wd = out.W; g.cy = m->dec_cy[j]; g.cx = m->dec_cx[j];
+            g.mGW = magic(in.W + 1);
+            g.mRC = magic((in.W + 2) * (m->dec_ci[j] / 8));
+            g.swz = choose_swz(false, m->dec_ci[j], in.W, 0, in.H + 1);
+            g.tile_off = (int)off;
+            off += (((size_t)(in.H + 2) * (in.W + 2) * m->dec_ci[j] * 2) + 15) & ~(size_t)15;
+            a.skip[j] = act[BN_LEVELS - j];
+            a.Ts[j] = j == 0 ? 1 : BN_T;
+            a.wf[j] = (const half8 *)(prep + pr->dec[j].wfrag);
+            a.epi[j] = (const float *)(prep + pr->dec[j].epi);
+        }
+        a.scr_off = (int)off;
+        const size_t lds = off + 8 * 2048;
+        if (lds <= 160 * 1024 - 256) {
+            a.out = dact[2]; a.B = batch; a.zero = prep + pr->zero;
+            int rc = set_lds(ctx, dec012_mfma, lds);
+            if (rc) return rc;
+            ProfScope ps(ctx, "dec012_mfma");
+            LAUNCH(dec012_mfma, dim3(std::min(batch, num_cu)), dim3(512), lds, ctx->stream, a);
+            COVAHIP_CHECK_HIP(ctx, hipGetLastError());
+            first_dec = 3;
+        }
+    }
     // ---------------- decoder blocks 0..3 (the last one carries the folded final conv + threshold)
-    for (int j = 0; j < BN_LEVELS; j++) {
+    for (int j = first_dec; j < BN_LEVELS; j++) {
         const BnLevelGeom in = m->lv[BN_LEVELS - j], out = m->lv[BN_LEVELS - 1 - j];
         const bool last = j == BN_LEVELS - 1;
         DecArgs a;

@@ -11,9 +11,10 @@
 extern "C" {
 #endif
 
-/* Encoder implementation of the loaded model: 1 = defaults (stacked entry: one kernel per encoder level; carrier-frame
+/* Kernel chain of the loaded model: 1 = defaults (stacked entry: one kernel per encoder level; carrier-frame
  * entry: level 0 per carrier frame + level 1 with the gather), 2 = stacked entry with levels 0 and 1 in one kernel,
- * 3 = carrier-frame entry with the time-walking level-0+1 kernel.  2 and 3 are measured slower on MI355X
+ * 3 = carrier-frame entry with the time-walking level-0+1 kernel, 4 = defaults, but decoder blocks 0..2 as three
+ * launches instead of one (the form before the fused decoder).  2, 3 and 4 are measured slower on MI355X
  * and kept for study; all forms compute identical bits (tests/test_gpu_blobnet.py). */
 int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl);
 

@@ -268,3 +268,26 @@ def test_encoder_band_plans_give_identical_bits(ctx, weights_flat, plans):
     np.testing.assert_array_equal(got[3], ref[3])
     np.testing.assert_array_equal(got[2], ref[2])
     np.testing.assert_array_equal(got[1], ref[1])
+
+
+@pytest.mark.parametrize("hw", [(68, 120), (67, 120), (45, 80), (35, 60)])
+def test_fused_decoder_blocks_match_separate_launches_bitwise(ctx, weights_flat, hw):
+    """Decoder blocks 0..2 as one launch (one workgroup per frame, intermediates in LDS) vs the three launches of
+    dec_mfma (developer switch "dec_separate"): same logits, masks and boxes, bit for bit."""
+    h, w = hw
+    b = 20
+    stack = synth.stacked_batch(b, h, w, seed=17, streams=2)
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=b)
+    logits, mask = net.infer(stack)
+    boxes, counts, _ = net.filter(stack, cc_threshold=2, max_boxes=1024)
+    net.set_impl("dec_separate")
+    try:
+        logits2, mask2 = net.infer(stack)
+        boxes2, counts2, _ = net.filter(stack, cc_threshold=2, max_boxes=1024)
+    finally:
+        net.set_impl("mfma")
+    np.testing.assert_array_equal(logits, logits2)
+    np.testing.assert_array_equal(mask, mask2)
+    np.testing.assert_array_equal(counts, counts2)
+    for i in range(b):
+        np.testing.assert_array_equal(boxes[i, :counts[i]], boxes2[i, :counts[i]])
