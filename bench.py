@@ -63,6 +63,7 @@ def kernel_macs_per_frame():
     for j in range(3):
         out[f"dec{j}_mfma"] = hs[4 - j] * ws[4 - j] * 16 * dec_ci[j] * dec_co[j]
     out["dec3_final_mfma"] = hs[1] * ws[1] * 16 * dec_ci[3] * dec_co[3] + H_MB * W_MB * 16
+    out["dec012_mfma"] = out["dec0_mfma"] + out["dec1_mfma"] + out["dec2_mfma"]      # the three blocks in one launch
     return out
 
 
@@ -79,12 +80,14 @@ def kernel_bytes_per_frame():
     for j in range(3):
         out[f"dec{j}_mfma"] = hs[4 - j] * ws[4 - j] * (dec_c1[j] + dec_c2[j]) * 2 + hs[3 - j] * ws[3 - j] * dec_co[j] * 2
     out["dec3_final_mfma"] = hs[1] * ws[1] * (dec_c1[3] + dec_c2[3]) * 2 + H_MB * W_MB
+    # one launch for blocks 0..2: the skip inputs of the three blocks in, block 2's output out (the intermediates stay in LDS)
+    out["dec012_mfma"] = sum(hs[4 - j] * ws[4 - j] * dec_c2[j] * 2 for j in range(3)) + hs[1] * ws[1] * dec_co[2] * 2
     return out
 
 
 PMC_KERNEL_KEYS = {"enc0_mfma": "enc0_mfma", "enc0p_mfma": "enc0p_mfma", "enc1t_mfma": "enc_mfma<16, 32", "enc1_mfma": "enc_mfma<16, 32", "enc2_mfma": "enc_mfma<32, 64",
                    "enc3_mfma": "enc_mfma<64, 128", "dec0_mfma": "dec_mfma<0, 128", "dec1_mfma": "dec_mfma<64, 64",
-                   "dec2_mfma": "dec_mfma<32, 32", "dec3_final_mfma": "dec_mfma<16, 16", "dec3_bboxcc_fused": "dec3cc_mfma",
+                   "dec2_mfma": "dec_mfma<32, 32", "dec012_mfma": "dec012_mfma", "dec3_final_mfma": "dec_mfma<16, 16", "dec3_bboxcc_fused": "dec3cc_mfma",
                    "bboxcc_kernel": "bboxcc_kernel"}
 
 
