@@ -65,6 +65,20 @@ __global__ __launch_bounds__(CC_THREADS) void bboxcc_kernel(const uint8_t *__res
     }
 }
 
+// ---- frames whose state does not fit in LDS (4K grids): the same block-based body with its arrays in a slab of global
+// memory per resident workgroup; persistent over the batch.  A correctness path, not a fast one.
+__global__ __launch_bounds__(CC_THREADS) void bboxcc_big_kernel(const uint8_t *__restrict__ masks, CcGeom g, uint8_t *slabs,
+                                                                 size_t slab_bytes, int batch, int area_thresh,
+                                                                 covahip_box *__restrict__ boxes, int32_t *__restrict__ counts,
+                                                                 int max_boxes) {
+    uint8_t *const slab = slabs + (size_t)blockIdx.x * slab_bytes;
+    for (int frame = blockIdx.x; frame < batch; frame += gridDim.x) {
+        bboxcc_frame(masks + (size_t)frame * g.H * g.W, slab, g, area_thresh, boxes + (size_t)frame * max_boxes, counts + frame,
+                     max_boxes, threadIdx.x);
+        __syncthreads();   // the next frame reuses the slab
+    }
+}
+
 // ---- one WAVE per frame (bboxcc_wave.h): WV_WAVES frames per workgroup, no workgroup barrier at all
 constexpr int WV_WAVES = 4;
 __global__ __launch_bounds__(WV_WAVES * 64) void bboxcc_wave_kernel(const uint8_t *__restrict__ masks, ccwave::WvGeom g, int batch,
@@ -152,7 +166,19 @@ int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, in
         }
         return COVAHIP_OK;
     }
-    if (!lds_wg) return COVAHIP_ERR_UNSUPPORTED;
+    if (!lds_wg) {
+        CcGeom gb;
+        const size_t slab = cc_plan_global(h, w, gb);
+        if (!slab) return COVAHIP_ERR_UNSUPPORTED;
+        const int grid = std::min(batch, 2 * num_cu);
+        int rc = covahip_ensure_buffer(ctx, &ctx->cc_slab, &ctx->cc_slab_bytes, slab * grid);
+        if (rc) return rc;
+        ProfScope ps(ctx, "bboxcc_big_kernel");
+        hipLaunchKernelGGL(bboxcc_big_kernel, dim3(grid), dim3(CC_THREADS), 0, ctx->stream, d_mask, gb, (uint8_t *)ctx->cc_slab, slab,
+                           batch, area_thresh, d_boxes, d_counts, max_boxes);
+        COVAHIP_CHECK_HIP(ctx, hipGetLastError());
+        return COVAHIP_OK;
+    }
     int rc = open_lds(ctx, bboxcc_kernel, lds_wg);
     if (rc) return rc;
     ProfScope ps(ctx, "bboxcc_kernel");

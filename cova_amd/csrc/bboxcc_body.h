@@ -63,6 +63,15 @@ inline size_t cc_plan(int h, int w, CcGeom &g) {
     if (lds + 64 > 160 * 1024 || g.BW > 128) return 0;
     return lds;
 }
+// The same carve-up for a frame whose state does not fit in LDS (4K grids): bytes of a slab in GLOBAL memory that
+// bboxcc_frame takes instead (generic pointers, flat atomics; slower, any height, width up to 256 blocks' worth of the
+// rowL bit rows = 128 blocks).  0: not even that (wider than 256 pixels).
+inline size_t cc_plan_global(int h, int w, CcGeom &g) {
+    const size_t fits = cc_plan(h, w, g);
+    if (fits) return fits;
+    if (g.BW > 128) return 0;
+    return (((size_t)g.wt_off + 64) + 255) & ~(size_t)255;
+}
 
 // m: the frame's H x W mask bytes (HBM or LDS); smem: this frame's LDS region of cc_plan() bytes;
 // ob: the frame's box slots; *count_out: its box count.  Called by all CC_THREADS threads.

@@ -78,6 +78,7 @@ void covahip_ctx_destroy(covahip_ctx *ctx) {
     if (ctx->stage_out) hipFree(ctx->stage_out);
     if (ctx->cc_scratch) hipFree(ctx->cc_scratch);
     if (ctx->cc_ovf) hipFree(ctx->cc_ovf);
+    if (ctx->cc_slab) hipFree(ctx->cc_slab);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     hipStreamDestroy(ctx->stream);
     delete ctx;

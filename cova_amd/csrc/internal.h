@@ -42,6 +42,8 @@ struct covahip_ctx {
     // bboxcc wave kernel: overflow list (count + frame indices) and the developer override of its run capacity
     void *cc_ovf = nullptr;
     size_t cc_ovf_bytes = 0;
+    void *cc_slab = nullptr;   // bboxcc state of frames too large for LDS (one slab per resident workgroup)
+    size_t cc_slab_bytes = 0;
     int cc_wave_cap = 0;
     struct { int nbands, nbuf; } enc_plan[4] = {};   // developer override of the encoder band plan per level (0 = automatic)
     covahip_blobnet *blobnet = nullptr;

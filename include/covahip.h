@@ -132,9 +132,9 @@ typedef struct covahip_box {
 /* mask: u8 [batch][h][w]; boxes: [batch][max_boxes]; counts: i32 [batch] = number of
  * components that pass the filter (if > max_boxes only the first max_boxes are
  * written).  mem_kind applies to mask, boxes and counts.
- * Limits (COVAHIP_ERR_UNSUPPORTED): w <= 256 and ceil(h/2)*ceil(w/2) <= about 6,400 2x2 blocks (the
- * frame's union-find lives in the LDS of one CU): 1080p (68x120) and 1440p (90x160) macroblock
- * grids fit, a 4K grid (135x240) does not.                                         */
+ * Limit (COVAHIP_ERR_UNSUPPORTED): w <= 256.  Frames of up to about 6,400 2x2 blocks (1080p = 68x120, 1440p =
+ * 90x160 macroblock grids) keep their union-find in the LDS of one CU; larger ones (a 4K grid is 135x240) run the
+ * same algorithm with that state in global memory -- same results, slower.        */
 int covahip_bboxcc(covahip_ctx *ctx, const uint8_t *mask, int batch, int h, int w, int area_thresh,
                    covahip_box *boxes, int32_t *counts, int max_boxes, int mem_kind);
 

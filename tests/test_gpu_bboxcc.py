@@ -104,3 +104,24 @@ def test_transform_ip_bincode(ctx):
     assert len(data) == 8 + 24 * 2
     assert [tuple(map(float, (b["left"], b["top"], b["width"], b["height"], b["area"]))) for b in bb] == \
         [(4.0, 2.0, 3.0, 1.0, 3.0), (8.0, 4.0, 4.0, 1.0, 4.0)]
+
+
+@pytest.mark.parametrize("hw", [(135, 240), (136, 240), (200, 250), (301, 97)])
+@pytest.mark.parametrize("density", [0.02, 0.3, 0.55])
+def test_frames_larger_than_lds(ctx, hw, density):
+    """4K-class macroblock grids (2160p = 135 x 240): the per-frame state does not fit in 160 KB of LDS, the launch takes
+    the block-based body with its arrays in a global-memory slab (bboxcc_big_kernel).  Same boxes, counts and order."""
+    masks = synth.random_masks(5, hw[0], hw[1], density, seed=hw[0] + int(density * 100))
+    _compare_one(ctx, masks, 1, None, 0)
+    _compare_one(ctx, masks, 30, 300, 0)
+    yy, xx = np.mgrid[0:hw[0], 0:hw[1]]
+    adversarial = np.stack([((yy + xx) % 2).astype(np.uint8), np.ones(hw, np.uint8), np.zeros(hw, np.uint8),
+                            ((yy % 4 < 2) & (xx % 6 < 5)).astype(np.uint8)])
+    _compare_one(ctx, adversarial, 1, None, 0)
+
+
+def test_frames_wider_than_256_pixels_are_refused(ctx):
+    from cova_amd import _lib as L
+    cc = BboxCc(ctx, cc_threshold=1, max_boxes=64)
+    with pytest.raises(L.CovahipError):
+        cc.regionprops(np.zeros((1, 300, 264), np.uint8))

@@ -291,3 +291,28 @@ def test_fused_decoder_blocks_match_separate_launches_bitwise(ctx, weights_flat,
     np.testing.assert_array_equal(counts, counts2)
     for i in range(b):
         np.testing.assert_array_equal(boxes[i, :counts[i]], boxes2[i, :counts[i]])
+
+
+def test_whole_path_on_a_4k_grid(ctx, weights_flat):
+    """2160p = 135 x 240 macroblocks: the fused decoder and the fused tail do not fit in LDS there, the launch plan falls
+    back to one kernel per block and to bboxcc with its state in global memory -- logits within the tolerance, frames
+    entry == stacked entry bit for bit, boxes == the oracle's regionprops of the mask."""
+    h, w, b = 135, 240, 2
+    stack = synth.stacked_batch(b, h, w, seed=3, streams=1)
+    frames, index = synth.carrier_batch(b, h, w, seed=3, streams=1)
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=b)
+    logits, mask = net.infer(stack)
+    ref_logits, _ = ref.blobnet_forward(weights_flat, stack, h, w)
+    _check(logits, mask, ref_logits)
+    boxes, counts, fmask = net.filter(stack, cc_threshold=2, max_boxes=8192, want_mask=True)
+    fboxes, fcounts, ffmask, flogits = net.filter_frames(frames, index, 2, max_boxes=8192, want_mask=True, want_logits=True)
+    np.testing.assert_array_equal(fmask, mask)
+    np.testing.assert_array_equal(flogits, logits)
+    np.testing.assert_array_equal(ffmask, mask)
+    np.testing.assert_array_equal(fcounts, counts)
+    rboxes, rcounts = ref.regionprops_batch(mask, 2, 8192)
+    np.testing.assert_array_equal(counts, rcounts)
+    for i in range(b):
+        for f, g in (("left", "left"), ("top", "top"), ("width", "width"), ("height", "height"), ("area_px", "area")):
+            np.testing.assert_array_equal(boxes[i, :counts[i]][f], rboxes[i, :counts[i]][g])
+            np.testing.assert_array_equal(fboxes[i, :counts[i]][f], rboxes[i, :counts[i]][g])
