@@ -139,7 +139,8 @@ int covahip_bboxcc(covahip_ctx *ctx, const uint8_t *mask, int batch, int h, int 
                    covahip_box *boxes, int32_t *counts, int max_boxes, int mem_kind);
 
 /* Fused hot path = nvinfer(BlobNet) -> maskcopy -> bboxcc for one batch: the mask
- * stays on the GPU.  logits/mask may be NULL.                                     */
+ * stays on the GPU.  logits/mask may be NULL.  bboxcc's limit applies on top of the model's: a grid wider than 256
+ * macroblocks loads (covahip_blobnet_forward works) but this call returns COVAHIP_ERR_UNSUPPORTED.   */
 int covahip_filter_forward(covahip_ctx *ctx, const uint8_t *rgba_stack, int batch, int area_thresh,
                            covahip_box *boxes, int32_t *counts, int max_boxes, float *logits,
                            uint8_t *mask, int mem_kind);
