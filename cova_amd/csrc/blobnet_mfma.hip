@@ -608,7 +608,7 @@ __global__ __launch_bounds__(WG0, 4) void enc0p_mfma(Enc0pArgs p) {
 #ifdef PHASE_TIMING
 // developer build only (tools/phase_timing.sh): wall-clock ticks (s_memrealtime, 100 MHz) per phase of the item loop,
 // summed over the workgroups' wave 0
-__device__ unsigned long long g_phase[64];
+__device__ unsigned long long g_phase[80];
 #define PHASE_MARK(i)                                                     \
     do {                                                                  \
         const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
@@ -1950,6 +1950,9 @@ __global__ __launch_bounds__(ccbody::CC_THREADS) void dec3cc_mfma(Dec3ccArgs q) 
     const int kh = lane >> 5;
     const float fbias = p.epi[0];
     uint8_t *const mfull = smem + q.mfull_off;
+#ifdef PHASE_TIMING
+    unsigned long long ph_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memrealtime();
+#endif
 
     for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
         // the weight fragments are (re)loaded per frame: their registers are free again while bboxcc runs
@@ -1979,12 +1982,16 @@ __global__ __launch_bounds__(ccbody::CC_THREADS) void dec3cc_mfma(Dec3ccArgs q) 
             }
         };
         lds_barrier();   // the previous frame's bboxcc is done with the band buffers it reuses
+        PHASE_MARK(0);
         stage(0, smem);
+        PHASE_MARK(1);   // requesting band 0 (+ weights)
         for (int band = 0; band < p.nbands; band++) {
             uint8_t *const cur = smem + (band & 1) * q.tile_bytes;
             wait_vmem();
             lds_barrier();   // this band has landed; every wave is done with the other buffer
+            PHASE_MARK(2);   // band landing
             if (band + 1 < p.nbands) stage(band + 1, smem + ((band + 1) & 1) * q.tile_bytes);
+            PHASE_MARK(3);   // requesting the next band
             const int u0 = band * GH / p.nbands, u1 = (band + 1) * GH / p.nbands;
             const int npos = (u1 - u0) * GW;
             const int ntiles = (npos + 31) / 32;
@@ -2022,7 +2029,9 @@ __global__ __launch_bounds__(ccbody::CC_THREADS) void dec3cc_mfma(Dec3ccArgs q) 
                 }
             }
         }
+        PHASE_MARK(4);   // tiles
         lds_barrier();   // the frame's mask is complete; the band buffers are free
+        PHASE_MARK(5);   // barrier
         if (p.mask) {
             uint8_t *dst = p.mask + (size_t)b * p.Hd * p.Wd;
             const int nbytes = p.Hd * p.Wd;
@@ -2033,13 +2042,19 @@ __global__ __launch_bounds__(ccbody::CC_THREADS) void dec3cc_mfma(Dec3ccArgs q) 
                 for (int i = tid; i < nbytes; i += NW * 64) dst[i] = mfull[i];
             }
         }
+        PHASE_MARK(6);   // mask out
         if constexpr (WV)
             ccwave::frame_wg<ccbody::CC_THREADS>(mfull, smem + q.cc_off, q.wg, q.area_thresh, q.boxes + (size_t)b * q.max_boxes,
                                                  q.counts + b, q.max_boxes, tid);
         else
             ccbody::bboxcc_frame(mfull, smem + q.cc_off, q.g, q.area_thresh, q.boxes + (size_t)b * q.max_boxes, q.counts + b,
                                  q.max_boxes, tid);
+        PHASE_MARK(7);   // bboxcc
     }
+#ifdef PHASE_TIMING
+    if (tid == 0)
+        for (int i = 0; i < 9; i++) atomicAdd(&g_phase[64 + i], ph_[i]);
+#endif
 }
 
 // ------------------------------------------------------------------ host-side weight preparation
@@ -2829,7 +2844,7 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const BnInput &in
 extern "C" int covahip_dev_phase_read(unsigned long long *out64, int reset) {
     if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase), sizeof(g_phase)) != hipSuccess) return 1;
     if (reset) {
-        unsigned long long z[64] = {0};
+        unsigned long long z[80] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return 1;
     }
     return 0;

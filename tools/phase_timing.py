@@ -16,7 +16,8 @@ ctx = Context(0)
 net = BlobNetInfer(ctx, W.random_init(1234), H, Wd, max_batch=B)
 for spec in filter(None, os.environ.get("QB_PLAN", "").split(",")):      # level:nbands:nbuf
     net.set_enc_plan(*[int(x) for x in spec.split(":")])
-NWG = {0: int(os.environ.get("NWG1", 512)), 16: 512, 32: 256, 48: 256}
+NWG = {0: int(os.environ.get("NWG1", 512)), 16: 512, 32: 256, 48: 256, 64: 256}
+TAIL_NAMES = ["barrier (previous frame)", "requesting band 0 + weights", "bands landing", "requesting the next band", "tiles", "barrier", "mask out", "bboxcc", "-"]
 DEC_NAMES = ["barrier (previous frame)", "requesting the three tiles + block 0 weights", "tiles landing", "block 0: tiles",
              "block 1: weights + barrier", "block 1: tiles", "block 2: weights + barrier", "block 2: tiles + stores", "-"]
 frames, index = synth.carrier_batch(B, H, Wd, seed=1, streams=8)
@@ -24,7 +25,7 @@ d_frames = ctx.malloc(frames.nbytes)
 ctx.h2d(d_frames, frames)
 d_boxes, d_counts, d_mask = ctx.malloc(B * 256 * 20), ctx.malloc(B * 4), ctx.malloc(B * H * Wd)
 lib = ctypes.CDLL(L.LIB_PATH)
-out = (ctypes.c_ulonglong * 64)()
+out = (ctypes.c_ulonglong * 80)()
 names = ["bookkeeping", "barrier (previous item)", "DMA issue", "band landing", "temporal MLP in place", "skip slice out", "tiles: matrix part", "tiles: epilogue", "weights into registers (kernel start)"]
 steps = 20
 for _ in range(3):
@@ -36,8 +37,8 @@ for _ in range(steps):
 ctx.sync()
 lib.covahip_dev_phase_read(out, 1)
 v = np.array(list(out), dtype=np.float64)
-for base, label in ((0, "enc1t (PRE)"), (16, "enc2"), (32, "enc3"), (48, "dec012")):
+for base, label in ((0, "enc1t (PRE)"), (16, "enc2"), (32, "enc3"), (48, "dec012"), (64, "dec3cc")):
     tot = v[base:base + 9].sum()
     print(f"{label}: {tot / steps / 100:.0f} us of workgroup time per launch (all workgroups)")
-    for i, n in enumerate(DEC_NAMES if base == 48 else names):
+    for i, n in enumerate(DEC_NAMES if base == 48 else TAIL_NAMES if base == 64 else names):
         print(f"   {n:40s} {100 * v[base + i] / tot:5.1f} %   {v[base + i] / steps / 100 / NWG[base]:7.2f} us per workgroup ({NWG[base]} of them)")
