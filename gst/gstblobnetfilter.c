@@ -11,6 +11,12 @@
  * a bincode Vec<Bbox> buffer with the PTS of the frame (cova-rs/gst-plugins/src/bboxcc/imp.rs:232-272).
  * Batches are filled in pinned host memory; copy-in, kernels and copy-out of consecutive batches overlap
  * (include/covahip.h, covahip_pipe_*).  The per-stream elements `blobnetinfer` / `bboxcc` stay for compatibility.
+ * Threads: the N streaming threads take their positions in the open slot with one compare-and-swap (no lock) and copy
+ * their frame in; whoever completes a batch hands the slot to the SUBMITTER thread (the HIP calls); the COLLECTOR thread
+ * waits for results in order and hands every finished batch to eight PUSHER threads (src pad i is always served by
+ * pusher i % 8, batches in order, so every pad sees its frames in order; the last share of a batch releases the slot);
+ * a TIMER thread implements batched-push-timeout.  The element mutex covers model load, batch hand-over and waiting for
+ * a free slot only.
  *
  * maskcopy keeps the reference element's name and properties (gst-plugins/gst-maskcopy/gstmaskcopy.cpp:39-46,
  * 102-125: unique-id, gpu-id, timestep; GRAY8 out).  In the reference it turns nvinfer's segmentation metadata into a
