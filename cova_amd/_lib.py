@@ -75,6 +75,8 @@ PROTOTYPES = {
     "covahip_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "covahip_ctx_destroy": (None, [_P]),
     "covahip_ctx_sync": (C.c_int, [_P]),
+    "covahip_ctx_set_lanes": (C.c_int, [_P, C.c_int]),
+    "covahip_ctx_get_lanes": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "covahip_last_hip_error": (C.c_char_p, [_P]),
     "covahip_device_info": (C.c_int, [_P, C.c_char_p, _SZ, C.POINTER(C.c_int), C.POINTER(_SZ)]),
     "covahip_malloc": (C.c_int, [_P, _SZ, C.POINTER(_P)]),

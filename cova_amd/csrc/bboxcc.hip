@@ -120,6 +120,7 @@ int open_lds(covahip_ctx *ctx, K kernel, size_t lds) {
 int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, int h, int w, int area_thresh,
                           covahip_box *d_boxes, int32_t *d_counts, int max_boxes) {
     if (batch == 0) return COVAHIP_OK;
+    CtxLane &ln = ctx->lane();             // scratch of the lane this call runs on (lane 0 on the primary stream)
     CcGeom g;
     const size_t lds = cc_plan(h, w, g);   // shapes the kernel assumes, checked on the host before any launch
     const int num_cu = ctx->props.multiProcessorCount;
@@ -142,11 +143,11 @@ int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, in
         (size_t)WV_WAVES * wg.wave_bytes <= 160 * 1024 - 64 && (cap >= nb || lds_wg)) {
         const bool can_overflow = cap < nb;
         if (can_overflow) {
-            int rc = covahip_ensure_buffer(ctx, &ctx->cc_ovf, &ctx->cc_ovf_bytes, ((size_t)batch + 1) * sizeof(int32_t));
+            int rc = covahip_ensure_buffer(ctx, &ln.cc_ovf, &ln.cc_ovf_bytes, ((size_t)batch + 1) * sizeof(int32_t));
             if (rc) return rc;
-            COVAHIP_CHECK_HIP(ctx, hipMemsetAsync(ctx->cc_ovf, 0, sizeof(int32_t), ctx->stream));
+            COVAHIP_CHECK_HIP(ctx, hipMemsetAsync(ln.cc_ovf, 0, sizeof(int32_t), ctx->stream));
         }
-        int32_t *ovf_n = (int32_t *)ctx->cc_ovf, *ovf_list = ovf_n ? ovf_n + 1 : nullptr;
+        int32_t *ovf_n = (int32_t *)ln.cc_ovf, *ovf_list = ovf_n ? ovf_n + 1 : nullptr;
         const size_t wlds = (size_t)WV_WAVES * wg.wave_bytes;
         int rc = open_lds(ctx, bboxcc_wave_kernel, wlds);
         if (rc) return rc;
@@ -171,10 +172,10 @@ int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, in
         const size_t slab = cc_plan_global(h, w, gb);
         if (!slab) return COVAHIP_ERR_UNSUPPORTED;
         const int grid = std::min(batch, 2 * num_cu);
-        int rc = covahip_ensure_buffer(ctx, &ctx->cc_slab, &ctx->cc_slab_bytes, slab * grid);
+        int rc = covahip_ensure_buffer(ctx, &ln.cc_slab, &ln.cc_slab_bytes, slab * grid);
         if (rc) return rc;
         ProfScope ps(ctx, "bboxcc_big_kernel");
-        hipLaunchKernelGGL(bboxcc_big_kernel, dim3(grid), dim3(CC_THREADS), 0, ctx->stream, d_mask, gb, (uint8_t *)ctx->cc_slab, slab,
+        hipLaunchKernelGGL(bboxcc_big_kernel, dim3(grid), dim3(CC_THREADS), 0, ctx->stream, d_mask, gb, (uint8_t *)ln.cc_slab, slab,
                            batch, area_thresh, d_boxes, d_counts, max_boxes);
         COVAHIP_CHECK_HIP(ctx, hipGetLastError());
         return COVAHIP_OK;
@@ -200,6 +201,7 @@ extern "C" int covahip_bboxcc(covahip_ctx *ctx, const uint8_t *mask, int batch, 
     if (batch == 0) return COVAHIP_OK;
     if (!mask || !counts || (!boxes && max_boxes > 0)) return COVAHIP_ERR_INVALID_ARG;
     COVAHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    if (int prc = covahip_primary_op(ctx)) return prc;   // stand-alone bboxcc runs on the primary stream
     if (mem_kind == COVAHIP_MEM_DEVICE)
         return covahip_bboxcc_launch(ctx, mask, batch, h, w, area_thresh, boxes, counts, max_boxes);
     if (mem_kind != COVAHIP_MEM_HOST) return COVAHIP_ERR_INVALID_ARG;

@@ -18,13 +18,10 @@ struct WalkGeom {   // plan of the time-walking level-0+1 kernel of the carrier-
     size_t lds = 0;
 };
 
-struct covahip_blobnet {
-    int H = 0, W = 0, max_batch = 0;
-    BnLevelGeom lv[BN_LEVELS + 1];
-    int enc_c[BN_LEVELS + 1] = {3, 16, 32, 64, 128};
-    int dec_ci[BN_LEVELS] = {128, 128, 64, 32};
-    int dec_co[BN_LEVELS] = {64, 32, 16, 16};
-    int dec_cy[BN_LEVELS], dec_cx[BN_LEVELS];  // crop offsets (top/left) per decoder block
+// HBM workspace of one lane (internal.h, CtxLane): everything a forward in flight writes.  Lane 0's also serves the calls
+// that run on the ctx's primary stream.
+struct BnWorkspace {
+    bool ready = false;
     // activations (fp16, channels-last)
     __half *act[BN_LEVELS + 1] = {};  // act[i], i=1..3: [B][T][H_i][W_i][C_i]; act[4]: [B][H_4][W_4][128] (t=0)
     __half *dact[BN_LEVELS] = {};     // dact[j], j=0..2: [B][Hd][Wd][Cout_j]
@@ -39,6 +36,16 @@ struct covahip_blobnet {
     std::vector<int32_t> last_table;  // the table the resident plan was made from (an unchanged table is not re-planned)
     int last_n_frames = 0, last_n_items = 0;
     WalkGeom last_walk;
+};
+
+struct covahip_blobnet {
+    int H = 0, W = 0, max_batch = 0;
+    BnLevelGeom lv[BN_LEVELS + 1];
+    int enc_c[BN_LEVELS + 1] = {3, 16, 32, 64, 128};
+    int dec_ci[BN_LEVELS] = {128, 128, 64, 32};
+    int dec_co[BN_LEVELS] = {64, 32, 16, 16};
+    int dec_cy[BN_LEVELS], dec_cx[BN_LEVELS];  // crop offsets (top/left) per decoder block
+    BnWorkspace ws[COVAHIP_MAX_LANES];
     int frames_impl = 0;              // developer switch: 0 = two kernels (default), 2 = time-walking level-0+1 kernel
     // prepared (MFMA path) weights
     void *d_prepared = nullptr;
@@ -76,5 +83,5 @@ struct BnInput {
 };
 bool blobnet_plan_walk(const covahip_blobnet *m, int num_cu, const int32_t *idx, int batch, std::vector<int32_t> &order,
                        std::vector<int32_t> &items, WalkGeom &g);
-int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const BnInput &in, int batch, float *d_logits,
+int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, const BnInput &in, int batch, float *d_logits,
                          uint8_t *d_mask, const BnCcTail *cc = nullptr, bool *cc_done = nullptr);

@@ -22,21 +22,23 @@ constexpr size_t N_PARAMS = 320305;
 static void free_model(covahip_ctx *ctx, covahip_blobnet *m) {
     if (!m) return;
     blobnet_release_mfma(ctx, m);
-    for (int i = 0; i <= BN_LEVELS; i++)
-        if (m->act[i]) hipFree(m->act[i]);
-    for (int j = 0; j < BN_LEVELS; j++)
-        if (m->dact[j]) hipFree(m->dact[j]);
-    if (m->pbuf) hipFree(m->pbuf);
-    if (m->d_index) hipFree(m->d_index);
-    if (m->h_index) hipHostFree(m->h_index);
-    if (m->ev_index) hipEventDestroy(m->ev_index);
+    for (BnWorkspace &ws : m->ws) {
+        for (int i = 0; i <= BN_LEVELS; i++)
+            if (ws.act[i]) hipFree(ws.act[i]);
+        for (int j = 0; j < BN_LEVELS; j++)
+            if (ws.dact[j]) hipFree(ws.dact[j]);
+        if (ws.pbuf) hipFree(ws.pbuf);
+        if (ws.d_index) hipFree(ws.d_index);
+        if (ws.h_index) hipHostFree(ws.h_index);
+        if (ws.ev_index) hipEventDestroy(ws.ev_index);
+    }
     delete m;
 }
 
 void covahip_blobnet_destroy(covahip_ctx *ctx) {
     if (!ctx->blobnet) return;
     hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    covahip_sync_all(ctx);
     free_model(ctx, ctx->blobnet);
     ctx->blobnet = nullptr;
 }
@@ -57,7 +59,7 @@ static int filter_dev(covahip_ctx *ctx, const BnInput &in, int batch, float *d_l
     if (batch == 0) return COVAHIP_OK;
     BnCcTail tail{area_thresh, max_boxes, d_boxes, d_counts};
     bool cc_done = false;
-    int rc = blobnet_forward_mfma(ctx, m, in, batch, d_logits, d_mask, with_cc ? &tail : nullptr, &cc_done);
+    int rc = blobnet_forward_mfma(ctx, m, m->ws[ctx->cur_lane], in, batch, d_logits, d_mask, with_cc ? &tail : nullptr, &cc_done);
     if (rc) return rc;
     // the fused decoder tail normally runs bboxcc itself; the separate kernel is the fallback for
     // geometries whose frame does not fit its LDS plan
@@ -69,7 +71,7 @@ static int filter_dev(covahip_ctx *ctx, const BnInput &in, int batch, float *d_l
 // Carrier-frame input: validates the stack -> frame table on the host (an index outside the frame array would be an
 // out-of-bounds read on the GPU), plans the time walk (chains of stacks that shift by one frame), uploads table and
 // plan.  stack_index == nullptr: one stream in order.  A table equal to the previous call's is not planned again.
-static int prepare_frames(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_frames, int n_frames,
+static int prepare_frames(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, const uint8_t *d_frames, int n_frames,
                           const int32_t *stack_index, int batch, BnInput &in) {
     if (n_frames < BN_T || n_frames > BN_T * m->max_batch) return COVAHIP_ERR_INVALID_ARG;
     if (!stack_index && batch != n_frames - (BN_T - 1)) return COVAHIP_ERR_INVALID_ARG;
@@ -80,7 +82,7 @@ static int prepare_frames(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d
             if (f < 0 || f >= n_frames) return COVAHIP_ERR_INVALID_ARG;
             table[(size_t)b * BN_T + t] = f;
         }
-    const bool same = m->d_index && table == m->last_table && n_frames == m->last_n_frames;
+    const bool same = ws.d_index && table == ws.last_table && n_frames == ws.last_n_frames;
     if (!same) {
         std::vector<int32_t> order, items;
         WalkGeom g;
@@ -88,55 +90,55 @@ static int prepare_frames(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d
                           blobnet_plan_walk(m, ctx->props.multiProcessorCount, table.data(), batch, order, items, g);
         if (!walk) { order.clear(); items.clear(); }
         const size_t need = table.size() + order.size() + items.size();
-        if (m->d_index) COVAHIP_CHECK_HIP(ctx, hipEventSynchronize(m->ev_index));
-        if (need > m->index_ints) {
-            if (m->d_index) {
+        if (ws.d_index) COVAHIP_CHECK_HIP(ctx, hipEventSynchronize(ws.ev_index));
+        if (need > ws.index_ints) {
+            if (ws.d_index) {
                 COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                hipFree(m->d_index);
-                hipHostFree(m->h_index);
-                m->d_index = nullptr; m->h_index = nullptr; m->index_ints = 0;
-                m->last_table.clear();
+                hipFree(ws.d_index);
+                hipHostFree(ws.h_index);
+                ws.d_index = nullptr; ws.h_index = nullptr; ws.index_ints = 0;
+                ws.last_table.clear();
             }
             const size_t cap = std::max(need, (size_t)m->max_batch * 16);
-            COVAHIP_CHECK_HIP(ctx, hipMalloc((void **)&m->d_index, cap * sizeof(int32_t)));
-            COVAHIP_CHECK_HIP(ctx, hipHostMalloc((void **)&m->h_index, cap * sizeof(int32_t), hipHostMallocDefault));
-            m->index_ints = cap;
-            if (!m->ev_index) COVAHIP_CHECK_HIP(ctx, hipEventCreateWithFlags(&m->ev_index, hipEventDisableTiming));
+            COVAHIP_CHECK_HIP(ctx, hipMalloc((void **)&ws.d_index, cap * sizeof(int32_t)));
+            COVAHIP_CHECK_HIP(ctx, hipHostMalloc((void **)&ws.h_index, cap * sizeof(int32_t), hipHostMallocDefault));
+            ws.index_ints = cap;
+            if (!ws.ev_index) COVAHIP_CHECK_HIP(ctx, hipEventCreateWithFlags(&ws.ev_index, hipEventDisableTiming));
         }
-        std::copy(table.begin(), table.end(), m->h_index);
-        std::copy(order.begin(), order.end(), m->h_index + table.size());
-        std::copy(items.begin(), items.end(), m->h_index + table.size() + order.size());
-        COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(m->d_index, m->h_index, need * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-        COVAHIP_CHECK_HIP(ctx, hipEventRecord(m->ev_index, ctx->stream));
-        m->last_table = std::move(table);
-        m->last_n_frames = n_frames;
-        m->last_n_items = (int)(items.size() / 4);
-        m->last_walk = g;
+        std::copy(table.begin(), table.end(), ws.h_index);
+        std::copy(order.begin(), order.end(), ws.h_index + table.size());
+        std::copy(items.begin(), items.end(), ws.h_index + table.size() + order.size());
+        COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(ws.d_index, ws.h_index, need * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        COVAHIP_CHECK_HIP(ctx, hipEventRecord(ws.ev_index, ctx->stream));
+        ws.last_table = std::move(table);
+        ws.last_n_frames = n_frames;
+        ws.last_n_items = (int)(items.size() / 4);
+        ws.last_walk = g;
     }
     in.frames = d_frames;
     in.n_frames = n_frames;
-    in.index = m->d_index;
-    if (m->last_n_items > 0) {
-        in.order = m->d_index + (size_t)batch * BN_T;
+    in.index = ws.d_index;
+    if (ws.last_n_items > 0) {
+        in.order = ws.d_index + (size_t)batch * BN_T;
         in.items = in.order + batch;
-        in.n_items = m->last_n_items;
-        in.walk = m->last_walk;
+        in.n_items = ws.last_n_items;
+        in.walk = ws.last_walk;
         return COVAHIP_OK;
     }
     // two-kernel form: the tensor P of pooled level-0 values, one slice per carrier frame
-    if (m->pbuf_frames < (size_t)n_frames) {
+    if (ws.pbuf_frames < (size_t)n_frames) {
         // grown in whole steps; the pad row / column of P (odd grids) is zeroed here and never written
-        const size_t want = std::min((size_t)BN_T * m->max_batch, std::max((size_t)n_frames, 2 * m->pbuf_frames));
+        const size_t want = std::min((size_t)BN_T * m->max_batch, std::max((size_t)n_frames, 2 * ws.pbuf_frames));
         const size_t bytes = want * m->lv[1].H * m->lv[1].W * m->enc_c[1] * sizeof(__half);
-        if (m->pbuf) {
+        if (ws.pbuf) {
             COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            COVAHIP_CHECK_HIP(ctx, hipFree(m->pbuf));
-            m->pbuf = nullptr;
-            m->pbuf_frames = 0;
+            COVAHIP_CHECK_HIP(ctx, hipFree(ws.pbuf));
+            ws.pbuf = nullptr;
+            ws.pbuf_frames = 0;
         }
-        COVAHIP_CHECK_HIP(ctx, hipMalloc((void **)&m->pbuf, bytes));
-        COVAHIP_CHECK_HIP(ctx, hipMemsetAsync(m->pbuf, 0, bytes, ctx->stream));
-        m->pbuf_frames = want;
+        COVAHIP_CHECK_HIP(ctx, hipMalloc((void **)&ws.pbuf, bytes));
+        COVAHIP_CHECK_HIP(ctx, hipMemsetAsync(ws.pbuf, 0, bytes, ctx->stream));
+        ws.pbuf_frames = want;
     }
     return COVAHIP_OK;
 }
@@ -146,6 +148,36 @@ int covahip_blobnet_forward_dev(covahip_ctx *ctx, const uint8_t *d_stack, int ba
     BnInput in;
     in.stack = d_stack;
     return filter_dev(ctx, in, batch, d_logits, d_mask, false, 0, nullptr, nullptr, 0);
+}
+
+// HBM workspace of one lane: activations stay resident; pad rows/columns are zeroed once here and never written
+// afterwards.  (The memsets go to the stream of the caller's choice: ctx->stream.)
+static int alloc_workspace(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws) {
+    if (ws.ready) return COVAHIP_OK;
+    for (int i = 1; i <= BN_LEVELS; i++) {
+        const size_t tt = (i == BN_LEVELS) ? 1 : BN_T;
+        const size_t n = (size_t)m->max_batch * tt * m->lv[i].H * m->lv[i].W * m->enc_c[i];
+        COVAHIP_CHECK_HIP(ctx, hipMalloc((void **)&ws.act[i], n * sizeof(__half)));
+        COVAHIP_CHECK_HIP(ctx, hipMemsetAsync(ws.act[i], 0, n * sizeof(__half), ctx->stream));
+    }
+    for (int j = 0; j < BN_LEVELS - 1; j++) {
+        const BnLevelGeom out = m->lv[BN_LEVELS - 1 - j];
+        const size_t n = (size_t)m->max_batch * out.H * out.W * m->dec_co[j];
+        COVAHIP_CHECK_HIP(ctx, hipMalloc((void **)&ws.dact[j], n * sizeof(__half)));
+    }
+    ws.ready = true;
+    return COVAHIP_OK;
+}
+
+int covahip_blobnet_grow_lanes(covahip_ctx *ctx, int n_lanes) {
+    covahip_blobnet *m = ctx->blobnet;
+    if (!m) return COVAHIP_OK;
+    for (int k = 0; k < n_lanes && k < COVAHIP_MAX_LANES; k++) {
+        const int rc = alloc_workspace(ctx, m, m->ws[k]);
+        if (rc) return rc;
+    }
+    COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return COVAHIP_OK;
 }
 
 // Geometry, HBM workspace and prepared weights of a model.  Every limit of the kernels is checked here (a
@@ -176,18 +208,9 @@ static int build_model(covahip_ctx *ctx, covahip_blobnet *m, const float *h_w, i
     macs += (int64_t)h_mb * w_mb * 16;
     m->macs_per_frame = macs;
 
-    // HBM workspace: activations stay resident; pad rows/columns are zeroed once here and
-    // never written afterwards.
-    for (int i = 1; i <= BN_LEVELS; i++) {
-        const size_t tt = (i == BN_LEVELS) ? 1 : BN_T;
-        const size_t n = (size_t)max_batch * tt * m->lv[i].H * m->lv[i].W * m->enc_c[i];
-        COVAHIP_CHECK_HIP(ctx, hipMalloc((void **)&m->act[i], n * sizeof(__half)));
-        COVAHIP_CHECK_HIP(ctx, hipMemsetAsync(m->act[i], 0, n * sizeof(__half), ctx->stream));
-    }
-    for (int j = 0; j < BN_LEVELS - 1; j++) {
-        const BnLevelGeom out = m->lv[BN_LEVELS - 1 - j];
-        const size_t n = (size_t)max_batch * out.H * out.W * m->dec_co[j];
-        COVAHIP_CHECK_HIP(ctx, hipMalloc((void **)&m->dact[j], n * sizeof(__half)));
+    for (int k = 0; k < ctx->n_lanes; k++) {
+        const int rc = alloc_workspace(ctx, m, m->ws[k]);
+        if (rc) return rc;
     }
     int rc = blobnet_prepare_mfma(ctx, m, h_w);
     if (rc) return rc;
@@ -196,7 +219,7 @@ static int build_model(covahip_ctx *ctx, covahip_blobnet *m, const float *h_w, i
     for (int pass = 0; pass < 4 && !rc; pass++) {
         const int b = (pass & 1) ? max_batch : 1;
         plan.n_frames = (pass & 2) ? b + BN_T - 1 : 0;   // the two-kernel form of the carrier-frame path must always fit
-        rc = blobnet_forward_mfma(ctx, m, plan, b, nullptr, nullptr, nullptr, nullptr);
+        rc = blobnet_forward_mfma(ctx, m, m->ws[0], plan, b, nullptr, nullptr, nullptr, nullptr);
     }
     return rc;
 }
@@ -254,8 +277,28 @@ int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl) {
     ctx->blobnet->fuse01 = impl == 2;
     ctx->blobnet->frames_impl = impl == 3 ? 2 : 0;
     ctx->blobnet->fuse_dec = impl != 4;
-    ctx->blobnet->last_table.clear();   // the resident plan belongs to the other form
+    for (BnWorkspace &ws : ctx->blobnet->ws) ws.last_table.clear();   // the resident plans belong to the other form
     return COVAHIP_OK;
+}
+
+// The hot path on device pointers, on ctx->stream with the current lane's workspace (the caller has placed the call).
+static int filter_placed(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_src, int n_frames, const int32_t *stack_index,
+                         int batch, int area_thresh, covahip_box *d_boxes, int32_t *d_counts, int max_boxes, float *d_logits,
+                         uint8_t *d_mask) {
+    if (!d_mask) {
+        CtxLane &l = ctx->lane();
+        int rc = covahip_ensure_buffer(ctx, &l.cc_scratch, &l.cc_scratch_bytes, (size_t)batch * m->H * m->W);
+        if (rc) return rc;
+        d_mask = (uint8_t *)l.cc_scratch;
+    }
+    BnInput in;
+    if (n_frames > 0) {
+        int rc = prepare_frames(ctx, m, m->ws[ctx->cur_lane], d_src, n_frames, stack_index, batch, in);
+        if (rc) return rc;
+    } else {
+        in.stack = d_src;
+    }
+    return filter_dev(ctx, in, batch, d_logits, d_mask, true, area_thresh, d_boxes, d_counts, max_boxes);
 }
 
 // Shared body of covahip_filter_forward / covahip_filter_forward_frames: `src` is the stacked tensor (n_frames == 0)
@@ -279,38 +322,29 @@ static int filter_any(covahip_ctx *ctx, const uint8_t *src, int n_frames, const 
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     if (mem_kind != COVAHIP_MEM_DEVICE && mem_kind != COVAHIP_MEM_HOST) return COVAHIP_ERR_INVALID_ARG;
 
+    // device pointers: the call goes to the next lane (internal.h, CtxLane) and overlaps the calls before it; host pointers:
+    // synchronous, on the primary stream, behind everything in flight
+    if (mem_kind == COVAHIP_MEM_DEVICE) {
+        LaneScope lane(ctx);
+        if (!lane.ok()) return COVAHIP_ERR_HIP;
+        return filter_placed(ctx, m, src, n_frames, stack_index, batch, area_thresh, boxes, counts, max_boxes, logits, mask);
+    }
+    if (int rc = covahip_primary_op(ctx)) return rc;
     const uint8_t *d_src = src;
-    uint8_t *d_mask = mask;
-    float *d_logits = logits;
-    covahip_box *d_boxes = boxes;
-    int32_t *d_counts = counts;
-    if (mem_kind == COVAHIP_MEM_HOST) {
-        int rc = covahip_ensure_buffer(ctx, &ctx->stage_in, &ctx->stage_in_bytes, in_bytes);
-        if (rc) return rc;
-        rc = covahip_ensure_buffer(ctx, &ctx->stage_out, &ctx->stage_out_bytes,
-                                   al(mask_bytes) + al(logit_bytes) + al(box_bytes) + al(cnt_bytes));
-        if (rc) return rc;
-        uint8_t *base = (uint8_t *)ctx->stage_out;
-        d_mask = base;
-        d_logits = logits ? (float *)(base + al(mask_bytes)) : nullptr;
-        d_boxes = (covahip_box *)(base + al(mask_bytes) + al(logit_bytes));
-        d_counts = (int32_t *)(base + al(mask_bytes) + al(logit_bytes) + al(box_bytes));
-        COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(ctx->stage_in, src, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-        d_src = (const uint8_t *)ctx->stage_in;
-    } else if (!d_mask) {
-        int rc = covahip_ensure_buffer(ctx, &ctx->cc_scratch, &ctx->cc_scratch_bytes, mask_bytes);
-        if (rc) return rc;
-        d_mask = (uint8_t *)ctx->cc_scratch;
-    }
-    BnInput in;
-    if (by_frames) {
-        int rc = prepare_frames(ctx, m, d_src, n_frames, stack_index, batch, in);
-        if (rc) return rc;
-    } else {
-        in.stack = d_src;
-    }
-    int rc = filter_dev(ctx, in, batch, d_logits, d_mask, true, area_thresh, d_boxes, d_counts, max_boxes);
-    if (rc || mem_kind == COVAHIP_MEM_DEVICE) return rc;
+    int rc = covahip_ensure_buffer(ctx, &ctx->stage_in, &ctx->stage_in_bytes, in_bytes);
+    if (rc) return rc;
+    rc = covahip_ensure_buffer(ctx, &ctx->stage_out, &ctx->stage_out_bytes,
+                               al(mask_bytes) + al(logit_bytes) + al(box_bytes) + al(cnt_bytes));
+    if (rc) return rc;
+    uint8_t *base = (uint8_t *)ctx->stage_out;
+    uint8_t *d_mask = base;
+    float *d_logits = logits ? (float *)(base + al(mask_bytes)) : nullptr;
+    covahip_box *d_boxes = (covahip_box *)(base + al(mask_bytes) + al(logit_bytes));
+    int32_t *d_counts = (int32_t *)(base + al(mask_bytes) + al(logit_bytes) + al(box_bytes));
+    COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(ctx->stage_in, src, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    d_src = (const uint8_t *)ctx->stage_in;
+    rc = filter_placed(ctx, m, d_src, n_frames, stack_index, batch, area_thresh, d_boxes, d_counts, max_boxes, d_logits, d_mask);
+    if (rc) return rc;
     if (logits) COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(logits, d_logits, logit_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (mask) COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(mask, d_mask, mask_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (box_bytes) COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(boxes, d_boxes, box_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -340,6 +374,7 @@ int covahip_blobnet_forward(covahip_ctx *ctx, const uint8_t *rgba_stack, int bat
     if (batch == 0) return COVAHIP_OK;
     if (!rgba_stack || batch > m->max_batch) return COVAHIP_ERR_INVALID_ARG;
     COVAHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    if (int prc = covahip_primary_op(ctx)) return prc;   // BlobNet alone runs on the primary stream (lane 0's workspace)
     if (mem_kind == COVAHIP_MEM_DEVICE) return covahip_blobnet_forward_dev(ctx, rgba_stack, batch, logits, mask);
     if (mem_kind != COVAHIP_MEM_HOST) return COVAHIP_ERR_INVALID_ARG;
     const size_t hw = (size_t)m->H * m->W;

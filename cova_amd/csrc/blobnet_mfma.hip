@@ -2467,14 +2467,14 @@ void blobnet_release_mfma(covahip_ctx *, covahip_blobnet *m) {
     m->prep = nullptr;
 }
 
-int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const BnInput &inp, int batch, float *d_logits,
+int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, const BnInput &inp, int batch, float *d_logits,
                          uint8_t *d_mask, const BnCcTail *cc, bool *cc_done) {
     if (cc_done) *cc_done = false;
     const bool dry = inp.dry;              // planning only: every check below runs, no kernel is launched
     const uint8_t *d_stack = inp.stack;
     const bool by_frames = inp.frames != nullptr || (dry && inp.n_frames > 0);
-    __half *const *act = m->act;
-    __half *const *dact = m->dact;
+    __half *const *act = ws.act;
+    __half *const *dact = ws.dact;
     const uint8_t *prep = (const uint8_t *)m->d_prepared;
     const Prepared *pr = m->prep;
     const int num_cu = ctx->props.multiProcessorCount;
@@ -2529,7 +2529,7 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const BnInput &in
         const int rbmax = (Hp + nbands - 1) / nbands;
         const size_t tile_bytes = (((size_t)(2 * rbmax + 2) * TC * 8) + 15) & ~(size_t)15;
         Enc0pArgs a;
-        a.in = inp.frames; a.out = m->pbuf;
+        a.in = inp.frames; a.out = ws.pbuf;
         a.wfrag = (const half8 *)(prep + pr->enc[0].wfrag); a.epi = (const float *)(prep + pr->enc[0].epi);
         a.F = inp.n_frames; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.Ho = m->lv[1].H; a.Wo = m->lv[1].W;
         a.oy = H & 1; a.ox = W & 1; a.nbands = nbands; a.TC = TC;
@@ -2672,7 +2672,7 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, const BnInput &in
             a.pidx = inp.index; a.skip = act[1]; a.tm_pre = (const float *)(prep + pr->enc[0].epi) + 48;
             int rc = COVAHIP_OK;
             if (i == 1 && by_frames) {
-                a.in = m->pbuf;
+                a.in = ws.pbuf;
                 rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true, true, true>, lds) : set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true, false, true>, lds);
                 if (rc) return rc;
                 ProfScope ps(ctx, "enc1t_mfma");

@@ -45,8 +45,17 @@ int covahip_ctx_create(int device_id, covahip_ctx **out) {
     covahip_ctx *ctx = new covahip_ctx();
     ctx->device = device_id;
     if (hipGetDeviceProperties(&ctx->props, device_id) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamCreateWithFlags(&ctx->primary, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
+        return COVAHIP_ERR_NO_DEVICE;
+    }
+    ctx->stream = ctx->primary;
+    bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < COVAHIP_MAX_LANES && ok; k++)
+        ok = hipStreamCreateWithFlags(&ctx->lanes[k].stream, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&ctx->lanes[k].done, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        covahip_ctx_destroy(ctx);
         return COVAHIP_ERR_NO_DEVICE;
     }
     for (int i = 0; i < 16; i++) {
@@ -60,11 +69,11 @@ int covahip_ctx_create(int device_id, covahip_ctx **out) {
 void covahip_ctx_destroy(covahip_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    covahip_sync_all(ctx);
     covahip_blobnet_destroy(ctx);
     for (int i = 0; i < 16; i++) {
-        hipEventDestroy(ctx->t_start[i]);
-        hipEventDestroy(ctx->t_stop[i]);
+        if (ctx->t_start[i]) hipEventDestroy(ctx->t_start[i]);
+        if (ctx->t_stop[i]) hipEventDestroy(ctx->t_stop[i]);
     }
     for (auto &p : ctx->prof_pending) {
         hipEventDestroy(p.a);
@@ -76,17 +85,41 @@ void covahip_ctx_destroy(covahip_ctx *ctx) {
     }
     if (ctx->stage_in) hipFree(ctx->stage_in);
     if (ctx->stage_out) hipFree(ctx->stage_out);
-    if (ctx->cc_scratch) hipFree(ctx->cc_scratch);
-    if (ctx->cc_ovf) hipFree(ctx->cc_ovf);
-    if (ctx->cc_slab) hipFree(ctx->cc_slab);
+    for (CtxLane &l : ctx->lanes) {
+        if (l.cc_scratch) hipFree(l.cc_scratch);
+        if (l.cc_ovf) hipFree(l.cc_ovf);
+        if (l.cc_slab) hipFree(l.cc_slab);
+        if (l.done) hipEventDestroy(l.done);
+        if (l.stream) hipStreamDestroy(l.stream);
+    }
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->pinned) hipHostFree(ctx->pinned);
-    hipStreamDestroy(ctx->stream);
+    if (ctx->primary) hipStreamDestroy(ctx->primary);
     delete ctx;
 }
 
 int covahip_ctx_sync(covahip_ctx *ctx) {
     if (!ctx) return COVAHIP_ERR_INVALID_ARG;
-    COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return covahip_sync_all(ctx);
+}
+
+int covahip_ctx_set_lanes(covahip_ctx *ctx, int n_lanes) {
+    if (!ctx || n_lanes < 1 || n_lanes > COVAHIP_MAX_LANES || ctx->in_lane) return COVAHIP_ERR_INVALID_ARG;
+    COVAHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = covahip_sync_all(ctx);
+    if (rc) return rc;
+    if (ctx->blobnet && n_lanes > ctx->n_lanes) {
+        rc = covahip_blobnet_grow_lanes(ctx, n_lanes);
+        if (rc) return rc;
+    }
+    ctx->n_lanes = n_lanes;
+    ctx->next_lane = 0;
+    return COVAHIP_OK;
+}
+
+int covahip_ctx_get_lanes(covahip_ctx *ctx, int *n_lanes) {
+    if (!ctx || !n_lanes) return COVAHIP_ERR_INVALID_ARG;
+    *n_lanes = ctx->n_lanes;
     return COVAHIP_OK;
 }
 
@@ -112,13 +145,15 @@ int covahip_malloc(covahip_ctx *ctx, size_t bytes, void **dev_ptr) {
 int covahip_free(covahip_ctx *ctx, void *dev_ptr) {
     if (!ctx) return COVAHIP_ERR_INVALID_ARG;
     if (!dev_ptr) return COVAHIP_OK;
-    COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = covahip_sync_all(ctx);
+    if (rc) return rc;
     COVAHIP_CHECK_HIP(ctx, hipFree(dev_ptr));
     return COVAHIP_OK;
 }
 
 int covahip_memcpy_h2d(covahip_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes) {
     if (!ctx || (!dev_dst && bytes) || (!host_src && bytes)) return COVAHIP_ERR_INVALID_ARG;
+    if (int rc = covahip_primary_op(ctx)) return rc;
     COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return COVAHIP_OK;
@@ -126,6 +161,7 @@ int covahip_memcpy_h2d(covahip_ctx *ctx, void *dev_dst, const void *host_src, si
 
 int covahip_memcpy_d2h(covahip_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
     if (!ctx || (!host_dst && bytes) || (!dev_src && bytes)) return COVAHIP_ERR_INVALID_ARG;
+    if (int rc = covahip_primary_op(ctx)) return rc;
     COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return COVAHIP_OK;
@@ -133,18 +169,21 @@ int covahip_memcpy_d2h(covahip_ctx *ctx, void *host_dst, const void *dev_src, si
 
 int covahip_memset(covahip_ctx *ctx, void *dev_ptr, int value, size_t bytes) {
     if (!ctx || (!dev_ptr && bytes)) return COVAHIP_ERR_INVALID_ARG;
+    if (int rc = covahip_primary_op(ctx)) return rc;
     COVAHIP_CHECK_HIP(ctx, hipMemsetAsync(dev_ptr, value, bytes, ctx->stream));
     return COVAHIP_OK;
 }
 
 int covahip_timer_start(covahip_ctx *ctx, int slot) {
     if (!ctx || slot < 0 || slot >= 16) return COVAHIP_ERR_INVALID_ARG;
+    if (int rc = covahip_primary_op(ctx)) return rc;
     COVAHIP_CHECK_HIP(ctx, hipEventRecord(ctx->t_start[slot], ctx->stream));
     return COVAHIP_OK;
 }
 
 int covahip_timer_stop(covahip_ctx *ctx, int slot) {
     if (!ctx || slot < 0 || slot >= 16) return COVAHIP_ERR_INVALID_ARG;
+    if (int rc = covahip_primary_op(ctx)) return rc;
     COVAHIP_CHECK_HIP(ctx, hipEventRecord(ctx->t_stop[slot], ctx->stream));
     return COVAHIP_OK;
 }
@@ -242,6 +281,67 @@ ProfScope::~ProfScope() {
         }
         ctx->prof_pending.clear();
     }
+}
+
+// ---------------------------------------------------------------- lanes (see CtxLane in internal.h)
+int covahip_primary_op(covahip_ctx *ctx) {
+    if (ctx->in_lane) return COVAHIP_OK;   // inside a LaneScope `stream` is the lane's: nothing touches the primary stream
+    for (int k = 0; k < COVAHIP_MAX_LANES; k++) {
+        CtxLane &l = ctx->lanes[k];
+        if (l.pending) {
+            COVAHIP_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->primary, l.done, 0));
+            l.pending = false;
+        }
+    }
+    ctx->primary_seq++;
+    return COVAHIP_OK;
+}
+
+int covahip_sync_all(covahip_ctx *ctx) {
+    for (int k = 0; k < COVAHIP_MAX_LANES; k++) {
+        CtxLane &l = ctx->lanes[k];
+        if (l.pending && l.stream) {
+            COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(l.stream));
+            l.pending = false;
+        }
+    }
+    if (ctx->primary) COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->primary));
+    return COVAHIP_OK;
+}
+
+LaneScope::LaneScope(covahip_ctx *c) : ctx(c) {
+    if (ctx->in_lane || ctx->n_lanes <= 1) {
+        // one lane: the call runs on the primary stream, behind whatever an earlier multi-lane configuration left in flight
+        if (!ctx->in_lane && covahip_primary_op(ctx)) failed = true;
+        return;
+    }
+    const int k = ctx->next_lane;
+    CtxLane &l = ctx->lanes[k];
+    if (l.seen_seq != ctx->primary_seq) {
+        // something was enqueued on the primary stream since this lane last looked: order the lane behind it
+        hipError_t e = hipEventRecord(ctx->ev_fork, ctx->primary);
+        if (e == hipSuccess) e = hipStreamWaitEvent(l.stream, ctx->ev_fork, 0);
+        if (e != hipSuccess) {
+            ctx->last_hip_error = std::string("lane fork: ") + hipGetErrorString(e);
+            failed = true;
+            return;
+        }
+        l.seen_seq = ctx->primary_seq;
+    }
+    ctx->next_lane = (k + 1) % ctx->n_lanes;
+    ctx->cur_lane = k;
+    ctx->stream = l.stream;
+    ctx->in_lane = true;
+    owner = true;
+}
+
+LaneScope::~LaneScope() {
+    if (!owner) return;
+    CtxLane &l = ctx->lanes[ctx->cur_lane];
+    if (hipEventRecord(l.done, l.stream) == hipSuccess) l.pending = true;
+    ctx->stream = ctx->primary;
+    ctx->cur_lane = 0;
+    ctx->in_lane = false;
 }
 
 int covahip_ensure_buffer(covahip_ctx *ctx, void **buf, size_t *cur, size_t need) {

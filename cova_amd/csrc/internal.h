@@ -11,9 +11,42 @@
 
 struct covahip_blobnet;  // blobnet.hip
 
+// Lanes: batches in flight on one GPU.  Every launch of the hot path has a fixed cost (weights into registers, the first
+// band's DMA, the slowest workgroup's tail) during which most of the chip idles; at b = 256 that is a third of a step.
+// The reference keeps its GPU busy the same way -- sixteen BlobNet engines with their own batches on one GPU
+// (experiment/cova/config.yaml:33-34, pipeline/cova/pipeline.py:139-181).  A ctx therefore owns `n_lanes` HIP streams,
+// each with its own activation workspace and bboxcc scratch; consecutive covahip_filter_forward(_frames) calls on device
+// pointers go to consecutive lanes and overlap.  Ordering rules (LaneScope / covahip_primary_op, ctx.hip):
+//   * a call placed on a lane is ordered behind everything enqueued on the ctx's primary stream before it;
+//   * every other entry point (timers, sync, copies, stand-alone bboxcc / blobnet calls) first makes the primary stream
+//     wait for all lanes, so it observes every earlier filter call;
+//   * two filter calls with nothing in between are NOT ordered with each other: they must not share output buffers.
+// n_lanes = 1: everything runs on the primary stream, in call order.
+constexpr int COVAHIP_MAX_LANES = 4;
+struct CtxLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;     // recorded behind the last call placed on this lane
+    bool pending = false;          // `done` has not been joined into the primary stream yet
+    uint64_t seen_seq = 0;         // state of the primary stream this lane is ordered behind (covahip_ctx::primary_seq)
+    // bboxcc scratch of the fused path (mask when the caller wants none), overflow list of the wave kernel (count + frame
+    // indices), state slab of frames too large for LDS (one per resident workgroup)
+    void *cc_scratch = nullptr;
+    size_t cc_scratch_bytes = 0;
+    void *cc_ovf = nullptr;
+    size_t cc_ovf_bytes = 0;
+    void *cc_slab = nullptr;
+    size_t cc_slab_bytes = 0;
+};
+
 struct covahip_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t primary = nullptr;   // the ctx's own stream
+    hipStream_t stream = nullptr;    // where launches go NOW: `primary`, or the current lane's stream inside a LaneScope
+    CtxLane lanes[COVAHIP_MAX_LANES];
+    int n_lanes = 2, next_lane = 0, cur_lane = 0;
+    bool in_lane = false;
+    uint64_t primary_seq = 1;        // bumped by every operation enqueued on the primary stream
+    hipEvent_t ev_fork = nullptr;
     std::string last_hip_error;
     hipDeviceProp_t props{};
     // timers
@@ -36,15 +69,8 @@ struct covahip_ctx {
     size_t stage_out_bytes = 0;
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
-    // bboxcc scratch for the fused path (mask / boxes / counts on device)
-    void *cc_scratch = nullptr;
-    size_t cc_scratch_bytes = 0;
-    // bboxcc wave kernel: overflow list (count + frame indices) and the developer override of its run capacity
-    void *cc_ovf = nullptr;
-    size_t cc_ovf_bytes = 0;
-    void *cc_slab = nullptr;   // bboxcc state of frames too large for LDS (one slab per resident workgroup)
-    size_t cc_slab_bytes = 0;
-    int cc_wave_cap = 0;
+    int cc_wave_cap = 0;       // bboxcc wave kernel: developer override of its run capacity
+    CtxLane &lane() { return lanes[cur_lane]; }
     struct { int nbands, nbuf; } enc_plan[4] = {};   // developer override of the encoder band plan per level (0 = automatic)
     covahip_blobnet *blobnet = nullptr;
 };
@@ -68,6 +94,20 @@ struct ProfScope {
 
 int covahip_ensure_buffer(covahip_ctx *ctx, void **buf, size_t *cur, size_t need);
 
+// Places what follows on the next lane (see CtxLane above); re-entrant (an inner scope is a no-op).  `ok()` is false when a
+// HIP call of the fork failed (ctx->last_hip_error says which).
+struct LaneScope {
+    covahip_ctx *ctx;
+    bool owner = false, failed = false;
+    explicit LaneScope(covahip_ctx *c);
+    ~LaneScope();
+    bool ok() const { return !failed; }
+};
+// Before anything is enqueued on the primary stream: the primary stream waits for every lane's last call.
+int covahip_primary_op(covahip_ctx *ctx);
+// Blocks until every lane and the primary stream have drained.
+int covahip_sync_all(covahip_ctx *ctx);
+
 // bboxcc.hip
 int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, int h, int w, int area_thresh,
                           covahip_box *d_boxes, int32_t *d_counts, int max_boxes);
@@ -77,3 +117,4 @@ void covahip_blobnet_destroy(covahip_ctx *ctx);
 int covahip_blobnet_forward_dev(covahip_ctx *ctx, const uint8_t *d_stack, int batch, float *d_logits,
                                 uint8_t *d_mask);
 int covahip_blobnet_geometry(covahip_ctx *ctx, int *h, int *w);
+int covahip_blobnet_grow_lanes(covahip_ctx *ctx, int n_lanes);   // workspaces of lanes [0, n_lanes) of the loaded model

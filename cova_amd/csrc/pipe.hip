@@ -4,9 +4,9 @@
 //   * every slot owns PINNED host buffers (hipHostMalloc) for its carrier frames, its stack -> frame table and its
 //     results; the caller writes the frames of a batch straight into the slot (the copy a batching element makes
 //     anyway, nvstreammux-style), so no pageable copy ever blocks the calling thread;
-//   * three HIP streams: H2D of batch k+1, the kernels of batch k (the ctx stream; the activation workspace is shared,
-//     so compute is serial), D2H of batch k-1, chained by events -- PCIe traffic in both directions hides behind
-//     the kernels;
+//   * H2D of batch k+1, the kernels of batch k (a lane of the ctx: its own stream and activation workspace, so the
+//     kernels of consecutive batches overlap as well), D2H of batch k-1, chained by events -- PCIe traffic in both
+//     directions hides behind the kernels;
 //   * boxes are compacted on the device (exclusive scan of the per-frame counts -> one packed array + offsets), so
 //     the D2H copy carries what exists, not batch x max_boxes slots.
 //
@@ -97,7 +97,7 @@ extern "C" {
 void covahip_pipe_destroy(covahip_pipe *p) {
     if (!p) return;
     hipSetDevice(p->ctx->device);
-    hipStreamSynchronize(p->ctx->stream);
+    covahip_sync_all(p->ctx);
     if (p->s_h2d) hipStreamSynchronize(p->s_h2d);
     if (p->s_d2h) hipStreamSynchronize(p->s_d2h);
     for (Slot &s : p->slots) {
@@ -190,6 +190,10 @@ int covahip_pipe_submit(covahip_pipe *p, int slot, int n_frames, int batch, int 
     PIPE_CHECK(hipSetDevice(ctx->device));
     PIPE_CHECK(hipMemcpyAsync(s.d_frames, s.h_frames, (size_t)n_frames * p->frame_bytes, hipMemcpyHostToDevice, p->s_h2d));
     PIPE_CHECK(hipEventRecord(s.ev_in, p->s_h2d));
+    // the kernels of this batch go to the ctx's next lane (internal.h, CtxLane): with two lanes the kernels of batch k+1 fill
+    // the ramps and tails of batch k's launches
+    LaneScope lane(ctx);
+    if (!lane.ok()) return COVAHIP_ERR_HIP;
     PIPE_CHECK(hipStreamWaitEvent(ctx->stream, s.ev_in, 0));
     int32_t *d_counts = s.d_meta, *d_offsets = s.d_meta + p->max_batch;
     int rc = covahip_filter_forward_frames(ctx, s.d_frames, n_frames, s.h_index, batch, area_thresh, s.d_boxes, d_counts, p->max_boxes,

@@ -51,6 +51,16 @@ class Context:
     def sync(self):
         L.check(self._lib.covahip_ctx_sync(self.handle), "covahip_ctx_sync", self.handle)
 
+    def set_lanes(self, n: int):
+        """Batches in flight (covahip_ctx_set_lanes): 1 = strictly in call order, 2 (default) = consecutive device-pointer
+        filter calls overlap."""
+        L.check(self._lib.covahip_ctx_set_lanes(self.handle, n), "covahip_ctx_set_lanes", self.handle)
+
+    def lanes(self) -> int:
+        n = C.c_int()
+        L.check(self._lib.covahip_ctx_get_lanes(self.handle, C.byref(n)), "covahip_ctx_get_lanes", self.handle)
+        return n.value
+
     def info(self):
         name = C.create_string_buffer(256)
         cu = C.c_int()

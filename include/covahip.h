@@ -57,7 +57,22 @@ int covahip_device_count(int *count);
  *  gst-plugins/gst-maskcopy/gstmaskcopy.cpp:247.) */
 int covahip_ctx_create(int device_id, covahip_ctx **out);
 void covahip_ctx_destroy(covahip_ctx *ctx);
+/* Blocks until everything the ctx has enqueued (all lanes, see below) is done. */
 int covahip_ctx_sync(covahip_ctx *ctx);
+/* Lanes = batches in flight.  The reference keeps one GPU busy with sixteen BlobNet engines, each with a batch of its own
+ * (experiment/cova/config.yaml:33-34 num_mask / mask_batch_size, pipeline/cova/pipeline.py:139-181); here a ctx owns
+ * n_lanes HIP streams with an activation workspace each, and consecutive covahip_filter_forward /
+ * covahip_filter_forward_frames calls on DEVICE pointers (and consecutive covahip_pipe_submit calls) go to consecutive
+ * lanes, so the launches of batch k+1 fill the ramps and tails of batch k's.  Rules:
+ *   - such a call sees everything enqueued on the ctx before it (copies, memsets, timers);
+ *   - every other entry point (covahip_ctx_sync, timers, copies, covahip_bboxcc, covahip_blobnet_forward, host-pointer
+ *     calls) waits for / is ordered behind all lanes;
+ *   - two device-pointer filter calls with nothing in between may run concurrently: give them separate output buffers
+ *     (inputs may be shared) or call covahip_ctx_sync between them.
+ * n_lanes in [1, 4]; default 2; 1 = strictly in call order on one stream.  Workspace per lane at 68x120, max_batch 256:
+ * about 150 MB.  Drains the ctx first. */
+int covahip_ctx_set_lanes(covahip_ctx *ctx, int n_lanes);
+int covahip_ctx_get_lanes(covahip_ctx *ctx, int *n_lanes);
 /* Text of the last failing HIP call on this ctx ("" if none). */
 const char *covahip_last_hip_error(covahip_ctx *ctx);
 /* Device properties the bench reports: name (<=255 chars), CU count, HBM bytes. */
