@@ -12,7 +12,13 @@ every rank runs the same batch size on its own GPU (frames/streams are independe
 path), the timed region is bracketed by barrier + synchronize on both sides, the MAX over ranks is taken and
 rank 0 prints ONE JSON line.
 
+The K timed steps are enqueued back to back on a ctx with `--lanes` (default 2) batches in flight: step k+1 runs on
+the other lane (own HIP stream and activation workspace) and its launches fill the ramps and tails of step k's --
+the way the reference keeps sixteen BlobNet engines busy on one GPU (experiment/cova/config.yaml:33-34).  `value` =
+frames of all K steps / wall time; `ms_per_step_one_lane` is a step on its own (--lanes 1 times that).
+
     python bench.py                       # N=1, defaults finish in a few minutes
+    python bench.py --gpus N              # starts the N ranks itself (torch.distributed.run as a child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -333,14 +339,33 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--entry", choices=["frames", "stack"], default="frames",
                     help="entry point of the timed step: carrier frames + stack table (default) or pre-stacked tensors")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="batches in flight per GPU (covahip_ctx_set_lanes): 1 = one step after the other on one stream")
+    ap.add_argument("--min-warmup-s", type=float, default=0.3, help="warm up for at least this long on top of --warmup steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="only the timed workload (profiling runs)")
     args = ap.parse_args()
 
+    # ---- --gpus N without a launcher: start the N ranks ourselves, as a CHILD (this process has not touched the GPU and
+    # never will), relay its output and exit with its code
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        sys.exit(subprocess.run(cmd, env=env).returncode)
+    if env_world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} ...) or let --gpus start them")
+
     # ---- host-only legs first, before this process loads the HIP library: the GStreamer element bench (a child
     # process with a GPU context of its own) and the CPU tracking baseline (forked workers)
     pre = {}
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    if env_world == 1:
         if not args.no_extra_legs:
             pre["through_gstreamer_elements"] = element_rate()
         if not args.no_cpu_baseline:
@@ -349,12 +374,16 @@ def main():
     from cova_amd.multigpu import Group
     grp = Group()            # torch.distributed (RCCL) only when WORLD_SIZE > 1: rendezvous/barrier/MAX
     rank, local_rank, world = grp.rank, grp.local_rank, grp.world
+    if world != args.gpus:
+        sys.exit(f"bench.py: world size {world} != --gpus {args.gpus}")
 
     from cova_amd import synth, weights as W
     from cova_amd.elements import BlobNetInfer, Context
 
     ctx = Context(local_rank)
+    ctx.set_lanes(1)         # the extra legs and the per-kernel pass run one step after the other
     B = args.batch
+    NL = max(1, min(4, args.lanes))
     flat = W.random_init(1234)
     extras = {}
     if rank == 0 and not args.no_extra_legs:
@@ -365,30 +394,34 @@ def main():
     stack = synth.stacked_batch(B, H_MB, W_MB, seed=seed, streams=8)
     d_stack = ctx.malloc(stack.nbytes)
     ctx.h2d(d_stack, stack)
-    d_boxes = ctx.malloc(B * MAX_BOXES * 20)
-    d_counts = ctx.malloc(B * 4)
-    d_mask = ctx.malloc(B * H_MB * W_MB)
+    # one set of output buffers per lane: steps in flight together must not share them (include/covahip.h, lanes)
+    d_boxes = [ctx.malloc(B * MAX_BOXES * 20) for _ in range(NL)]
+    d_counts = [ctx.malloc(B * 4) for _ in range(NL)]
+    d_mask = [ctx.malloc(B * H_MB * W_MB) for _ in range(NL)]
 
     # the same 256 stacks as carrier frames + table
     frames, index = synth.carrier_batch(B, H_MB, W_MB, seed=seed, streams=8)
     assert np.array_equal(np.concatenate([frames[index[:, k]] for k in range(T)], axis=1), stack)
     d_frames = ctx.malloc(frames.nbytes)
     ctx.h2d(d_frames, frames)
+    turn = [0]
 
     def step_stack():
-        net.filter_device(d_stack, B, CC_THRESHOLD, d_boxes, d_counts, MAX_BOXES, d_mask)
+        k = turn[0] = (turn[0] + 1) % NL
+        net.filter_device(d_stack, B, CC_THRESHOLD, d_boxes[k], d_counts[k], MAX_BOXES, d_mask[k])
 
     def step_frames():
-        net.filter_frames_device(d_frames, frames.shape[0], index, B, CC_THRESHOLD, d_boxes, d_counts, MAX_BOXES, d_mask)
+        k = turn[0] = (turn[0] + 1) % NL
+        net.filter_frames_device(d_frames, frames.shape[0], index, B, CC_THRESHOLD, d_boxes[k], d_counts[k], MAX_BOXES, d_mask[k])
 
     step = step_frames if args.entry == "frames" else step_stack
     other = step_stack if args.entry == "frames" else step_frames
 
     def barrier():
-        ctx.sync()           # the ctx's own HIP stream
+        ctx.sync()           # every lane of the ctx
         grp.barrier()        # torch.cuda.synchronize() + dist.barrier() when world > 1
 
-    # ---- find the dominant kernel (profiled warm-up pass, not timed)
+    # ---- one lane: per-kernel times of a step on its own (profiled pass, not timed), the dominant kernel, the step latency
     for _ in range(3):
         step()
     ctx.profile(True)
@@ -400,9 +433,17 @@ def main():
     per_kernel_us = {k: t / n * 1e3 for k, (t, n) in prof.items()}
     blob_kernels = {k: v for k, v in per_kernel_us.items() if k not in ("bboxcc_kernel", "bboxcc_wave_kernel", "dec3_bboxcc_fused")}
     dominant = max(blob_kernels, key=blob_kernels.get)
+    serial_ms = timed_steps(ctx, step, max(20, args.steps // 4), 5)
 
-    for _ in range(args.warmup):
+    # ---- warm-up with the lanes of the timed region: --warmup steps and at least --min-warmup-s of them (clocks and caches settle)
+    ctx.set_lanes(NL)
+    t_w = time.perf_counter()
+    n_w = 0
+    while n_w < args.warmup or time.perf_counter() - t_w < args.min_warmup_s:
         step()
+        n_w += 1
+        if n_w % 64 == 0:
+            ctx.sync()
     # ---- timed region: K steps; only the dominant kernel carries HIP events (2 per step)
     ctx.profile(True, only=dominant)
     barrier()
@@ -416,20 +457,29 @@ def main():
     ev_ms = ctx.timer_ms(0)
     dom_ms, dom_n = ctx.profile_read()[dominant]
     ctx.profile(False)
+    # shader clock under this load: a probe wave beside 60 more steps (untimed)
+    for _ in range(60):
+        step()
+    clock_mhz = ctx.clock_mhz(300)
+    ctx.sync()
 
     # ---- bboxcc roofline (outside the timed region).  Inside the hot path bboxcc runs in the same launch as the last
     # decoder block; standalone it is timed (a) on the masks the last step left in HBM (b = 256: one frame per CU,
     # latency bound) and (b) at B = 65,536 sparse-blob masks, where the byte rate of the wave-per-frame kernel shows.
     from cova_amd.elements import BboxCc
+    ctx.set_lanes(1)
     cc = BboxCc(ctx, CC_THRESHOLD, MAX_BOXES)
     d_boxes2 = ctx.malloc(B * MAX_BOXES * 20)
     d_counts2 = ctx.malloc(B * 4)
-    cc_ms = timed_steps(ctx, lambda: cc.regionprops_device(d_mask, B, H_MB, W_MB, d_boxes2, d_counts2), args.steps, 3)
+    cc_ms = timed_steps(ctx, lambda: cc.regionprops_device(d_mask[0], B, H_MB, W_MB, d_boxes2, d_counts2), args.steps, 3)
     counts2 = np.zeros(B, dtype=np.int32)
     ctx.d2h(counts2, d_counts2)
     counts = np.zeros(B, dtype=np.int32)
-    ctx.d2h(counts, d_counts)
+    ctx.d2h(counts, d_counts[0])
     assert (counts == counts2).all(), "fused decoder tail and standalone bboxcc disagree"
+    for k in range(1, NL):
+        ctx.d2h(counts2, d_counts[k])
+        assert (counts == counts2).all(), "the lanes disagree"
     ctx.free(d_boxes2); ctx.free(d_counts2)
 
     rank0 = {}
@@ -446,12 +496,15 @@ def main():
                                                "frac_of_8TBs": round(BB * H_MB * W_MB / ms / 1e6 / HBM_PEAK_GBS, 4)}
         for p in (d_m, d_b, d_c):
             ctx.free(p)
-        # the other entry point on the SAME 256 stacks
-        ms = timed_steps(ctx, other, args.steps)
-        ctx.d2h(counts2, d_counts)
+        # the other entry point on the SAME 256 stacks: one lane (the latency of a step on its own) and NL lanes
+        ms1 = timed_steps(ctx, other, max(20, args.steps // 2))
+        ctx.set_lanes(NL)
+        msn = timed_steps(ctx, other, args.steps, 2 * NL)
+        ctx.set_lanes(1)
+        ctx.d2h(counts2, d_counts[0])
         assert (counts == counts2).all(), "carrier-frame entry and stacked entry disagree"
         rank0["stacked_entry" if args.entry == "frames" else "carrier_frame_entry"] = {
-            "frames_per_s": round(B / ms * 1e3, 1), "ms_per_step": round(ms, 4),
+            "frames_per_s": round(B / msn * 1e3, 1), "ms_per_step": round(msn, 4), "ms_per_step_one_lane": round(ms1, 4),
             "carrier_frames_per_step": int(frames.shape[0]), "carrier_input_bytes_per_step": int(frames.nbytes),
             "stacked_input_bytes_per_step": int(stack.nbytes)}
         # PCIe-inclusive rates (never `value`)
@@ -460,7 +513,9 @@ def main():
         for _ in range(5):
             net.filter(stack, CC_THRESHOLD, max_boxes=MAX_BOXES)
         rank0["frames_per_s_pcie_inclusive_host_buffers"] = round(5 * B / (time.perf_counter() - t1), 1)
+        ctx.set_lanes(NL)
         rank0["frames_per_s_pcie_inclusive_pipelined_carrier_frames"] = pipelined_host_rate(net, frames, index, args.steps)
+        ctx.set_lanes(1)
 
     elapsed = grp.max(elapsed)
 
@@ -478,12 +533,16 @@ def main():
         cc_s = cc_ms * 1e-3
         cc_gbs = B * H_MB * W_MB / cc_s / 1e9
         total_flop = 2.0 * net.macs_per_frame * B
+        # what the timed entry executes: the carrier-frame entry runs level 0's convolution once per carrier frame
+        # (nfr slices) instead of once per (stack, T slice) (4 B slices)
+        executed_flop = total_flop - (2.0 * hs[0] * ws[0] * 9 * 3 * 16 * (T * B - nfr) if args.entry == "frames" else 0.0)
         step_s = elapsed / args.steps
         dom_flop = 2.0 * macs[dominant] * B
         ach_tflops = dom_flop / dom_s / 1e12
         dom_bytes = kbytes[dominant] * B
         dom_traffic, dom_traffic_src = committed_traffic(dominant, args.entry) if B == BATCH else (None, None)
         cc_traffic, _ = committed_traffic("bboxcc_kernel", "stack") if B == BATCH else (None, None)
+        serial_dom_s = per_kernel_us[dominant] * 1e-6
         line = {
             "metric": "compressed-domain frames/sec (BlobNet+bboxcc) at 1080p b=256",
             "value": round(world * B * args.steps / elapsed, 1),
@@ -497,14 +556,17 @@ def main():
             "vs_baseline": None,
             "dtype": "f16",
             "data": "synthetic",
-            "config": {"workload": ("temporal stacking as a GPU gather + BlobNet + bboxcc fused (covahip_filter_forward_frames): carrier "
-                                    "frames of 8 streams + stack table, 256 output frames, 1080p macroblock grid 68x120, T=4, inputs "
-                                    "resident in HBM" if args.entry == "frames" else
-                                    "BlobNet + bboxcc fused (covahip_filter_forward) on 256 pre-stacked tensors, 1080p macroblock grid "
-                                    "68x120, T=4, inputs resident in HBM"),
-                       "entry": args.entry,
-                       "batch_per_gpu": B, "grid_mb": [H_MB, W_MB], "timestep": T, "cc_threshold": CC_THRESHOLD,
-                       "parallelism": f"{world} x independent per-GPU batches, no collective"},
+            "lanes": NL,
+            "ms_per_step_one_lane": round(serial_ms, 4),
+            "shader_clock_mhz_under_load": round(clock_mhz, 1),
+            "blobnet_mfma_util_whole_net": round(total_flop / step_s / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "blobnet_mfma_util_whole_net_executed": round(executed_flop / step_s / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "algorithmic_flop_per_step": total_flop,
+            "executed_flop_per_step": executed_flop,
+            "per_kernel_us": {k: round(v, 2) for k, v in sorted(per_kernel_us.items())},
+        }
+        line.update({k: rank0.pop(k) for k in ("stacked_entry", "carrier_frame_entry") if k in rank0})
+        line.update({
             # SURVEY.md section 8(d) prices the BlobNet kernels against the MFMA roof; the same launch against
             # the HBM roof (compulsory bytes of the kernel / time) is given beside it, with the tighter one named.
             "roofline": {"kernel": dominant, "bound": "mfma", "achieved": round(ach_tflops, 2),
@@ -512,7 +574,14 @@ def main():
                          "traffic": dom_traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
                          "traffic_source": dom_traffic_src,
                          "algorithmic_flop_per_launch": dom_flop, "avg_launch_us": round(dom_s * 1e6, 2),
-                         "launches_timed": dom_n, "measured": "HIP events on the launch stream inside the timed region",
+                         "launches_timed": dom_n,
+                         "measured": (f"HIP events on the launch's own stream inside the timed region; with {NL} lanes the launch "
+                                      "shares the chip with the other lane's launches, so its duration is longer than on its own"
+                                      if NL > 1 else "HIP events on the launch stream inside the timed region"),
+                         "one_lane": {"avg_launch_us": round(serial_dom_s * 1e6, 2),
+                                      "achieved": round(dom_flop / serial_dom_s / 1e12, 2),
+                                      "frac": round(dom_flop / serial_dom_s / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                      "measured": "HIP events, the launch alone on the chip (per-kernel pass before the timed region)"},
                          "hbm_view": {"algorithmic_bytes_per_launch": dom_bytes,
                                       "achieved_GBs": round(dom_bytes / dom_s / 1e9, 1),
                                       "frac_of_8TBs": round(dom_bytes / dom_s / 1e9 / HBM_PEAK_GBS, 4)},
@@ -524,13 +593,12 @@ def main():
                                 "note": "standalone kernel on the step's masks (in the hot path bboxcc runs inside the last "
                                         "decoder block's launch); b=256 masks are 2.09 MB: latency bound -- the byte rate is "
                                         "bboxcc_B65536_sparse_blobs"},
-            "blobnet_mfma_util_whole_net": round(total_flop / step_s / 1e12 / MFMA_PEAK_TFLOPS, 4),
-            "blobnet_mfma_util_note": "algorithmic BlobNet FLOP over the WHOLE step time (bboxcc included: it shares a launch)",
-            "per_kernel_us": {k: round(v, 2) for k, v in sorted(per_kernel_us.items())},
+            "blobnet_mfma_util_note": "BlobNet FLOP (algorithmic: SURVEY.md 8d; executed: level 0 once per carrier frame) over the "
+                                      "WHOLE step time (bboxcc included: it shares a launch)",
             "hip_event_ms_per_step_rank0": round(ev_ms / args.steps, 4),
             "boxes_per_frame_mean": float(counts.mean()),
             "device": ctx.info(),
-        }
+        })
         line.update(rank0)
         line.update(extras)
         if "through_gstreamer_elements" in pre:
@@ -539,6 +607,19 @@ def main():
             line["cpu_baseline"] = cpu_baseline(flat, stack)
             line["cpu_baseline"].update(pre.get("cpu_tracking", {}))
             line["gpu_over_cpu"] = round(line["value"] / world / line["cpu_baseline"]["value"], 1)
+        # the long strings last, so that the numbers survive a truncated log
+        line["config"] = {"workload": ("temporal stacking as a GPU gather + BlobNet + bboxcc fused (covahip_filter_forward_frames): carrier "
+                                       "frames of 8 streams + stack table, 256 output frames, 1080p macroblock grid 68x120, T=4, inputs "
+                                       "resident in HBM" if args.entry == "frames" else
+                                       "BlobNet + bboxcc fused (covahip_filter_forward) on 256 pre-stacked tensors, 1080p macroblock grid "
+                                       "68x120, T=4, inputs resident in HBM"),
+                          "entry": args.entry, "lanes": NL,
+                          "lanes_note": (f"{NL} batches of {B} in flight per GPU on {NL} HIP streams with a workspace each, as the reference keeps "
+                                         "16 BlobNet engines busy on one GPU (experiment/cova/config.yaml:33-34); ms_per_step = wall time / steps; "
+                                         "ms_per_step_one_lane = one step after the other"),
+                          "stack_table": "the same table every step: validated and uploaded once, then found unchanged (blobnet.hip prepare_frames)",
+                          "batch_per_gpu": B, "grid_mb": [H_MB, W_MB], "timestep": T, "cc_threshold": CC_THRESHOLD,
+                          "parallelism": f"{world} x independent per-GPU batches, no collective"}
         print(json.dumps(line), flush=True)
 
     barrier()

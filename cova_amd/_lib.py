@@ -158,6 +158,7 @@ DEV_PROTOTYPES = {
     "covahip_blobnet_set_impl": (C.c_int, [_P, C.c_int]),
     "covahip_bboxcc_set_wave_cap": (C.c_int, [_P, C.c_int]),
     "covahip_blobnet_set_enc_plan": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    "covahip_dev_clock_mhz": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
 }
 
 _lib = None

@@ -344,6 +344,47 @@ LaneScope::~LaneScope() {
     ctx->in_lane = false;
 }
 
+// ---------------------------------------------------------------- shader clock under load (covahip_dev.h)
+// One wave runs a dependent chain for about `busy_us` and brackets it with s_memtime (shader cycles) and s_memrealtime
+// (100 MHz): MI355X_MICROARCH.md, DVFS give-back (6).  On a stream of its own, so it shares the chip with whatever the
+// ctx has in flight -- that is the clock the caller wants.
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long *out, int iters) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    float x = (float)threadIdx.x;
+    for (int i = 0; i < iters; i++) {
+        x = __builtin_fmaf(x, 1.0001f, 0.5f);
+        asm volatile("" : "+v"(x));
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[0] = t1 - t0;
+        out[1] = r1 - r0;
+    }
+    if (x == 12345.678f) out[2] = 1;   // keeps the chain alive
+}
+
+extern "C" int covahip_dev_clock_mhz(covahip_ctx *ctx, int busy_us, float *mhz) {
+    if (!ctx || !mhz || busy_us <= 0 || busy_us > 100000) return COVAHIP_ERR_INVALID_ARG;
+    COVAHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = nullptr;
+    unsigned long long *d = nullptr, h[3] = {0, 0, 0};
+    COVAHIP_CHECK_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipError_t e = hipMalloc((void **)&d, sizeof(h));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, st, d, busy_us * 400);   // ~5 cycles per dependent fma
+        e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (d) hipFree(d);
+    hipStreamDestroy(st);
+    if (e != hipSuccess) {
+        ctx->last_hip_error = std::string("clock probe: ") + hipGetErrorString(e);
+        return COVAHIP_ERR_HIP;
+    }
+    *mhz = h[1] ? (float)((double)h[0] / (double)h[1] * 100.0) : 0.f;
+    return COVAHIP_OK;
+}
+
 int covahip_ensure_buffer(covahip_ctx *ctx, void **buf, size_t *cur, size_t need) {
     if (*cur >= need && *buf) return COVAHIP_OK;
     if (*buf) {

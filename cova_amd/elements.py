@@ -61,6 +61,12 @@ class Context:
         L.check(self._lib.covahip_ctx_get_lanes(self.handle, C.byref(n)), "covahip_ctx_get_lanes", self.handle)
         return n.value
 
+    def clock_mhz(self, busy_us: int = 200) -> float:
+        """Shader clock held right now, measured beside whatever the ctx has in flight (covahip_dev_clock_mhz)."""
+        mhz = C.c_float()
+        L.check(self._lib.covahip_dev_clock_mhz(self.handle, busy_us, C.byref(mhz)), "covahip_dev_clock_mhz", self.handle)
+        return mhz.value
+
     def info(self):
         name = C.create_string_buffer(256)
         cu = C.c_int()

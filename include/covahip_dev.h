@@ -28,6 +28,11 @@ int covahip_bboxcc_set_wave_cap(covahip_ctx *ctx, int cap);
  * COVAHIP_ERR_UNSUPPORTED. */
 int covahip_blobnet_set_enc_plan(covahip_ctx *ctx, int level, int nbands, int nbuf);
 
+/* Shader clock (MHz) the chip holds right now: one wave runs a dependent chain for about busy_us microseconds on a stream
+ * of its own -- beside whatever the ctx has in flight -- and brackets it with s_memtime / s_memrealtime
+ * (MI355X_MICROARCH.md, DVFS give-back).  bench.py prints it so that step times of different boxes can be compared. */
+int covahip_dev_clock_mhz(covahip_ctx *ctx, int busy_us, float *mhz);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 H, Wd = 68, 120
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 ctx = Context(0)
+ctx.set_lanes(int(os.environ.get("QB_LANES", "1")))      # per-kernel times want one step after the other
 flat = W.random_init(1234)
 net = BlobNetInfer(ctx, flat, H, Wd, max_batch=B)
 if os.environ.get("QB_IMPL"):
