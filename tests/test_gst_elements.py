@@ -301,11 +301,19 @@ def test_blobnetfilter_batching_element(tmp_path, weights_flat, batch_size, time
     total = 0
     for s in range(n_streams):
         stack = np.stack([np.concatenate([carriers[s][i - k] for k in range(4)], axis=0) for i in range(3, n)])
-        boxes, counts, _ = net.filter(stack, cc_threshold=4, max_boxes=512)
+        boxes, counts, mask = net.filter(stack, cc_threshold=4, max_boxes=512, want_mask=True)
         assert [p for p, _ in per_stream[s]] == [i * CLK for i in range(3, n)]        # in order, PTS of the current frame
         for j, (_, payload) in enumerate(per_stream[s]):
             assert payload == E.serialize_vec(E.boxes_to_bbox(boxes[j, :counts[j]]))
             total += int(counts[j])
+        if s in (0, n_streams - 1):
+            # ... and not only "what the C-ABI path gives": the oracle's regionprops on the HIP mask, serialised, is the payload
+            rb, rc = ref.regionprops_batch(mask, 4, 512)
+            for j, (_, payload) in enumerate(per_stream[s]):
+                bx = np.zeros(int(rc[j]), dtype=L.BOX_DTYPE)
+                for f, g in (("left", "left"), ("top", "top"), ("width", "width"), ("height", "height"), ("area_px", "area")):
+                    bx[f] = rb[j, :rc[j]][g]
+                assert payload == E.serialize_vec(E.boxes_to_bbox(bx))
     assert total > 0
     ctx.close()
 
