@@ -734,10 +734,13 @@ struct OutSink {
 // cova/tracker.rs:59-83 / :91-118: every finished track goes out as one length-delimited bincode Frame
 // {range_start, oldest = smallest start among the live trackers, history}.  (The reference re-sends the
 // frames already in its buffer for every further track of the same call -- not reproduced.)
-void export_tracks(covahip_gopfilter *g, const std::vector<Tracker> &tracks) {
-    if (tracks.empty()) return;
+uint64_t oldest_start(const covahip_gopfilter *g) {   // get_oldest_timestamp (cova/tracker.rs:85-90)
     uint64_t oldest = UINT64_MAX;
     for (const Tracker &t : g->sort->trackers) oldest = std::min(oldest, t.start);
+    return oldest;
+}
+void export_tracks(covahip_gopfilter *g, const std::vector<Tracker> &tracks, uint64_t oldest) {
+    if (tracks.empty()) return;
     for (const Tracker &t : tracks) {
         const size_t fl = covahip_frame_serialize(g->range_start, oldest, t.history.data(), t.history.size(), nullptr, 0, nullptr);
         const size_t at = g->track_wire.size();
@@ -810,7 +813,7 @@ int covahip_gopfilter_push_boxes(covahip_gopfilter *g, const covahip_bbox *boxes
     }
     std::vector<Tracker> dead;
     if (!g->sort->update(std::vector<covahip_bbox>(boxes, boxes + n), pts, dead)) return COVAHIP_ERR_BAD_DATA;
-    export_tracks(g, dead);
+    export_tracks(g, dead, oldest_start(g));   // after the update, over the trackers that are left (tracker.rs:51-58)
     bool have_min = !dead.empty();
     uint64_t min_track_pts = 0;
     for (const Tracker &t : dead)
@@ -939,7 +942,10 @@ int covahip_gopfilter_eos(covahip_gopfilter *g, covahip_au_out *out, size_t cap,
     }
     g->bufs.clear();
     g->dropped += dropped;
-    if (g->sort) export_tracks(g, g->sort->finalize());  // tracker.take().flush(): cova/tracker.rs:91-118
+    if (g->sort) {   // tracker.take().flush(): `oldest` over ALL live trackers, taken BEFORE finalize() removes the active ones (cova/tracker.rs:97-99)
+        const uint64_t oldest = oldest_start(g);
+        export_tracks(g, g->sort->finalize(), oldest);
+    }
     delete g->sort;
     g->sort = nullptr;
     if (n_out) *n_out = sink.n;

@@ -135,3 +135,38 @@ def test_every_access_unit_is_forwarded_or_reported_dropped_and_tracks_are_expor
     a = E.Associator([0])
     for f in frames:
         a.push_track_frame(f)                                     # the aggregator side parses them (track.rs:47-66)
+
+
+def test_tracks_flushed_at_eos_carry_the_oldest_start_taken_before_the_flush():
+    """cova/tracker.rs:91-118: flush() reads get_oldest_timestamp() BEFORE Sort::finalize() removes the active trackers, over
+    all live ones; the aggregator retires pending detections by Frame.oldest (analysis-aggregator assoc.rs finalize_dnn).
+    Two objects are still tracked when the stream ends: both EOS frames carry the start of the older one."""
+    import struct
+    n, gop = 500, 250
+    objects = [(10, 80, 5, 5, 0.4, 0.2, 6, 6), (100, n - 1, 60, 30, -0.05, 0.0, 8, 5), (300, n - 1, 10, 10, 0.1, 0.05, 7, 7)]
+    dets = _timeline(n, gop, objects)
+    c = E.Cova(sort_maxage=10, sort_minhits=5, sort_iou=0.1)
+    wire = b""
+    for i in range(n):
+        c.sink_enc_chain(i, i * CLK, delta_unit=(i % gop != 0))
+    for i in range(n):
+        c.sink_mask_chain(E.serialize_vec(_bb(dets[i])), i * CLK)
+        wire += c.take_track_export()
+    during = len(wire)
+    c.eos("sink_enc")
+    c.eos("sink_mask")
+    wire += c.take_track_export()
+    frames, off = [], 0
+    while off < len(wire):
+        (fl,) = struct.unpack_from(">I", wire, off)
+        frames.append((off >= during, wire[off + 4:off + 4 + fl]))
+        off += 4 + fl
+    at_eos = [f for late, f in frames if late]
+    assert len(frames) == 3 and len(at_eos) == 2
+    for f in at_eos:
+        range_start, oldest, nb = struct.unpack_from("<QQQ", f, 0)
+        assert range_start == 0 and oldest == 100 * CLK and nb > 5     # range_start = PTS of the first update (tracker.rs:45)
+    # the track that died during the stream (frame 91, before the second object appears): no tracker is left after that
+    # update, and the reference folds from u64::MAX (tracker.rs:85-90)
+    range_start, oldest, nb = struct.unpack_from("<QQQ", [f for late, f in frames if not late][0], 0)
+    assert oldest == 2 ** 64 - 1
