@@ -13,11 +13,6 @@ struct BnLevelGeom {
     int H, W;  // spatial size of the tensor at this level (level 0 = network input)
 };
 
-struct WalkGeom {   // plan of the time-walking level-0+1 kernel of the carrier-frame path (blobnet_mfma.hip)
-    int rb = 0, nbands = 0, TC0 = 0, TC1 = 0, tsz = 0;
-    size_t lds = 0;
-};
-
 // HBM workspace of one lane (internal.h, CtxLane): everything a forward in flight writes.  Lane 0's also serves the calls
 // that run on the ctx's primary stream.
 struct BnWorkspace {
@@ -28,14 +23,13 @@ struct BnWorkspace {
     // carrier-frame path: pooled level-0 values per carrier frame, [frames][H_1][W_1][16] (pad row / column zero)
     __half *pbuf = nullptr;
     size_t pbuf_frames = 0;
-    // stack -> frame index table of the call in flight, followed by the time-walk plan (order, items)
+    // stack -> frame index table of the call in flight
     int32_t *d_index = nullptr;
     int32_t *h_index = nullptr;       // pinned host copy it is uploaded from
     size_t index_ints = 0;            // capacity of both
     hipEvent_t ev_index = nullptr;    // upload of h_index done (the next call may overwrite it)
-    std::vector<int32_t> last_table;  // the table the resident plan was made from (an unchanged table is not re-planned)
-    int last_n_frames = 0, last_n_items = 0;
-    WalkGeom last_walk;
+    std::vector<int32_t> last_table;  // the table that is resident in d_index (an unchanged table is not uploaded again)
+    int last_n_frames = 0;
 };
 
 struct covahip_blobnet {
@@ -46,13 +40,11 @@ struct covahip_blobnet {
     int dec_co[BN_LEVELS] = {64, 32, 16, 16};
     int dec_cy[BN_LEVELS], dec_cx[BN_LEVELS];  // crop offsets (top/left) per decoder block
     BnWorkspace ws[COVAHIP_MAX_LANES];
-    int frames_impl = 0;              // developer switch: 0 = two kernels (default), 2 = time-walking level-0+1 kernel
     // prepared (MFMA path) weights
     void *d_prepared = nullptr;
     size_t prepared_bytes = 0;
     struct Prepared *prep = nullptr;
     int fuse_tail = 1;  // MFMA path, with bboxcc requested: last decoder block + bboxcc in one launch
-    int fuse01 = 0;  // MFMA path: encoder levels 0 and 1 as one kernel (default off: measured slower)
     int fuse_dec = 1;  // MFMA path: decoder blocks 0..2 as one launch (a frame's three input tiles side by side in LDS) when they fit
     int64_t macs_per_frame = 0;
 };
@@ -74,14 +66,7 @@ struct BnInput {
     const uint8_t *frames = nullptr;
     int n_frames = 0;
     const int32_t *index = nullptr;   // i32 [batch][4]
-    // time-walk plan (n_items == 0: the two-kernel form of the carrier-frame path)
-    const int32_t *order = nullptr;   // i32 [batch]
-    const int32_t *items = nullptr;   // i32 [n_items][4]
-    int n_items = 0;
-    WalkGeom walk;
     bool dry = false;
 };
-bool blobnet_plan_walk(const covahip_blobnet *m, int num_cu, const int32_t *idx, int batch, std::vector<int32_t> &order,
-                       std::vector<int32_t> &items, WalkGeom &g);
 int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, const BnInput &in, int batch, float *d_logits,
                          uint8_t *d_mask, const BnCcTail *cc = nullptr, bool *cc_done = nullptr);

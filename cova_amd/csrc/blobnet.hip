@@ -69,8 +69,8 @@ static int filter_dev(covahip_ctx *ctx, const BnInput &in, int batch, float *d_l
 }
 
 // Carrier-frame input: validates the stack -> frame table on the host (an index outside the frame array would be an
-// out-of-bounds read on the GPU), plans the time walk (chains of stacks that shift by one frame), uploads table and
-// plan.  stack_index == nullptr: one stream in order.  A table equal to the previous call's is not planned again.
+// out-of-bounds read on the GPU) and uploads it.  stack_index == nullptr: one stream in order.  A table equal to the
+// one resident in this lane's workspace is not uploaded again.
 static int prepare_frames(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, const uint8_t *d_frames, int n_frames,
                           const int32_t *stack_index, int batch, BnInput &in) {
     if (n_frames < BN_T || n_frames > BN_T * m->max_batch) return COVAHIP_ERR_INVALID_ARG;
@@ -84,13 +84,8 @@ static int prepare_frames(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws,
         }
     const bool same = ws.d_index && table == ws.last_table && n_frames == ws.last_n_frames;
     if (!same) {
-        std::vector<int32_t> order, items;
-        WalkGeom g;
-        const bool walk = m->frames_impl == 2 &&
-                          blobnet_plan_walk(m, ctx->props.multiProcessorCount, table.data(), batch, order, items, g);
-        if (!walk) { order.clear(); items.clear(); }
-        const size_t need = table.size() + order.size() + items.size();
-        if (ws.d_index) COVAHIP_CHECK_HIP(ctx, hipEventSynchronize(ws.ev_index));
+        const size_t need = table.size();
+        if (ws.d_index) COVAHIP_CHECK_HIP(ctx, hipEventSynchronize(ws.ev_index));   // the pinned copy is free again
         if (need > ws.index_ints) {
             if (ws.d_index) {
                 COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -99,33 +94,22 @@ static int prepare_frames(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws,
                 ws.d_index = nullptr; ws.h_index = nullptr; ws.index_ints = 0;
                 ws.last_table.clear();
             }
-            const size_t cap = std::max(need, (size_t)m->max_batch * 16);
+            const size_t cap = std::max(need, (size_t)m->max_batch * BN_T);
             COVAHIP_CHECK_HIP(ctx, hipMalloc((void **)&ws.d_index, cap * sizeof(int32_t)));
             COVAHIP_CHECK_HIP(ctx, hipHostMalloc((void **)&ws.h_index, cap * sizeof(int32_t), hipHostMallocDefault));
             ws.index_ints = cap;
             if (!ws.ev_index) COVAHIP_CHECK_HIP(ctx, hipEventCreateWithFlags(&ws.ev_index, hipEventDisableTiming));
         }
         std::copy(table.begin(), table.end(), ws.h_index);
-        std::copy(order.begin(), order.end(), ws.h_index + table.size());
-        std::copy(items.begin(), items.end(), ws.h_index + table.size() + order.size());
         COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(ws.d_index, ws.h_index, need * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
         COVAHIP_CHECK_HIP(ctx, hipEventRecord(ws.ev_index, ctx->stream));
         ws.last_table = std::move(table);
         ws.last_n_frames = n_frames;
-        ws.last_n_items = (int)(items.size() / 4);
-        ws.last_walk = g;
     }
     in.frames = d_frames;
     in.n_frames = n_frames;
     in.index = ws.d_index;
-    if (ws.last_n_items > 0) {
-        in.order = ws.d_index + (size_t)batch * BN_T;
-        in.items = in.order + batch;
-        in.n_items = ws.last_n_items;
-        in.walk = ws.last_walk;
-        return COVAHIP_OK;
-    }
-    // two-kernel form: the tensor P of pooled level-0 values, one slice per carrier frame
+    // the tensor P of pooled level-0 values, one slice per carrier frame
     if (ws.pbuf_frames < (size_t)n_frames) {
         // grown in whole steps; the pad row / column of P (odd grids) is zeroed here and never written
         const size_t want = std::min((size_t)BN_T * m->max_batch, std::max((size_t)n_frames, 2 * ws.pbuf_frames));
@@ -218,7 +202,7 @@ static int build_model(covahip_ctx *ctx, covahip_blobnet *m, const float *h_w, i
     plan.dry = true;
     for (int pass = 0; pass < 4 && !rc; pass++) {
         const int b = (pass & 1) ? max_batch : 1;
-        plan.n_frames = (pass & 2) ? b + BN_T - 1 : 0;   // the two-kernel form of the carrier-frame path must always fit
+        plan.n_frames = (pass & 2) ? b + BN_T - 1 : 0;   // both entry points
         rc = blobnet_forward_mfma(ctx, m, m->ws[0], plan, b, nullptr, nullptr, nullptr, nullptr);
     }
     return rc;
@@ -273,11 +257,8 @@ int covahip_blobnet_set_enc_plan(covahip_ctx *ctx, int level, int nbands, int nb
 
 int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl) {
     if (!ctx || !ctx->blobnet) return COVAHIP_ERR_NOT_LOADED;
-    if (impl < 1 || impl > 4) return COVAHIP_ERR_INVALID_ARG;
-    ctx->blobnet->fuse01 = impl == 2;
-    ctx->blobnet->frames_impl = impl == 3 ? 2 : 0;
+    if (impl != 1 && impl != 4) return COVAHIP_ERR_INVALID_ARG;
     ctx->blobnet->fuse_dec = impl != 4;
-    for (BnWorkspace &ws : ctx->blobnet->ws) ws.last_table.clear();   // the resident plans belong to the other form
     return COVAHIP_OK;
 }
 

@@ -173,11 +173,6 @@ __device__ __forceinline__ void tmix4h(const TmixW &w, const half4 pb, half4 &o)
     tmix4h<1>(w, pbs, os);
     o = os[0];
 }
-__device__ __forceinline__ void tmix4(const TmixW &w, const float (&p)[BN_T], half4 &o) {
-    const f32x4 pv = {p[0], p[1], p[2], p[3]};
-    tmix4h(w, __builtin_convertvector(pv, half4), o);
-}
-
 // Asynchronous 16-byte global -> LDS copy (LDS-DMA): every lane supplies its own global source
 // address, the data lands at lds_base (wave-uniform) + lane*16.  Completion is covered by the
 // an explicit wait_vmem() before the workgroup barrier.
@@ -730,7 +725,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
         const int y0 = 2 * ((band * p.Hp) / p.nbands);
         const int rows = 2 * (((band + 1) * p.Hp) / p.nbands) - y0;
         // opaque per-item copy of the lane id: keeps hipcc from hoisting (and, at level 3, spilling) the
-        // lane-only index math out of the item loop -- see enc01_mfma
+        // lane-only index math out of the item loop
         int ll = lane;
         asm volatile("" : "+v"(ll));
         uint8_t *const bandp = smem + cur * p.buf_stride;   // this item's band in LDS
@@ -959,546 +954,6 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     if (tid == 64 * (PHASE_WAVE < 0 ? NWV + PHASE_WAVE : PHASE_WAVE))
         for (int i = 0; i < 9; i++) atomicAdd(&g_phase[i + (PRE ? 0 : COUT == 64 ? 16 : COUT == 128 ? 32 : 48)], ph_[i]);
 #endif
-}
-
-// ------------------------------------------------------------------ enc levels 0 + 1 fused
-// Level 0's output is 4x the size of its input and level 1 reads it back with a halo: as two
-// kernels the pair moves ~235 MB per 256 frames and both are bound by that traffic.  Here a
-// workgroup takes (frame, band of level-1 pool-window rows), computes the level-0 rows the band
-// needs straight into level 1's LDS image A1 (same swizzled layout enc_mfma stages), and runs level 1
-// from there: HBM sees the u8 input, the T = 0 slice of level 0 (the last decoder block's skip
-// input) and level 1's output.  Level 0 is recomputed for the two halo rows of a band.
-//   LDS: RAW [T][raw_rows][W0] x 4 B    the item's u8 input rows, fetched by LDS-DMA while the previous
-//                                      item's level-1 tiles run (no registers, no exposed HBM latency)
-//        IN  [T][in_rows][TC0] x 8 B   level-0 input sub-band (fp16, as enc0_mfma), converted from RAW;
-//                                      reused as the per-wave output transpose scratch of level 1
-//        A1  [T][NR1][TC1] x 32 B      level-1 input band with halo and zero padding
-//        WL  13 KB                     weight fragments of both levels
-//   per item: wait for RAW, zero A1; for each sub-band of SB A1 rows: RAW -> IN, barrier, level-0
-//   tiles -> A1, barrier; then LDS-DMA of the next item's RAW, T = 0 rows of A1 -> HBM and
-//   level-1 tiles -> HBM.
-struct Enc01Args {
-    const uint8_t *in;   // [B][T][H0][W0][4]
-    __half *skip;        // level-0 output tensor [B][T][H1][W1][16]; only t = 0 is written
-    __half *out;         // level-1 output [B][T][H2][W2][32]
-    const half8 *w0frag, *w1frag;
-    const float *epi0, *epi1;
-    int B, H0, W0, Hp0, Wp0, oy0, ox0;
-    int H1, W1, Hp1, Wp1, oy1, ox1, H2, W2;
-    int nbands, TC0, TC1, NR1, SB, in_rows, a1_off, wl_off, raw_off;
-    uint32_t mNb, mW4, mWp0, mWp1, mW1;
-    const void *zero;   // >= 16 zero bytes in global memory (source of out-of-image rows)
-};
-
-constexpr int WG01 = 1024;   // 16 waves, one workgroup per CU
-template <bool ALLPOS0, bool ALLPOS1>
-__global__ __launch_bounds__(WG01, 4) void enc01_mfma(Enc01Args p) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int TC0 = p.TC0, TC1 = p.TC1;
-    const int tsz0 = p.in_rows * TC0 * 8;    // bytes per T slice of IN
-    const int tsz1 = p.NR1 * TC1 * 32;       // bytes per T slice of A1
-    uint8_t *const a1 = smem + p.a1_off;
-
-    // The weight fragments (4 + 9 per lane) and epilogue constants of both levels are parked in LDS
-    // once and pulled into registers at the start of each phase, so that the two sets are never live
-    // together (128 VGPRs per lane at 16 waves per CU, no scratch).
-    half8 *const wl = reinterpret_cast<half8 *>(smem + p.wl_off);
-    float *const cl = reinterpret_cast<float *>(smem + p.wl_off + 13 * 1024);   // epi0[80] | epi1[128]
-    for (int i = tid; i < 13 * 64; i += WG01) wl[i] = i < 256 ? p.w0frag[i] : p.w1frag[i - 256];
-    if (tid < 208) cl[tid] = tid < 80 ? p.epi0[tid] : p.epi1[tid - 80];
-
-    const int W4 = p.W0 >> 2;
-    const size_t tplane0 = (size_t)p.H0 * p.W0 * 4;
-    const half2v clip = {(_Float16)1030.f, (_Float16)1030.f}, off1024 = {(_Float16)1024.f, (_Float16)1024.f};
-
-    uint8_t *const raw = smem + p.raw_off;
-    // input rows an item needs: [y_first, y_first + n_raw); issue their LDS-DMA, linear [t][row][16-byte chunk]
-    auto dma_raw = [&](int item) {
-        const int b = fdiv(item, p.mNb), band = item - b * p.nbands;
-        const int w0 = (band * p.Hp1) / p.nbands, w1 = ((band + 1) * p.Hp1) / p.nbands;
-        const int a_base = 2 * w0 - 1, n2 = 2 * (w1 - w0) + 2;
-        const int r_lo = max(0, p.oy0 - a_base), r_hi = min(n2, p.H1 - a_base);
-        const int y_first = 2 * (a_base + r_lo - p.oy0) - 1, n_raw = 2 * (r_hi - r_lo) + 2;
-        const int per_t = n_raw * W4, total = BN_T * per_t;
-        const uint8_t *fb = p.in + (size_t)b * BN_T * tplane0;
-        for (int s0 = wave * 64; s0 < total; s0 += WG01) {
-            const int i = s0 + lane;
-            if (i < total) {
-                const int t = (i >= per_t) + (i >= 2 * per_t) + (i >= 3 * per_t), rem = i - t * per_t;
-                const int r = fdiv(rem, p.mW4), c4 = rem - r * W4;
-                const int y = y_first + r;
-                const void *src = (y >= 0 && y < p.H0) ? (const void *)(fb + t * tplane0 + ((size_t)y * p.W0 + c4 * 4) * 4) : p.zero;
-                glds16(src, raw + s0 * 16);
-            }
-        }
-    };
-
-    const int n_items = p.B * p.nbands;
-    if ((int)blockIdx.x < n_items) dma_raw(blockIdx.x);
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int b = fdiv(item, p.mNb), band = item - b * p.nbands;
-        const int w0 = (band * p.Hp1) / p.nbands, w1 = ((band + 1) * p.Hp1) / p.nbands;
-        const int rb = w1 - w0, n2 = 2 * rb + 2;
-        const int a_base = 2 * w0 - 1;                        // level-0 output row of A1 row 0
-        const int r_lo = max(0, p.oy0 - a_base), r_hi = min(n2, p.H1 - a_base);   // A1 rows that hold data
-        const int y_first = 2 * (a_base + r_lo - p.oy0) - 1, n_raw = 2 * (r_hi - r_lo) + 2;
-        // Per-lane index math below depends only on the lane; re-deriving it per item from an opaque copy
-        // keeps hipcc from hoisting a few dozen loop-invariant registers out of the item loop (they
-        // would be spilled to scratch, and a kernel with scratch pays ~90 us per launch here).
-        int ll = lane;
-        asm volatile("" : "+v"(ll));
-        const int tv = (wave << 6) | ll;
-        wait_vmem();     // this item's RAW has landed
-        lds_barrier();   // ... for every wave; the previous item's level-1 tiles are done with A1 and the scratch
-        for (int i = tv; i < (BN_T * tsz1) / 16; i += WG01) reinterpret_cast<uint4 *>(a1)[i] = make_uint4(0, 0, 0, 0);
-
-        for (int r0 = r_lo; r0 < r_hi; r0 += p.SB) {
-            const int cnt = min(p.SB, r_hi - r0);             // level-0 pool rows of this sub-band
-            const int pr0 = a_base + r0 - p.oy0;              // first pool row
-            const int yin0 = 2 * pr0 - 1, nin = 2 * cnt + 2;  // input rows [yin0, yin0 + nin)
-            // ---- RAW -> IN: u8 -> fp16 with the clip at 6 (see enc0_mfma)
-            {
-                const int per_t = nin * W4;
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const int i = tv + k * WG01;
-                    if (i < per_t) {
-                        const int r = fdiv(i, p.mW4), c4 = i - r * W4;
-                        const int dsto = r * TC0 * 8 + 16 + c4 * 32;
-                        const uint8_t *src = raw + ((yin0 - y_first + r) * W4 + c4) * 16;
-                        uint4 v[BN_T];
-#pragma unroll
-                        for (int t = 0; t < BN_T; t++) v[t] = *reinterpret_cast<const uint4 *>(src + t * n_raw * W4 * 16);
-#pragma unroll
-                        for (int t = 0; t < BN_T; t++) {
-                            const uint32_t px[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
-                            uint32_t o[8];
-#pragma unroll
-                            for (int q = 0; q < 4; q++) {
-                                const uint32_t c01 = __builtin_amdgcn_perm(0x64646464u, px[q], 0x05010500u);
-                                const uint32_t c23 = __builtin_amdgcn_perm(0x64646464u, px[q], 0x05030502u);
-                                const half2v h01 = __builtin_elementwise_min(__builtin_bit_cast(half2v, c01), clip) - off1024;
-                                const half2v h23 = __builtin_elementwise_min(__builtin_bit_cast(half2v, c23), clip) - off1024;
-                                o[2 * q] = __builtin_bit_cast(uint32_t, h01);
-                                o[2 * q + 1] = __builtin_bit_cast(uint32_t, h23);
-                            }
-                            uint8_t *d = smem + t * tsz0 + dsto;
-                            *reinterpret_cast<uint4 *>(d) = make_uint4(o[0], o[1], o[2], o[3]);
-                            *reinterpret_cast<uint4 *>(d + 16) = make_uint4(o[4], o[5], o[6], o[7]);
-                        }
-                    }
-                }
-                for (int i = tv; i < BN_T * nin * 2; i += WG01) {   // zero halo columns 0,1 and W+2,W+3
-                    const int rr = i >> 1;
-                    const int t = (rr >= nin) + (rr >= 2 * nin) + (rr >= 3 * nin);
-                    const int r = rr - t * nin;
-                    *reinterpret_cast<uint4 *>(smem + t * tsz0 + r * TC0 * 8 + ((i & 1) ? (p.W0 + 2) * 8 : 0)) =
-                        make_uint4(0, 0, 0, 0);
-                }
-            }
-            lds_barrier();
-            // ---- level-0 tiles of 8 pool windows (see enc0_mfma) -> A1
-            {
-                // level-0 weights: even-x / odd-x sets, two K-steps each; epilogue constants of channel lane & 15
-                const half8 be0 = wl[ll], be1 = wl[64 + ll], bo0 = wl[128 + ll], bo1 = wl[192 + ll];
-                const int co0 = ll & 15;
-                const float f0 = cl[co0], f1 = cl[16 + co0], f2 = cl[32 + co0];
-                const TmixW tm0 = load_tmix(cl + 48, ll);
-                const int nwin = cnt * p.Wp0;
-                const int ntiles = (nwin + 7) / 8;
-                const int m = ll & 15, g = ll >> 4;
-                for (int tile = wave; tile < ntiles; tile += WG01 / 64) {
-                    const int win = min(tile * 8 + (m >> 1), nwin - 1);
-                    const int wy = fdiv(win, p.mWp0), wx = win - wy * p.Wp0;
-                    const int yy = 2 * wy + (m & 1), xe = 2 * wx;
-                    const int offe0 = ((yy + (g >> 1)) * TC0 + xe + 2 * (g & 1)) * 8;
-                    const int offe1 = ((yy + 2) * TC0 + xe + 2 * (g & 1)) * 8;
-                    float pooled[2][BN_T];
-#pragma unroll
-                    for (int t = 0; t < BN_T; t++) {
-                        const uint8_t *base = smem + t * tsz0;
-                        const half8 ae0 = *reinterpret_cast<const half8 *>(base + offe0);
-                        const half8 ae1 = *reinterpret_cast<const half8 *>(base + offe1);
-                        const half8 ao0 = *reinterpret_cast<const half8 *>(base + offe0 + 16);
-                        const half8 ao1 = *reinterpret_cast<const half8 *>(base + offe1 + 16);
-                        f32x4 ce = {0.f, 0.f, 0.f, 0.f}, co_ = {0.f, 0.f, 0.f, 0.f};
-                        ce = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae0, be0, ce, 0, 0, 0);
-                        co_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao0, bo0, co_, 0, 0, 0);
-                        ce = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae1, be1, ce, 0, 0, 0);
-                        co_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao1, bo1, co_, 0, 0, 0);
-                        pooled[0][t] = pool4<ALLPOS0>(ce[0], ce[1], co_[0], co_[1], f0, f1, f2);
-                        pooled[1][t] = pool4<ALLPOS0>(ce[2], ce[3], co_[2], co_[3], f0, f1, f2);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        half4 o;
-                        tmix4(tm0, pooled[q], o);
-                        const int owin = tile * 8 + 2 * g + q;
-                        if (owin < nwin) {
-                            const int owy = fdiv(owin, p.mWp0), owx = owin - owy * p.Wp0;
-                            const int r = r0 + owy, c = owx + p.ox0 + 1;          // A1 coordinates
-                            // pixel = two 16-byte chunks, physical chunk = logical ^ (row & 1)  (enc_swz<16>)
-                            uint8_t *d = a1 + (r * TC1 + c) * 32 + (((co0 >> 3) ^ (r & 1)) * 16) + (co0 & 7) * 2;
-#pragma unroll
-                            for (int t = 0; t < BN_T; t++) *reinterpret_cast<_Float16 *>(d + t * tsz1) = o[t];
-                        }
-                    }
-                }
-            }
-            lds_barrier();
-        }
-        // ---- RAW is consumed: fetch the next item's rows behind the level-1 phase
-        if (item + (int)gridDim.x < n_items) dma_raw(item + gridDim.x);
-        // ---- T = 0 rows of the band proper -> level-0 tensor in HBM (skip input of the last decoder block)
-        {
-            const int ra = 2 * w0, rbnd = (band == p.nbands - 1) ? p.H1 : 2 * w1;   // level-0 output rows [ra, rbnd)
-            const int nch = (rbnd - ra) * p.W1 * 2;                                 // 16-byte chunks
-            __half *const sk = p.skip + (size_t)b * BN_T * p.H1 * p.W1 * 16;
-            for (int i = tv; i < nch; i += WG01) {
-                const int pix = i >> 1, ch = i & 1;
-                const int ry = fdiv(pix, p.mW1), x = pix - ry * p.W1;
-                const int r = ra + ry - a_base;                                     // A1 row
-                const uint4 v = *reinterpret_cast<const uint4 *>(a1 + (r * TC1 + x + 1) * 32 + ((ch ^ (r & 1)) * 16));
-                *reinterpret_cast<uint4 *>(sk + ((size_t)(ra + ry) * p.W1 + x) * 16 + ch * 8) = v;
-            }
-        }
-        // ---- level-1 tiles of 8 pool windows (see enc_mfma<16, 32>), one M-group per wave
-        {
-            half8 bf[9];   // one weight fragment per tap (16 input channels); epilogue constants of channel lane & 31
-#pragma unroll
-            for (int ks = 0; ks < 9; ks++) bf[ks] = wl[256 + ks * 64 + ll];
-            const int co1 = ll & 31;
-            const float e0 = cl[80 + co1], e1 = cl[80 + 32 + co1], e2 = cl[80 + 64 + co1];
-            const TmixW tm1 = load_tmix(cl + 80 + 96, ll);
-            const int nwin = rb * p.Wp1;
-            const int ntiles = (nwin + 7) / 8;
-            const int m = ll & 31, kh = ll >> 5;
-            uint8_t *const scr = smem + wave * 2048;
-            const uint32_t tstride = (uint32_t)(p.H2 * p.W2 * 32);
-            __half *const ob = p.out + (size_t)b * BN_T * tstride;
-            for (int tile = wave; tile < ntiles; tile += WG01 / 64) {
-                const int win = min(tile * 8 + (m >> 2), nwin - 1);
-                const int wy = fdiv(win, p.mWp1), wx = win - wy * p.Wp1;
-                const int yy0 = 2 * wy + ((m >> 1) & 1), xx0 = 2 * wx + (m & 1);
-                float pooled4[BN_T][4];
-#pragma unroll
-                for (int t = 0; t < BN_T; t++) {
-                    f32x16 acc;
-#pragma unroll
-                    for (int r = 0; r < 16; r++) acc[r] = 0.f;
-#pragma unroll
-                    for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-                        for (int kx = 0; kx < 3; kx++) {
-                            const int yy = yy0 + ky, xx = xx0 + kx;
-                            const half8 a = *reinterpret_cast<const half8 *>(a1 + t * tsz1 + (yy * TC1 + xx) * 32 + ((kh ^ (yy & 1)) * 16));
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[ky * 3 + kx], acc, 0, 0, 0);
-                        }
-#pragma unroll
-                    for (int g = 0; g < 4; g++)
-                        pooled4[t][g] = pool4<ALLPOS1>(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], e0, e1, e2);
-                }
-#pragma unroll
-                for (int t = 0; t < BN_T; t++)
-#pragma unroll
-                    for (int g = 0; g < 4; g++) asm volatile("" : "+v"(pooled4[t][g]));
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    float pooled[BN_T];
-                    half4 o;
-#pragma unroll
-                    for (int t = 0; t < BN_T; t++) pooled[t] = pooled4[t][g];
-                    tmix4(tm1, pooled, o);
-                    _Float16 *sw = reinterpret_cast<_Float16 *>(scr + (2 * g + kh) * 64) + co1;
-#pragma unroll
-                    for (int t = 0; t < BN_T; t++) sw[t * 256] = o[t];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int owin = tile * 8 + ((ll >> 2) & 7);
-                if (owin < nwin) {
-                    const int owy = fdiv(owin, p.mWp1), owx = owin - owy * p.Wp1;
-                    const int gy = w0 + owy + p.oy1, gx = owx + p.ox1;
-                    const uint32_t eo = (uint32_t)((gy * p.W2 + gx) * 32 + 8 * (ll & 3));
-#pragma unroll
-                    for (int j = 0; j < 2; j++) {
-                        const uint4 v = *reinterpret_cast<const uint4 *>(scr + (j * 64 + ll) * 16);
-                        *reinterpret_cast<uint4 *>(ob + (2 * j + (ll >> 5)) * tstride + eo) = v;
-                    }
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------ enc levels 0 + 1, walking along a stream
-// Carrier-frame path, single-launch form (developer switch; measured SLOWER than the two-kernel form on MI355X: 96 vs
-// 59 us at b = 256 -- every step is a chain of four short, barrier-separated phases on eight waves, and their
-// latencies add up).  A workgroup owns a band of level-1 rows of ONE stream and walks along time:
-// consecutive stacks of a stream share three of their four slices, so per step it
-//   (a) stages the band's input rows of the ONE new carrier frame (u8 -> fp16, as enc0_mfma),
-//   (c) runs level 0 up to the pool for that one slice into an LDS buffer P (level 1's tile layout),
-//   (e) applies level 0's temporal MLP over the four newest P buffers -> the four T slices of level 1's input A1,
-//   (g) writes A1's T = 0 rows to the skip tensor and runs the level-1 tiles (enc_mfma<16, 32>) from LDS.
-// HBM sees each carrier frame's band once (plus halo rows), the skip slice and level 1's output: level 0's output
-// never leaves the CU, its convolution runs once per carrier frame (x the band halo) instead of four times.
-//   LDS: 7 buffers of one T slice of the band (n2 rows x TC1 x 32 B): three P buffers stay alive from step to step,
-//   the fourth (oldest) is overwritten in place by A1's T = 3, three more take A1's T = 0..2; with step n the roles
-//   rotate: P of age a sits in buffer (3 - a + n) % 7, A1[t] in (4 + t + n) % 7 for t < 3 and n % 7 for t = 3.
-//   Behind them the input tile of one slice, reused as the per-wave store scratch of level 1.
-// An item = (chain chunk, band): `count` consecutive stacks of a chain (order[first ..]) whose index rows shift by one
-// (host: plan_chains); the first stack of a chunk computes all four of its slices (k = -3 .. 0).  Any index table
-// works -- chains of length one degenerate to four level-0 passes per stack.
-// Same tiles, MFMA operand order and rounding points as enc0_mfma / enc_mfma<16, 32>: bit-identical results.
-struct Enc01wArgs {
-    const uint8_t *frames;   // [F][H0][W0][4]
-    const int32_t *pidx;     // [B][4]
-    const int32_t *order;    // [B] stacks in chain order
-    const int4 *items;       // {first, count, band, 0}
-    __half *skip;            // level-0 output tensor [B][T][H1][W1][16]; only t = 0 is written
-    __half *out;             // level-1 output [B][T][H2][W2][32]
-    const half8 *w0frag, *w1frag;
-    const float *epi0, *epi1;
-    int n_items;
-    int H0, W0, Hp0, Wp0, oy0, ox0;
-    int H1, W1, Hp1, Wp1, oy1, ox1, H2, W2;
-    int nbands, TC0, TC1, tsz;
-    uint32_t mW4, mWp0, mWp1, mW1, mTC1;
-    Swz swz;                 // level-1 tile swizzle (CPP = 2)
-};
-
-template <bool ALLPOS0, bool ALLPOS1>
-__global__ __launch_bounds__(512, 2) void enc01w_mfma(Enc01wArgs p) {
-    constexpr int WGS = 512, NWV = 8;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int TC0 = p.TC0, TC1 = p.TC1, tsz = p.tsz;
-    uint8_t *const inb = smem + 7 * tsz;   // input tile of one slice; later the per-wave store scratch
-
-    // level-0 weights (even-x / odd-x sets, two K-steps each) and epilogue constants of channel lane & 15
-    const half8 be0 = p.w0frag[lane], be1 = p.w0frag[64 + lane], bo0 = p.w0frag[128 + lane], bo1 = p.w0frag[192 + lane];
-    const int co0 = lane & 15;
-    const float f0 = p.epi0[co0], f1 = p.epi0[16 + co0], f2 = p.epi0[32 + co0];
-    const TmixW tm0 = load_tmix(p.epi0 + 48, lane);
-    // level-1 weights: one fragment per tap (16 input channels), epilogue constants of channel lane & 31
-    half8 bf[9];
-#pragma unroll
-    for (int ks = 0; ks < 9; ks++) bf[ks] = p.w1frag[ks * 64 + lane];
-    const int co1 = lane & 31;
-    const float e0 = p.epi1[co1], e1 = p.epi1[32 + co1], e2 = p.epi1[64 + co1];
-    const TmixW tm1 = load_tmix(p.epi1 + 96, lane);
-
-    const int W4 = p.W0 >> 2;
-    const size_t fplane = (size_t)p.H0 * p.W0 * 4;
-    const half2v clip = {(_Float16)1030.f, (_Float16)1030.f}, off1024 = {(_Float16)1024.f, (_Float16)1024.f};
-
-    for (int item = blockIdx.x; item < p.n_items; item += gridDim.x) {
-        const int4 it = p.items[item];
-        const int first = it.x, count = it.y, band = it.z;
-        const int w0 = (band * p.Hp1) / p.nbands, w1 = ((band + 1) * p.Hp1) / p.nbands;
-        const int rb = w1 - w0, n2 = 2 * rb + 2;
-        const int a_base = 2 * w0 - 1;                                            // level-0 output row of A1 row 0
-        const int r_lo = max(0, p.oy0 - a_base), r_hi = min(n2, p.H1 - a_base);   // A1 rows that hold data
-        const int npr = r_hi - r_lo;                                              // level-0 pool rows of the band
-        const int pr0 = a_base + r_lo - p.oy0;                                    // first pool row
-        const int yin0 = 2 * pr0 - 1, nin = 2 * npr + 2;                          // input rows [yin0, yin0 + nin)
-        for (int k = -(BN_T - 1); k < count; k++) {
-            // k < 0: the three older slices of the chunk's first stack (ages 3, 2, 1); k >= 0: the newest slice of stack k
-            const int b = p.order[first + max(k, 0)];
-            const int age = k < 0 ? -k : 0, n = max(k, 0);
-            const int frame = p.pidx[b * BN_T + age];
-            uint8_t *const pnew = smem + ((BN_T - 1 - age + n) % 7) * tsz;
-            int ll = lane;   // opaque per-step copy of the lane id (see enc_mfma: keeps lane-only index math inside the loop)
-            asm volatile("" : "+v"(ll));
-            lds_barrier();   // every wave is done with the input tile / scratch and with the buffer pnew
-            // ---- (a) input rows of the new slice -> fp16 tile (see enc0_mfma); zero halo columns
-            {
-                const int per = nin * W4;
-                const uint8_t *fb = p.frames + (size_t)frame * fplane;
-                for (int i = tid; i < per; i += WGS) {
-                    const int r = fdiv(i, p.mW4), c4 = i - r * W4;
-                    const int y = yin0 + r;
-                    const uint4 v = (y >= 0 && y < p.H0) ? *reinterpret_cast<const uint4 *>(fb + ((size_t)y * p.W0 + c4 * 4) * 4)
-                                                         : make_uint4(0, 0, 0, 0);
-                    const uint32_t px[4] = {v.x, v.y, v.z, v.w};
-                    uint32_t o[8];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const uint32_t c01 = __builtin_amdgcn_perm(0x64646464u, px[q], 0x05010500u);
-                        const uint32_t c23 = __builtin_amdgcn_perm(0x64646464u, px[q], 0x05030502u);
-                        const half2v h01 = __builtin_elementwise_min(__builtin_bit_cast(half2v, c01), clip) - off1024;
-                        const half2v h23 = __builtin_elementwise_min(__builtin_bit_cast(half2v, c23), clip) - off1024;
-                        o[2 * q] = __builtin_bit_cast(uint32_t, h01);
-                        o[2 * q + 1] = __builtin_bit_cast(uint32_t, h23);
-                    }
-                    uint8_t *d = inb + r * TC0 * 8 + 16 + c4 * 32;
-                    *reinterpret_cast<uint4 *>(d) = make_uint4(o[0], o[1], o[2], o[3]);
-                    *reinterpret_cast<uint4 *>(d + 16) = make_uint4(o[4], o[5], o[6], o[7]);
-                }
-                for (int i = tid; i < nin * 2; i += WGS)
-                    *reinterpret_cast<uint4 *>(inb + (i >> 1) * TC0 * 8 + ((i & 1) ? (p.W0 + 2) * 8 : 0)) = make_uint4(0, 0, 0, 0);
-                // ---- the part of pnew the level-0 tiles do not write: rows without data, the zero columns left / right
-                // (and the pad column of an odd grid)
-                for (int i = tid; i < n2 * TC1 * 2; i += WGS) {
-                    const int pix = i >> 1;
-                    const int r = fdiv(pix, p.mTC1), c = pix - r * TC1;
-                    if (r < r_lo || r >= r_hi || c <= p.ox0 || c == TC1 - 1)
-                        *reinterpret_cast<uint4 *>(pnew + i * 16) = make_uint4(0, 0, 0, 0);
-                }
-            }
-            lds_barrier();
-            // ---- (c) level-0 tiles of 8 pool windows (enc0_mfma) for this ONE slice -> pnew in level 1's layout
-            {
-                const int nwin = npr * p.Wp0;
-                const int ntiles = (nwin + 7) / 8;
-                const int m = ll & 15, g = ll >> 4;
-                for (int tile = wave; tile < ntiles; tile += NWV) {
-                    const int win = min(tile * 8 + (m >> 1), nwin - 1);
-                    const int wy = fdiv(win, p.mWp0), wx = win - wy * p.Wp0;
-                    const int yy = 2 * wy + (m & 1), xe = 2 * wx;
-                    const int offe0 = ((yy + (g >> 1)) * TC0 + xe + 2 * (g & 1)) * 8;
-                    const int offe1 = ((yy + 2) * TC0 + xe + 2 * (g & 1)) * 8;
-                    const half8 ae0 = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(inb + offe0, 16));
-                    const half8 ae1 = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(inb + offe1, 16));
-                    const half8 ao0 = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(inb + offe0 + 16, 16));
-                    const half8 ao1 = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(inb + offe1 + 16, 16));
-                    f32x4 ce = {0.f, 0.f, 0.f, 0.f}, co_ = {0.f, 0.f, 0.f, 0.f};
-                    ce = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae0, be0, ce, 0, 0, 0);
-                    co_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao0, bo0, co_, 0, 0, 0);
-                    ce = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae1, be1, ce, 0, 0, 0);
-                    co_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao1, bo1, co_, 0, 0, 0);
-                    float v[2];
-                    v[0] = pool4<ALLPOS0>(ce[0], ce[1], co_[0], co_[1], f0, f1, f2);
-                    v[1] = pool4<ALLPOS0>(ce[2], ce[3], co_[2], co_[3], f0, f1, f2);
-                    asm volatile("" : "+v"(v[0]), "+v"(v[1]));   // fp32 first, then fp16: the rounding of enc0_mfma (see enc0p_mfma)
-#pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        const int owin = tile * 8 + 2 * g + q;
-                        if (owin < nwin) {
-                            const int owy = fdiv(owin, p.mWp0), owx = owin - owy * p.Wp0;
-                            const int r = r_lo + owy, c = owx + p.ox0 + 1;
-                            *reinterpret_cast<_Float16 *>(pnew + (r * TC1 + c) * 32 + (((co0 >> 3) ^ swz_eval<2>(p.swz, c, r)) * 16) +
-                                                          (co0 & 7) * 2) = (_Float16)v[q];
-                        }
-                    }
-                }
-            }
-            if (k < 0) continue;
-            lds_barrier();
-            // ---- (e) temporal MLP of level 0 over the four newest slices -> level 1's input (T = 3 in place)
-            uint8_t *ab[BN_T];
-            {
-                const uint8_t *pb[BN_T];
-#pragma unroll
-                for (int t = 0; t < BN_T; t++) {
-                    pb[t] = smem + ((BN_T - 1 - t + n) % 7) * tsz;
-                    ab[t] = smem + ((t < BN_T - 1 ? BN_T + t + n : n) % 7) * tsz;
-                }
-                for (int sidx = tid; sidx < n2 * TC1 * 2; sidx += WGS) {
-                    half8 v[BN_T], o[BN_T];
-#pragma unroll
-                    for (int t = 0; t < BN_T; t++) v[t] = *reinterpret_cast<const half8 *>(pb[t] + sidx * 16);
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const half4 hb = {v[0][j], v[1][j], v[2][j], v[3][j]};
-                        half4 r;
-                        tmix4h(tm0, hb, r);
-#pragma unroll
-                        for (int t = 0; t < BN_T; t++) o[t][j] = r[t];
-                    }
-#pragma unroll
-                    for (int t = 0; t < BN_T; t++) *reinterpret_cast<half8 *>(ab[t] + sidx * 16) = o[t];
-                }
-            }
-            lds_barrier();
-            // ---- (g) T = 0 rows of the band proper -> skip tensor (the last band also owns the odd last row)
-            {
-                const int ra = 2 * w0, rbnd = (band == p.nbands - 1) ? p.H1 : 2 * w1;
-                const int nch = (rbnd - ra) * p.W1 * 2;
-                __half *const sk = p.skip + (size_t)b * BN_T * p.H1 * p.W1 * 16;
-                for (int i = tid; i < nch; i += WGS) {
-                    const int pix = i >> 1, ch = i & 1;
-                    const int ry = fdiv(pix, p.mW1), x = pix - ry * p.W1;
-                    const int r = ra + ry - a_base, c = x + 1;
-                    const uint4 v = *reinterpret_cast<const uint4 *>(ab[0] + (r * TC1 + c) * 32 + ((ch ^ swz_eval<2>(p.swz, c, r)) * 16));
-                    *reinterpret_cast<uint4 *>(sk + ((size_t)(ra + ry) * p.W1 + x) * 16 + ch * 8) = v;
-                }
-            }
-            // ---- level-1 tiles of 8 pool windows (enc_mfma<16, 32>): one M-group per wave
-            {
-                const int nwin = rb * p.Wp1;
-                const int ntiles = (nwin + 7) / 8;
-                const int m = ll & 31, kh = ll >> 5;
-                uint8_t *const scr = inb + wave * 2048;
-                const uint32_t tstride = (uint32_t)(p.H2 * p.W2 * 32);
-                __half *const ob = p.out + (size_t)b * BN_T * tstride;
-                for (int tile = wave; tile < ntiles; tile += NWV) {
-                    const int win = min(tile * 8 + (m >> 2), nwin - 1);
-                    const int wy = fdiv(win, p.mWp1), wx = win - wy * p.Wp1;
-                    const int yy0 = 2 * wy + ((m >> 1) & 1), xx0 = 2 * wx + (m & 1);
-                    float pooled4[BN_T][4];
-#pragma unroll
-                    for (int t0 = 0; t0 < BN_T; t0 += 2) {
-                        f32x16 acc[2];
-#pragma unroll
-                        for (int t = 0; t < 2; t++)
-#pragma unroll
-                            for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
-#pragma unroll
-                        for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-                            for (int kx = 0; kx < 3; kx++) {
-                                const int yy = yy0 + ky, xx = xx0 + kx;
-                                const int off = (yy * TC1 + xx) * 32 + ((kh ^ swz_eval<2>(p.swz, xx, yy)) * 16);
-#pragma unroll
-                                for (int t = 0; t < 2; t++) {
-                                    const half8 a = *reinterpret_cast<const half8 *>(ab[t0 + t] + off);
-                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[ky * 3 + kx], acc[t], 0, 0, 0);
-                                }
-                            }
-#pragma unroll
-                        for (int t = 0; t < 2; t++)
-#pragma unroll
-                            for (int g = 0; g < 4; g++)
-                                pooled4[t0 + t][g] = pool4<ALLPOS1>(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3], e0, e1, e2);
-                    }
-#pragma unroll
-                    for (int t = 0; t < BN_T; t++)
-#pragma unroll
-                        for (int g = 0; g < 4; g++) asm volatile("" : "+v"(pooled4[t][g]));
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        float pooled[BN_T];
-                        half4 o;
-#pragma unroll
-                        for (int t = 0; t < BN_T; t++) pooled[t] = pooled4[t][g];
-                        tmix4(tm1, pooled, o);
-                        _Float16 *sw = reinterpret_cast<_Float16 *>(scr + (2 * g + kh) * 64) + co1;
-#pragma unroll
-                        for (int t = 0; t < BN_T; t++) sw[t * 256] = o[t];
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const int owin = tile * 8 + ((ll >> 2) & 7);
-                    if (owin < nwin) {
-                        const int owy = fdiv(owin, p.mWp1), owx = owin - owy * p.Wp1;
-                        const int gy = w0 + owy + p.oy1, gx = owx + p.ox1;
-                        const uint32_t eo = (uint32_t)((gy * p.W2 + gx) * 32 + 8 * (ll & 3));
-#pragma unroll
-                        for (int j = 0; j < 2; j++) {
-                            const uint4 v = *reinterpret_cast<const uint4 *>(scr + (j * 64 + ll) * 16);
-                            *reinterpret_cast<uint4 *>(ob + (2 * j + (ll >> 5)) * tstride + eo) = v;
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next tile's values stay behind these reads
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-        }
-    }
 }
 
 // ------------------------------------------------------------------ decoder blocks 0..3
@@ -2298,91 +1753,6 @@ int set_lds(covahip_ctx *ctx, K kernel, size_t lds) {
 
 }  // namespace
 
-// ---- carrier-frame path: plan of the time-walking level-0+1 kernel (enc01w_mfma)
-// Geometry: the tallest band of level-1 window rows (rb <= 3) whose level-1 tiles fit one pass of the 8 waves and
-// whose seven slice buffers + input tile fit LDS.
-static bool walk_geometry(const covahip_blobnet *m, WalkGeom &g) {
-    const int H0 = m->lv[0].H, W0 = m->lv[0].W, H1 = m->lv[1].H, W1 = m->lv[1].W;
-    if (W0 % 4) return false;
-    const int Hp1 = H1 / 2, Wp1 = W1 / 2;
-    const int TC0 = ((W0 + 4 - 16 + 31) / 32) * 32 + 16, TC1 = W1 + 2;
-    for (int rb = std::min(3, Hp1); rb >= 1; rb--) {
-        const int n2 = 2 * rb + 2;
-        if ((rb * Wp1 + 7) / 8 > 8) continue;
-        const size_t tsz = (size_t)n2 * TC1 * 32;
-        const size_t inb = std::max((size_t)(2 * n2 + 2) * TC0 * 8, (size_t)8 * 2048);
-        if (7 * tsz + inb > 160 * 1024 - 512) continue;
-        g.rb = rb; g.nbands = (Hp1 + rb - 1) / rb; g.TC0 = TC0; g.TC1 = TC1; g.tsz = (int)tsz; g.lds = 7 * tsz + inb;
-        (void)H0;
-        return true;
-    }
-    return false;
-}
-
-// Chains of stacks whose index rows shift by one (stack y follows stack x when y's slices 1..3 are x's slices 0..2),
-// cut into chunks so that the items (chunk x band) fill the CUs: minimises rounds x (chunk length + warm-up).
-bool blobnet_plan_walk(const covahip_blobnet *m, int num_cu, const int32_t *idx, int batch, std::vector<int32_t> &order,
-                       std::vector<int32_t> &items /* 4 ints each */, WalkGeom &g) {
-    if (!walk_geometry(m, g)) return false;
-    std::vector<int> succ(batch, -1), has_pred(batch, 0);
-    {
-        struct Key { int32_t a, b, c; int x; };
-        std::vector<Key> keys(batch);
-        for (int x = 0; x < batch; x++) keys[x] = Key{idx[4 * x], idx[4 * x + 1], idx[4 * x + 2], x};
-        std::sort(keys.begin(), keys.end(), [](const Key &p, const Key &q) {
-            if (p.a != q.a) return p.a < q.a;
-            if (p.b != q.b) return p.b < q.b;
-            if (p.c != q.c) return p.c < q.c;
-            return p.x < q.x;
-        });
-        for (int y = 0; y < batch; y++) {
-            const Key want{idx[4 * y + 1], idx[4 * y + 2], idx[4 * y + 3], -1};
-            auto it = std::lower_bound(keys.begin(), keys.end(), want, [](const Key &p, const Key &q) {
-                if (p.a != q.a) return p.a < q.a;
-                if (p.b != q.b) return p.b < q.b;
-                if (p.c != q.c) return p.c < q.c;
-                return p.x < q.x;
-            });
-            // a predecessor with a smaller batch position and no successor yet (no cycles, one successor each)
-            for (; it != keys.end() && it->a == want.a && it->b == want.b && it->c == want.c && it->x < y; ++it)
-                if (succ[it->x] < 0) {
-                    succ[it->x] = y;
-                    has_pred[y] = 1;
-                    break;
-                }
-        }
-    }
-    order.clear();
-    std::vector<std::pair<int, int>> chains;   // (first position in order, length)
-    for (int x = 0; x < batch; x++) {
-        if (has_pred[x]) continue;
-        const int first = (int)order.size();
-        for (int y = x; y >= 0; y = succ[y]) order.push_back(y);
-        chains.emplace_back(first, (int)order.size() - first);
-    }
-    int maxlen = 1;
-    for (auto &c : chains) maxlen = std::max(maxlen, c.second);
-    int best_ch = 1;
-    double best_cost = -1;
-    for (int ch = 1; ch <= maxlen; ch++) {
-        long long n = 0;
-        for (auto &c : chains) n += (c.second + ch - 1) / ch;
-        n *= g.nbands;
-        const double cost = (double)((n + num_cu - 1) / num_cu) * (ch + 1.2);
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_ch = ch; }
-    }
-    items.clear();
-    for (int band = 0; band < g.nbands; band++)
-        for (auto &c : chains) {
-            const int nchunk = (c.second + best_ch - 1) / best_ch;
-            for (int q = 0; q < nchunk; q++) {   // balanced chunk lengths
-                const int a = (int)((long long)q * c.second / nchunk), b = (int)((long long)(q + 1) * c.second / nchunk);
-                items.push_back(c.first + a); items.push_back(b - a); items.push_back(band); items.push_back(0);
-            }
-        }
-    return true;
-}
-
 // planning-only passes (blobnet_forward_mfma with d_stack == nullptr) go through every check and launch nothing
 #define LAUNCH(...)                                  \
     do {                                             \
@@ -2481,37 +1851,8 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
 
     // ---------------- encoder
     int first_level = 0;
-    if (by_frames && (inp.n_items > 0 || (dry && inp.walk.rb > 0))) {
-        // carrier-frame path, single-launch form (developer switch): levels 0 + 1 walk along the streams (enc01w_mfma)
-        const WalkGeom &g = inp.walk;
-        Enc01wArgs a{};
-        a.frames = inp.frames; a.pidx = inp.index; a.order = inp.order; a.items = reinterpret_cast<const int4 *>(inp.items);
-        a.skip = act[1]; a.out = act[2];
-        a.w0frag = (const half8 *)(prep + pr->enc[0].wfrag); a.epi0 = (const float *)(prep + pr->enc[0].epi);
-        a.w1frag = (const half8 *)(prep + pr->enc[1].wfrag); a.epi1 = (const float *)(prep + pr->enc[1].epi);
-        a.n_items = inp.n_items;
-        a.H0 = m->lv[0].H; a.W0 = m->lv[0].W; a.Hp0 = a.H0 / 2; a.Wp0 = a.W0 / 2; a.oy0 = a.H0 & 1; a.ox0 = a.W0 & 1;
-        a.H1 = m->lv[1].H; a.W1 = m->lv[1].W; a.Hp1 = a.H1 / 2; a.Wp1 = a.W1 / 2; a.oy1 = a.H1 & 1; a.ox1 = a.W1 & 1;
-        a.H2 = m->lv[2].H; a.W2 = m->lv[2].W;
-        a.nbands = g.nbands; a.TC0 = g.TC0; a.TC1 = g.TC1; a.tsz = g.tsz;
-        a.mW4 = magic(a.W0 / 4); a.mWp0 = magic(a.Wp0); a.mWp1 = magic(a.Wp1); a.mW1 = magic(a.W1); a.mTC1 = magic(g.TC1);
-        a.swz = choose_swz(true, 16, a.W1, a.Wp1, g.rb);
-        const bool p0 = pr->allpos[0], p1 = pr->allpos[1];
-        int rc = p0 ? (p1 ? set_lds(ctx, enc01w_mfma<true, true>, g.lds) : set_lds(ctx, enc01w_mfma<true, false>, g.lds))
-                    : (p1 ? set_lds(ctx, enc01w_mfma<false, true>, g.lds) : set_lds(ctx, enc01w_mfma<false, false>, g.lds));
-        if (rc) return rc;
-        const int grid = std::max(1, std::min(inp.n_items, num_cu));
-        {
-            ProfScope ps(ctx, "enc01w_mfma");
-            if (p0 && p1) LAUNCH((enc01w_mfma<true, true>), dim3(grid), dim3(512), g.lds, ctx->stream, a);
-            else if (p0) LAUNCH((enc01w_mfma<true, false>), dim3(grid), dim3(512), g.lds, ctx->stream, a);
-            else if (p1) LAUNCH((enc01w_mfma<false, true>), dim3(grid), dim3(512), g.lds, ctx->stream, a);
-            else LAUNCH((enc01w_mfma<false, false>), dim3(grid), dim3(512), g.lds, ctx->stream, a);
-        }
-        COVAHIP_CHECK_HIP(ctx, hipGetLastError());
-        first_level = 2;
-    } else if (by_frames) {
-        // carrier-frame path, two-kernel form: level 0 up to the pool ONCE per carrier frame (enc0p_mfma -> P); level 1 gathers the
+    if (by_frames) {
+        // carrier-frame path: level 0 up to the pool ONCE per carrier frame (enc0p_mfma -> P); level 1 gathers the
         // four frames of a stack, applies level 0's temporal MLP in LDS and writes the decoder's skip slice
         const int H = m->lv[0].H, W = m->lv[0].W, Hp = H / 2, Wp = W / 2;
         const int TC = ((W + 4 - 16 + 31) / 32) * 32 + 16;
@@ -2544,54 +1885,6 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
             else LAUNCH(enc0p_mfma<false>, dim3(grid), dim3(WG0), lds, ctx->stream, a);
         }
         COVAHIP_CHECK_HIP(ctx, hipGetLastError());
-    } else if (m->fuse01) {
-        // levels 0 + 1 in one kernel when the geometry fits its LDS plan (otherwise: one kernel per level)
-        const int H0 = m->lv[0].H, W0 = m->lv[0].W, H1 = m->lv[1].H, W1 = m->lv[1].W;
-        const int Hp1 = H1 / 2, Wp1 = W1 / 2;
-        const int TC0 = ((W0 + 4 - 16 + 31) / 32) * 32 + 16, TC1 = W1 + 2;
-        const size_t lds_max = 160 * 1024 - 512;
-        // fewest bands (least level-0 halo recomputation) whose A1 + IN fit; a level-1 band is at most 16 tiles
-        // (one per wave) and IN takes half the A1 rows (at most two chunk positions per thread)
-        int nbands = 0, NR1 = 0, SB = 0, in_rows = 0;
-        size_t in_bytes = 0, a1_bytes = 0, raw_bytes = 0;
-        for (int nb = 1; nb <= Hp1 && W0 % 4 == 0; nb++) {
-            const int rb = (Hp1 + nb - 1) / nb, nr1 = 2 * rb + 2;
-            if ((rb * Wp1 + 7) / 8 > WG01 / 64) continue;
-            const int sb = (nr1 + 1) / 2, inr = 2 * sb + 2;
-            const size_t ib = std::max((size_t)BN_T * inr * TC0 * 8, (size_t)(WG01 / 64) * 2048);
-            const size_t ab = (size_t)BN_T * nr1 * TC1 * 32;
-            const size_t rwb = (size_t)BN_T * (2 * nr1 + 2) * W0 * 4;
-            if (ib + ab + rwb + 14 * 1024 > lds_max || inr * (W0 / 4) > 2 * WG01) continue;
-            if ((long long)batch * nb < num_cu && nb < Hp1) continue;   // keep every CU busy
-            nbands = nb; NR1 = nr1; SB = sb; in_rows = inr; in_bytes = (ib + 15) & ~(size_t)15; a1_bytes = ab; raw_bytes = rwb;
-            break;
-        }
-        if (nbands) {
-            Enc01Args a{};
-            a.in = d_stack; a.skip = act[1]; a.out = act[2];
-            a.w0frag = (const half8 *)(prep + pr->enc[0].wfrag); a.epi0 = (const float *)(prep + pr->enc[0].epi);
-            a.w1frag = (const half8 *)(prep + pr->enc[1].wfrag); a.epi1 = (const float *)(prep + pr->enc[1].epi);
-            a.B = batch; a.H0 = H0; a.W0 = W0; a.Hp0 = H0 / 2; a.Wp0 = W0 / 2; a.oy0 = H0 & 1; a.ox0 = W0 & 1;
-            a.H1 = H1; a.W1 = W1; a.Hp1 = Hp1; a.Wp1 = Wp1; a.oy1 = H1 & 1; a.ox1 = W1 & 1;
-            a.H2 = m->lv[2].H; a.W2 = m->lv[2].W;
-            a.nbands = nbands; a.TC0 = TC0; a.TC1 = TC1; a.NR1 = NR1; a.SB = SB; a.in_rows = in_rows;
-            a.a1_off = (int)in_bytes; a.wl_off = (int)(in_bytes + a1_bytes); a.raw_off = (int)(in_bytes + a1_bytes + 14 * 1024);
-            a.zero = prep + pr->zero;
-            a.mNb = magic(nbands); a.mW4 = magic(W0 / 4); a.mWp0 = magic(W0 / 2); a.mWp1 = magic(Wp1); a.mW1 = magic(W1);
-            const size_t lds = in_bytes + a1_bytes + 14 * 1024 + raw_bytes;
-            const int grid = std::min(batch * nbands, num_cu);
-            const bool p0 = pr->allpos[0], p1 = pr->allpos[1];
-            int rc = p0 ? (p1 ? set_lds(ctx, enc01_mfma<true, true>, lds) : set_lds(ctx, enc01_mfma<true, false>, lds))
-                        : (p1 ? set_lds(ctx, enc01_mfma<false, true>, lds) : set_lds(ctx, enc01_mfma<false, false>, lds));
-            if (rc) return rc;
-            ProfScope ps(ctx, "enc01_mfma");
-            if (p0 && p1) LAUNCH((enc01_mfma<true, true>), dim3(grid), dim3(WG01), lds, ctx->stream, a);
-            else if (p0) LAUNCH((enc01_mfma<true, false>), dim3(grid), dim3(WG01), lds, ctx->stream, a);
-            else if (p1) LAUNCH((enc01_mfma<false, true>), dim3(grid), dim3(WG01), lds, ctx->stream, a);
-            else LAUNCH((enc01_mfma<false, false>), dim3(grid), dim3(WG01), lds, ctx->stream, a);
-            COVAHIP_CHECK_HIP(ctx, hipGetLastError());
-            first_level = 2;
-        }
     }
     if (by_frames && first_level == 0) first_level = 1;
     for (int i = first_level; i < BN_LEVELS; i++) {

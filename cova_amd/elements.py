@@ -177,9 +177,8 @@ class BlobNetInfer:
         L.check(self._lib.covahip_blobnet_set_enc_plan(self.ctx.handle, level, nbands, nbuf), "covahip_blobnet_set_enc_plan")
 
     def set_impl(self, impl: str):
-        """Developer switch (include/covahip_dev.h): encoder levels 0/1 as two kernels or as one; decoder blocks 0..2 as one
-        launch (default) or three ("dec_separate")."""
-        L.check(self._lib.covahip_blobnet_set_impl(self.ctx.handle, {"mfma": 1, "mfma_fused01": 2, "frames_walk": 3, "dec_separate": 4}[impl]), "set_impl")
+        """Developer switch (include/covahip_dev.h): decoder blocks 0..2 as one launch ("mfma", default) or three ("dec_separate")."""
+        L.check(self._lib.covahip_blobnet_set_impl(self.ctx.handle, {"mfma": 1, "dec_separate": 4}[impl]), "set_impl")
 
     @property
     def macs_per_frame(self) -> int:

@@ -11,11 +11,10 @@
 extern "C" {
 #endif
 
-/* Kernel chain of the loaded model: 1 = defaults (stacked entry: one kernel per encoder level; carrier-frame
- * entry: level 0 per carrier frame + level 1 with the gather), 2 = stacked entry with levels 0 and 1 in one kernel,
- * 3 = carrier-frame entry with the time-walking level-0+1 kernel, 4 = defaults, but decoder blocks 0..2 as three
- * launches instead of one (the form before the fused decoder).  2, 3 and 4 are measured slower on MI355X
- * and kept for study; all forms compute identical bits (tests/test_gpu_blobnet.py). */
+/* Kernel chain of the loaded model: 1 = default, 4 = decoder blocks 0..2 as three launches instead of one (the form
+ * before the fused decoder; measured slower on MI355X, kept because it is the fallback for grids whose three decoder
+ * tiles do not fit in LDS together, and tests compare the two bit for bit).  (2 and 3 were single-launch forms of encoder
+ * levels 0 + 1, measured slower and removed in round 3; DESIGN.md has their numbers.) */
 int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl);
 
 /* bboxcc kernel choice: cap > 0 = run capacity of the wave-per-frame kernel (frames with more runs take the

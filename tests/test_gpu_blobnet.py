@@ -24,7 +24,7 @@ def _check(logits, mask, ref_logits):
     return float(err.max())
 
 
-@pytest.mark.parametrize("impl", ["mfma", "mfma_fused01"])
+@pytest.mark.parametrize("impl", ["mfma", "dec_separate"])
 @pytest.mark.parametrize("hw", [(68, 120), (67, 120), (45, 80), (35, 60)])
 def test_logits_match_oracle(ctx, weights_flat, hw, impl):
     h, w = hw
@@ -61,7 +61,7 @@ def _mixed_gamma_weights(seed):
     return W.flatten(wts)
 
 
-@pytest.mark.parametrize("impl", ["mfma", "mfma_fused01"])
+@pytest.mark.parametrize("impl", ["mfma", "dec_separate"])
 @pytest.mark.parametrize("hw,b", [((68, 120), 16), ((67, 120), 16), ((45, 80), 2)])
 def test_negative_bn_gamma(ctx, impl, hw, b):
     """BN runs after ReLU and before max-pool; a negative gamma must not commute with the max
@@ -119,19 +119,6 @@ def test_fused_filter_matches_separate(ctx, weights_flat):
             np.testing.assert_array_equal(boxes[i, :n][f], rb[i, :n][g])
     _, mask2 = net.infer(stack)
     np.testing.assert_array_equal(mask, mask2)
-
-
-def test_fused_levels_match_per_level_kernels_bitwise(ctx, weights_flat):
-    """Encoder levels 0+1 as one kernel compute the same fp16 tensors as the two per-level kernels
-    (same MFMA tiles, same rounding points), so the logits are identical bit for bit."""
-    h, w = 68, 120
-    stack = synth.stacked_batch(64, h, w, seed=9, streams=4)
-    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=64)
-    l0, m0 = net.infer(stack)
-    net.set_impl("mfma_fused01")
-    l1, m1 = net.infer(stack)
-    np.testing.assert_array_equal(l0, l1)
-    np.testing.assert_array_equal(m0, m1)
 
 
 @pytest.mark.parametrize("hw", [(68, 120), (67, 120), (45, 80), (35, 60)])
@@ -208,8 +195,7 @@ def test_carrier_frame_entry_equals_stacked_entry_bitwise(ctx, weights_flat, hw,
     net = BlobNetInfer(ctx, flat, h, w, max_batch=64)
     boxes, counts, mask = net.filter(stack, cc_threshold=2, max_boxes=2048, want_mask=True)
     logits, _ = net.infer(stack)
-    # both forms of the carrier-frame path: two kernels (default) and the time-walking level-0+1 kernel
-    for impl in ("mfma", "frames_walk"):
+    for impl in ("mfma", "dec_separate"):
         net.set_impl(impl)
         fboxes, fcounts, fmask, flogits = net.filter_frames(frames, index, 2, max_boxes=2048, want_mask=True, want_logits=True)
         np.testing.assert_array_equal(flogits, logits, err_msg=impl)
@@ -217,7 +203,7 @@ def test_carrier_frame_entry_equals_stacked_entry_bitwise(ctx, weights_flat, hw,
         np.testing.assert_array_equal(fcounts, counts)
         for i in range(b):
             np.testing.assert_array_equal(fboxes[i, :counts[i]], boxes[i, :counts[i]])
-        # a shuffled batch: the chains of the time walk are found wherever the stacks sit in the batch
+        # a shuffled batch: any order of the table's rows
         perm = np.random.default_rng(3).permutation(b)
         _, pcounts, pmask, plogits = net.filter_frames(frames, index[perm], 2, max_boxes=2048, want_mask=True, want_logits=True)
         np.testing.assert_array_equal(plogits, logits[perm], err_msg=impl + " shuffled")
