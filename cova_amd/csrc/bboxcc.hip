@@ -79,19 +79,38 @@ __global__ __launch_bounds__(CC_THREADS) void bboxcc_big_kernel(const uint8_t *_
     }
 }
 
-// ---- one WAVE per frame (bboxcc_wave.h): WV_WAVES frames per workgroup, no workgroup barrier at all
+// ---- one WAVE per frame (bboxcc_wave.h): WV_WAVES frames per workgroup, no workgroup barrier at all.
+// list == nullptr: frame = global wave index.  Otherwise the launch is persistent over the *n_list frame indices in list
+// (the second-chance pass over the frames that had more runs than the first pass's capacity).  A frame with more than
+// g.cap runs goes to ovf_list.
 constexpr int WV_WAVES = 4;
 __global__ __launch_bounds__(WV_WAVES * 64) void bboxcc_wave_kernel(const uint8_t *__restrict__ masks, ccwave::WvGeom g, int batch,
                                                                     int area_thresh, covahip_box *__restrict__ boxes,
                                                                     int32_t *__restrict__ counts, int max_boxes,
-                                                                    int32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_n) {
+                                                                    const int32_t *__restrict__ list, const int32_t *__restrict__ n_list,
+                                                                    int32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_n,
+                                                                    int base_cap, int32_t *__restrict__ n_big) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int frame = blockIdx.x * WV_WAVES + wave;
-    if (frame >= batch) return;
-    const bool done = ccwave::frame_wave(masks + (size_t)frame * g.H * g.W, smem + (size_t)wave * g.wave_bytes, g, area_thresh,
-                                         boxes + (size_t)frame * max_boxes, counts + frame, max_boxes, lane);
-    if (!done && lane == 0) ovf_list[atomicAdd(ovf_n, 1)] = frame;   // more runs than the LDS region holds
+    uint8_t *const sm = smem + (size_t)wave * g.wave_bytes;
+    auto one = [&](int frame) {
+        const int n = ccwave::frame_wave(masks + (size_t)frame * g.H * g.W, sm, g, area_thresh, boxes + (size_t)frame * max_boxes,
+                                         counts + frame, max_boxes, lane);
+        if (lane == 0) {
+            if (n > g.cap) ovf_list[atomicAdd(ovf_n, 1)] = frame;   // more runs than the LDS region holds
+            if (n_big && n > base_cap) atomicAdd(n_big, 1);        // (statistics for the next call's plan; pass 1 only)
+        }
+    };
+    if (!list) {
+        const int frame = blockIdx.x * WV_WAVES + wave;
+        if (frame < batch) one(frame);
+        return;
+    }
+    const int n = *n_list;
+    for (int k = blockIdx.x * WV_WAVES + wave; k < n; k += gridDim.x * WV_WAVES) {
+        one(list[k]);
+        ccwave::wave_fence();   // the next frame reuses this wave's LDS region
+    }
 }
 
 template <typename K>
@@ -111,12 +130,15 @@ int open_lds(covahip_ctx *ctx, K kernel, size_t lds) {
 }  // namespace
 
 // Launch plan.  Shapes the wave kernel takes (W a multiple of 8, H and W <= 128, 8-byte aligned frames) go to it:
-//   * small batches (a few frames per CU): every wave gets the worst-case run capacity (one run per 2x2 block),
-//     nothing can overflow, one launch;
-//   * large batches: 256 runs per wave (7 KB of LDS -> about twenty frames in flight per CU); frames with more
-//     runs -- noise-like masks -- are collected in an overflow list that a second, persistent launch of the
-//     workgroup-per-frame kernel drains (it exits at once when the list is empty).
+//   * small batches (a few frames per CU): the workgroup-per-frame kernel finishes a frame sooner than one wave does;
+//   * large batches: pass 1 = one wave per frame with a run capacity of WAVE_CAP (4.2 KB of LDS per wave, about thirty
+//     frames in flight per CU); frames with more runs -- many objects, noise -- are collected in an overflow list and get a
+//     SECOND CHANCE on the wave kernel at four times the capacity (persistent launch over the list); what overflows that too
+//     goes to a persistent launch of the workgroup-per-frame kernel.  Passes 2 and 3 exit at once when their list is empty.
+//     The first pass's capacity adapts: when more than a quarter of the previous call's frames (same lane) overflowed, the
+//     next call starts at the larger capacity and skips the wasted first read of those frames.
 // Everything else runs the workgroup-per-frame kernel.
+constexpr int WAVE_CAP = 128;
 int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, int h, int w, int area_thresh,
                           covahip_box *d_boxes, int32_t *d_counts, int max_boxes) {
     if (batch == 0) return COVAHIP_OK;
@@ -126,10 +148,19 @@ int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, in
     const int num_cu = ctx->props.multiProcessorCount;
     ccwave::WvGeom wg;
     const int nb = ((h + 1) / 2) * ((w + 1) / 2);
-    int cap = ctx->cc_wave_cap;            // developer override: > 0 capacity, < 0 wave kernel off, 0 automatic
+    int cap = ctx->cc_wave_cap;            // developer override: > 0 capacity of pass 1, < 0 wave kernel off, 0 automatic
     // a few frames per CU: the workgroup kernel finishes a frame sooner than a single wave does (9.5 vs 13.5 us at
     // b = 256), and there is nothing to overlap it with
-    if (cap == 0) cap = batch <= 3 * num_cu ? -1 : 128;
+    if (cap == 0) {
+        cap = -1;
+        if (batch > 3 * num_cu) {
+            // the previous call's statistics, when they have arrived (pinned host words behind an event): frames with more
+            // than WAVE_CAP runs; until then the last decision stands
+            if (ln.cc_stat && ln.cc_stat_batch > 0 && hipEventQuery(ln.cc_stat_ev) == hipSuccess)
+                ln.cc_first_cap = 4 * (int64_t)ln.cc_stat[2] > ln.cc_stat_batch ? 4 * WAVE_CAP : WAVE_CAP;
+            cap = ln.cc_first_cap ? ln.cc_first_cap : WAVE_CAP;
+        }
+    }
     cap = std::min(cap, nb);
     const bool aligned = (reinterpret_cast<uintptr_t>(d_mask) & 7) == 0 && (((size_t)h * w) & 7) == 0;
     // the workgroup-per-frame kernel runs the run-based body too when the shape allows it (worst-case capacity)
@@ -142,31 +173,70 @@ int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, in
     if (cap > 0 && aligned && ccwave::wv_plan(h, w, cap, wg) &&
         (size_t)WV_WAVES * wg.wave_bytes <= 160 * 1024 - 64 && (cap >= nb || lds_wg)) {
         const bool can_overflow = cap < nb;
+        // second chance: four times the capacity, as long as four such waves still fit a workgroup's LDS
+        ccwave::WvGeom wg2{};
+        const int cap2 = std::min(4 * cap, nb);
+        const bool second = can_overflow && cap2 > cap && ccwave::wv_plan(h, w, cap2, wg2) &&
+                            (size_t)WV_WAVES * wg2.wave_bytes <= 160 * 1024 - 64;
+        const bool third = can_overflow && (!second || cap2 < nb);
+        int32_t *ovf = nullptr;            // [n1][n2][n_big][-][list1: batch][list2: batch]
         if (can_overflow) {
-            int rc = covahip_ensure_buffer(ctx, &ln.cc_ovf, &ln.cc_ovf_bytes, ((size_t)batch + 1) * sizeof(int32_t));
+            int rc = covahip_ensure_buffer(ctx, &ln.cc_ovf, &ln.cc_ovf_bytes, (2 * (size_t)batch + 4) * sizeof(int32_t));
             if (rc) return rc;
-            COVAHIP_CHECK_HIP(ctx, hipMemsetAsync(ln.cc_ovf, 0, sizeof(int32_t), ctx->stream));
+            ovf = (int32_t *)ln.cc_ovf;
+            COVAHIP_CHECK_HIP(ctx, hipMemsetAsync(ovf, 0, 4 * sizeof(int32_t), ctx->stream));
         }
-        int32_t *ovf_n = (int32_t *)ln.cc_ovf, *ovf_list = ovf_n ? ovf_n + 1 : nullptr;
+        int32_t *n1 = ovf, *n2 = ovf ? ovf + 1 : nullptr, *n_big = ovf ? ovf + 2 : nullptr;
+        int32_t *list1 = ovf ? ovf + 4 : nullptr, *list2 = ovf ? ovf + 4 + batch : nullptr;
         const size_t wlds = (size_t)WV_WAVES * wg.wave_bytes;
-        int rc = open_lds(ctx, bboxcc_wave_kernel, wlds);
+        int rc = open_lds(ctx, bboxcc_wave_kernel, std::max(wlds, second ? (size_t)WV_WAVES * wg2.wave_bytes : 0));
         if (rc) return rc;
         {
             ProfScope ps(ctx, "bboxcc_wave_kernel");
             hipLaunchKernelGGL(bboxcc_wave_kernel, dim3((batch + WV_WAVES - 1) / WV_WAVES), dim3(WV_WAVES * 64), wlds, ctx->stream,
-                               d_mask, wg, batch, area_thresh, d_boxes, d_counts, max_boxes, ovf_list, ovf_n);
+                               d_mask, wg, batch, area_thresh, d_boxes, d_counts, max_boxes, (const int32_t *)nullptr,
+                               (const int32_t *)nullptr, list1, n1, WAVE_CAP, n_big);
             COVAHIP_CHECK_HIP(ctx, hipGetLastError());
         }
-        if (can_overflow) {
+        if (second) {
+            const size_t wlds2 = (size_t)WV_WAVES * wg2.wave_bytes;
+            const int per_cu = std::max(1, (int)((160 * 1024 - 256) / wlds2));
+            const int grid = std::min((batch + WV_WAVES - 1) / WV_WAVES, per_cu * num_cu);
+            ProfScope ps(ctx, "bboxcc_wave_kernel_2");
+            hipLaunchKernelGGL(bboxcc_wave_kernel, dim3(grid), dim3(WV_WAVES * 64), wlds2, ctx->stream, d_mask, wg2, batch, area_thresh,
+                               d_boxes, d_counts, max_boxes, (const int32_t *)list1, (const int32_t *)n1, list2, n2, 0, (int32_t *)nullptr);
+            COVAHIP_CHECK_HIP(ctx, hipGetLastError());
+        }
+        if (third) {
             rc = open_lds(ctx, bboxcc_kernel, lds_wg);
             if (rc) return rc;
             ProfScope ps(ctx, "bboxcc_kernel");
             hipLaunchKernelGGL(bboxcc_kernel, dim3(std::min(batch, 2 * num_cu)), dim3(CC_THREADS), lds_wg, ctx->stream, d_mask, g, wfull,
-                               area_thresh, d_boxes, d_counts, max_boxes, (const int32_t *)ovf_list, (const int32_t *)ovf_n);
+                               area_thresh, d_boxes, d_counts, max_boxes, (const int32_t *)(second ? list2 : list1),
+                               (const int32_t *)(second ? n2 : n1));
             COVAHIP_CHECK_HIP(ctx, hipGetLastError());
+        }
+        if (can_overflow) {
+            // overflow counts of this call -> pinned host words (read by the next call's plan and by covahip_dev_bboxcc_overflow)
+            if (!ln.cc_stat_ring) {
+                COVAHIP_CHECK_HIP(ctx, hipHostMalloc((void **)&ln.cc_stat_ring, 16 * sizeof(int32_t), hipHostMallocDefault));
+                for (hipEvent_t &e : ln.cc_stat_evs) COVAHIP_CHECK_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
+            const unsigned slot = ln.cc_stat_turn++ & 3;
+            int32_t *st = ln.cc_stat_ring + 4 * slot;   // {overflowed pass 1, overflowed pass 2, frames with more than WAVE_CAP runs, -}
+            COVAHIP_CHECK_HIP(ctx, hipEventSynchronize(ln.cc_stat_evs[slot]));   // the copy of four calls ago (never recorded: returns at once)
+            COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(st, ovf, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+            COVAHIP_CHECK_HIP(ctx, hipEventRecord(ln.cc_stat_evs[slot], ctx->stream));
+            ln.cc_stat = st;
+            ln.cc_stat_ev = ln.cc_stat_evs[slot];
+            ln.cc_stat_batch = batch;
+            ln.cc_stat_cap = cap;
+        } else {
+            ln.cc_stat_batch = 0;
         }
         return COVAHIP_OK;
     }
+    ln.cc_stat_batch = 0;   // the kernels below cannot overflow
     if (!lds_wg) {
         CcGeom gb;
         const size_t slab = cc_plan_global(h, w, gb);
@@ -186,6 +256,20 @@ int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, in
     hipLaunchKernelGGL(bboxcc_kernel, dim3(batch), dim3(CC_THREADS), lds_wg, ctx->stream, d_mask, g, wfull, area_thresh,
                        d_boxes, d_counts, max_boxes, (const int32_t *)nullptr, (const int32_t *)nullptr);
     COVAHIP_CHECK_HIP(ctx, hipGetLastError());
+    return COVAHIP_OK;
+}
+
+// (covahip_dev.h) overflow statistics of the last large-batch bboxcc call on the primary stream: out = {batch, frames that
+// overflowed pass 1, frames that overflowed pass 2 too, capacity of pass 1}; batch = 0 when that call could not overflow.
+extern "C" int covahip_dev_bboxcc_overflow(covahip_ctx *ctx, int32_t *out4) {
+    if (!ctx || !out4) return COVAHIP_ERR_INVALID_ARG;
+    int rc = covahip_sync_all(ctx);
+    if (rc) return rc;
+    const CtxLane &ln = ctx->lanes[0];
+    out4[0] = ln.cc_stat_batch;
+    out4[1] = ln.cc_stat && ln.cc_stat_batch ? ln.cc_stat[0] : 0;
+    out4[2] = ln.cc_stat && ln.cc_stat_batch ? ln.cc_stat[1] : 0;
+    out4[3] = ln.cc_stat_cap;
     return COVAHIP_OK;
 }
 

@@ -80,8 +80,8 @@ __device__ __forceinline__ int nth_set_bit64(uint64_t x, int k) {
 __device__ __forceinline__ uint64_t mask_upto(int e) { return e >= 63 ? ~0ull : ((2ull << e) - 1); }   // bits 0..e
 
 // One frame by the calling wave.  m: the frame's mask bytes (8-byte aligned; HBM or LDS); sm: this wave's LDS
-// region of g.wave_bytes.  Returns false (nothing written) when the frame has more than g.cap runs.
-__device__ __forceinline__ bool frame_wave(const uint8_t *m, uint8_t *sm, const WvGeom &g, int area_thresh, covahip_box *ob,
+// region of g.wave_bytes.  Returns the frame's number of runs n; nothing is written when n > g.cap.
+__device__ __forceinline__ int frame_wave(const uint8_t *m, uint8_t *sm, const WvGeom &g, int area_thresh, covahip_box *ob,
                                            int32_t *count_out, int max_boxes, int lane) {
     uint32_t *rows = reinterpret_cast<uint32_t *>(sm);            // [2*BH + 2][4]: E lo, E hi, O lo, O hi; pixel row y at y + 1
     uint32_t *lab = reinterpret_cast<uint32_t *>(sm + g.rows_bytes);
@@ -142,7 +142,7 @@ __device__ __forceinline__ bool frame_wave(const uint8_t *m, uint8_t *sm, const 
     }
     const int base = incl - nr;
     const int n = __shfl(incl, 63, 64);
-    if (n > g.cap) return false;
+    if (n > g.cap) return n;
     uint64_t S_up = (uint64_t)__shfl_up((unsigned long long)S, 1, 64), J_up = (uint64_t)__shfl_up((unsigned long long)J, 1, 64);
     int base_up = __shfl_up(base, 1, 64);
     if (lane == 0) { S_up = 0; J_up = 0; base_up = 0; }
@@ -218,7 +218,7 @@ __device__ __forceinline__ bool frame_wave(const uint8_t *m, uint8_t *sm, const 
         total += __popcll((unsigned long long)bal);
     }
     if (lane == 0) *count_out = total;
-    return true;
+    return n;
 }
 
 // ---- the same algorithm by ONE WORKGROUP of NTH threads per frame (the fused decoder tail: one frame per CU, the frame's

@@ -416,6 +416,13 @@ class BboxCc:
         """Developer switch (include/covahip_dev.h): > 0 run capacity of the wave-per-frame kernel, < 0 workgroup kernel only, 0 auto."""
         L.check(self._lib.covahip_bboxcc_set_wave_cap(self.ctx.handle, cap), "covahip_bboxcc_set_wave_cap")
 
+    def overflow_stats(self):
+        """Developer read-out (include/covahip_dev.h): {batch, overflowed pass 1, overflowed pass 2, capacity of pass 1} of the last
+        large-batch device-pointer call."""
+        out = (C.c_int32 * 4)()
+        L.check(self._lib.covahip_dev_bboxcc_overflow(self.ctx.handle, out), "covahip_dev_bboxcc_overflow", self.ctx.handle)
+        return {"batch": out[0], "overflow_pass1": out[1], "overflow_pass2": out[2], "cap_pass1": out[3]}
+
     def regionprops(self, masks: np.ndarray):
         """masks u8 [B][H][W] (host) -> (boxes [B][max_boxes], counts [B])."""
         masks = np.ascontiguousarray(masks, dtype=np.uint8)

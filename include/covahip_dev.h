@@ -17,9 +17,14 @@ extern "C" {
  * levels 0 + 1, measured slower and removed in round 3; DESIGN.md has their numbers.) */
 int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl);
 
-/* bboxcc kernel choice: cap > 0 = run capacity of the wave-per-frame kernel (frames with more runs take the
- * overflow pass), cap < 0 = workgroup-per-frame kernel only, 0 = automatic (default). */
+/* bboxcc kernel choice: cap > 0 = run capacity of the wave-per-frame kernel's first pass (frames with more runs get a
+ * second chance at four times the capacity, then the workgroup kernel), cap < 0 = workgroup-per-frame kernel only,
+ * 0 = automatic (default: 128, or 512 when more than a quarter of the previous call's frames overflowed). */
 int covahip_bboxcc_set_wave_cap(covahip_ctx *ctx, int cap);
+/* Overflow statistics of the last large-batch covahip_bboxcc call (device pointers): out4 = {batch, frames that overflowed
+ * pass 1, frames that overflowed pass 2 too, capacity of pass 1}; batch = 0 when that call ran a kernel that cannot
+ * overflow.  Synchronises the ctx.  (tools/bboxcc_sweep.py) */
+int covahip_dev_bboxcc_overflow(covahip_ctx *ctx, int32_t *out4);
 
 /* Encoder band plan of level 1..3 (tools/plan_sweep.sh): nbands bands of pool-window rows per frame, nbuf = 1 or 2 LDS
  * buffers (2 = the next band is requested while this one is computed; measured no faster).  nbands = 0

@@ -16,6 +16,15 @@ H, W = 68, 120
 
 def make_masks(kind, n, seed=0):
     rng = np.random.default_rng(seed)
+    if kind.startswith("obj"):            # "obj50": exactly 50 ellipses of 1 .. 5 macroblocks radius per frame
+        k = int(kind[3:])
+        yy, xx = np.mgrid[0:H, 0:W]
+        m = np.zeros((n, H, W), np.uint8)
+        for i in range(n):
+            for _ in range(k):
+                cy, cx, ry, rx = rng.uniform(0, H), rng.uniform(0, W), rng.uniform(1, 5), rng.uniform(1, 5)
+                m[i] |= (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1).astype(np.uint8)
+        return m
     if kind == "blobs":
         yy, xx = np.mgrid[0:H, 0:W]
         m = np.zeros((n, H, W), np.uint8)
@@ -55,8 +64,14 @@ def main():
             ctx.timer_stop(1)
             us = ctx.timer_ms(1) / reps * 1e3
             gbs = B * H * W / (us * 1e-6) / 1e9
+            st = cc.overflow_stats()
+            cnt = np.zeros(B, dtype=np.int32)
+            ctx.d2h(cnt, d_c)
             out.append({"kind": kind, "batch": B, "wave_cap": cap, "us": round(us, 1), "ns_per_frame": round(us * 1e3 / B, 1),
-                        "GBps": round(gbs, 1), "frac_hbm_peak": round(gbs / 8000, 4)})
+                        "GBps": round(gbs, 1), "frac_hbm_peak": round(gbs / 8000, 4), "boxes_per_frame": round(float(cnt.mean()), 1),
+                        "cap_pass1": st["cap_pass1"] if st["batch"] else None,
+                        "overflow_frac_pass1": round(st["overflow_pass1"] / B, 4) if st["batch"] else None,
+                        "overflow_frac_pass2": round(st["overflow_pass2"] / B, 4) if st["batch"] else None})
             print(out[-1], flush=True)
             for p in (d_m, d_b, d_c):
                 ctx.free(p)
