@@ -318,10 +318,11 @@ def pipelined_host_rate(net, frames, index, steps):
     return res
 
 
-def element_rate():
-    """frames/s through the GStreamer batching element (tools/element_bench.sh; a child process with its own ctx)."""
+def element_rate(script="element_bench.sh", args=("20000", "8", str(CC_THRESHOLD))):
+    """frames/s through the GStreamer elements (tools/element_bench.sh: the batching element alone; tools/chain_bench.sh: the
+    batching element + one cova element per stream = BASELINE config 4); a child process with its own ctx."""
     try:
-        r = subprocess.run(["bash", os.path.join(ROOT, "tools", "element_bench.sh"), "20000", "8", str(CC_THRESHOLD)],
+        r = subprocess.run(["bash", os.path.join(ROOT, "tools", script), *args],
                            capture_output=True, text=True, timeout=180)
         for line in r.stdout.splitlines():
             if line.startswith("{"):
@@ -368,6 +369,17 @@ def main():
     if env_world == 1:
         if not args.no_extra_legs:
             pre["through_gstreamer_elements"] = element_rate()
+            # BASELINE config 4: metapreprocess -> BlobNet -> bboxcc -> cova (embedded SORT + GoP filter) per stream, the
+            # experiment's tracker parameters, blob-like weights (a few boxes per frame, as a trained BlobNet gives)
+            chain = element_rate("chain_bench.sh", ("6000", "16"))
+            if "frames_per_s_full_chain" in chain:
+                t_cova = chain["seconds"] * min(16, os.cpu_count() or 1) / max(1, chain["frames_in"])
+                chain["limiter"] = ("host: the per-stream cova elements (SORT with the experiment's minhits 30 / maxage 60 keeps "
+                                    "dozens of young trackers per stream alive); the GPU side of the same element runs at "
+                                    "through_gstreamer_elements")
+                chain["host_threads"] = "16 decoder-branch threads + 8 pusher threads of blobnetfilter on this box's CPU share"
+                chain["cova_us_per_frame_upper_bound"] = round(t_cova * 1e6, 1)
+            pre["full_filter_chain"] = chain
         if not args.no_cpu_baseline:
             pre["cpu_tracking"] = cpu_tracking_baseline()
 
@@ -601,11 +613,20 @@ def main():
         })
         line.update(rank0)
         line.update(extras)
-        if "through_gstreamer_elements" in pre:
-            line["through_gstreamer_elements"] = pre["through_gstreamer_elements"]
+        for k in ("through_gstreamer_elements", "full_filter_chain"):
+            if k in pre:
+                line[k] = pre[k]
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(flat, stack)
             line["cpu_baseline"].update(pre.get("cpu_tracking", {}))
+            cb = line["cpu_baseline"]
+            if "bboxcc_sort_nstreams_frames_per_s" in cb:
+                # the whole chain on the host's cores: BlobNet and the per-stream bboxcc + SORT share them
+                cb["full_chain_frames_per_s"] = round(1.0 / (1.0 / cb["value"] + 1.0 / cb["bboxcc_sort_nstreams_frames_per_s"]), 2)
+            if "frames_per_s_full_chain" in pre.get("full_filter_chain", {}):
+                fc = pre["full_filter_chain"]
+                fc["vs_cpu_full_chain"] = round(fc["frames_per_s_full_chain"] / cb.get("full_chain_frames_per_s", cb["value"]), 1)
+                fc["host_cores_one_gpu_would_need"] = int(line["value"] / max(1.0, fc["frames_per_s_full_chain"]) * min(16, os.cpu_count() or 1))
             line["gpu_over_cpu"] = round(line["value"] / world / line["cpu_baseline"]["value"], 1)
         # the long strings last, so that the numbers survive a truncated log
         line["config"] = {"workload": ("temporal stacking as a GPU gather + BlobNet + bboxcc fused (covahip_filter_forward_frames): carrier "

@@ -137,3 +137,39 @@ def random_init(seed: int = 1234, fg_bias: float = -3.9) -> np.ndarray:
             raise AssertionError(name)
     t["final.bias"] = np.array([fg_bias])
     return flatten(t)
+
+
+def blob_like(seed: int = 7, noise: float = 0.04) -> np.ndarray:
+    """A seeded weight set whose masks look like a trained BlobNet's: connected blobs over the moving objects of the
+    synthetic inputs, background empty (random_init gives salt-and-pepper masks with ~500 one-macroblock components per
+    1080p frame -- pessimistic for bboxcc and meaningless for the trackers behind it; the reference ships no weights).
+
+    random_init(seed) scaled down to `noise` on every kernel, plus one hand-made signal path through the reference
+    architecture: encoder level 0, channel 0 = relu(3x3 mean of (mv_x + mv_y) / 2 - 0.35) (motion-vector energy; the
+    inputs arrive as clip(x, 0, 6) / 6, utils/model/preprocessing.py:6-7), which reaches the last decoder block through
+    the level-0 skip connection (utils/model/blobnet.py:32, decoder.py:128), is spread by the 4x4 stride-2 transposed
+    convolution and read by the final 1x1 convolution.  The kernels do the same work whatever the weights are."""
+    t = unflatten(random_init(seed))
+    for name in t:
+        kind = name.split(".", 1)[1]
+        if kind in ("conv.kernel", "up.kernel") or name == "final.kernel" or kind.startswith("tmix"):
+            t[name] = t[name] * noise
+        elif kind.endswith("bias"):
+            t[name] = t[name] * noise
+    for i in range(4):      # BN of the signal channel: identity
+        for n, v in (("gamma", 1.0), ("beta", 0.0), ("mean", 0.0), ("var", 1.0)):
+            t[f"enc{i}.bn.{n}"][0] = v
+    k0 = t["enc0.conv.kernel"]            # [3][3][Cin=3][Cout=16]
+    k0[:, :, :, 0] = 0.0
+    k0[:, :, 1, 0] = 1.0 / 18.0
+    k0[:, :, 2, 0] = 1.0 / 18.0
+    t["enc0.conv.bias"][0] = -0.35
+    for w in ("enc0.tmix.w1", "enc0.tmix.w2"):
+        t[w] = t[w] * 0.0 + t[w] * 0.25   # the temporal MLP adds little: out = relu(relu(..) + p) ~ p
+    up = t["dec3.up.kernel"]              # [4][4][Cout=16][Cin=32]: input channels 16.. are the level-0 skip
+    up[:, :, 0, :] = 0.0
+    up[:, :, 0, 16] = 0.25
+    t["dec3.up.bias"][0] = 0.0
+    t["final.kernel"][0] = 22.0
+    t["final.bias"] = np.array([-3.0])
+    return flatten(t)

@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 
 typedef struct { uint8_t kind; uint64_t pts; uint32_t flags, len; uint8_t *data; } rec_t;
 
@@ -353,8 +354,164 @@ static int run_muxbench(const char *desc, int n_pads, int w_px, int h_px, int fr
     return 0;
 }
 
+/* ---- chainbench: BASELINE config 4 as a throughput number.  N streams -> blobnetfilter (metapreprocess + nvstreammux + nvinfer +
+ * nvstreamdemux + maskcopy + bboxcc stand-in) -> per stream a `cova` element (embedded SORT + GoP frame filter) whose sink_enc gets
+ * the stream's encoded access units (dummy payloads; key frame every 250) -> counting sink.  pipeline/cova/pipeline.py:104-261.
+ * Carrier frames: per stream a cycle of 256 frames with a few ellipses of motion vectors bouncing across the grid (periodic in the
+ * cycle, so the stream is continuous for as long as it runs) over sparse background noise. ---- */
+typedef struct { guint64 bufs, lists; } chain_out_t;
+static GstFlowReturn chainb_chain(GstPad *pad, GstObject *parent, GstBuffer *b) {
+    chain_out_t *o = gst_pad_get_element_private(pad);
+    o->bufs++;
+    gst_buffer_unref(b);
+    return GST_FLOW_OK;
+}
+static GstFlowReturn chainb_chain_list(GstPad *pad, GstObject *parent, GstBufferList *l) {
+    chain_out_t *o = gst_pad_get_element_private(pad);
+    o->bufs += gst_buffer_list_length(l);
+    o->lists++;
+    gst_buffer_list_unref(l);
+    return GST_FLOW_OK;
+}
+typedef struct { GstPad *src; int first, n_frames, eos; } enc_feed_t;
+static gpointer enc_feeder(gpointer data) {
+    enc_feed_t *f = data;
+    for (int i = f->first; i < f->first + f->n_frames; i++) {
+        GstBuffer *b = gst_buffer_new_allocate(NULL, 64, NULL);
+        GST_BUFFER_PTS(b) = (GstClockTime)i * (GST_SECOND / 30);
+        if (i % 250) GST_BUFFER_FLAG_SET(b, GST_BUFFER_FLAG_DELTA_UNIT);
+        if (gst_pad_push(f->src, b) != GST_FLOW_OK) break;
+    }
+    if (f->eos) gst_pad_push_event(f->src, gst_event_new_eos());
+    return NULL;
+}
+static double tri_wave(double x) {   /* period 2, range [0, 1] */
+    x -= 2.0 * floor(x / 2.0);
+    return x < 1.0 ? x : 2.0 - x;
+}
+static void chain_make_frames(GstBuffer **bufs, int n, int wmb, int hmb, unsigned seed) {
+    struct { double cx, cy, lx, ly, rx, ry; int mx, my; double px, py; } ob[5];
+    unsigned x = seed * 2654435761u + 12345u;
+#define RND() (x = x * 1664525u + 1013904223u, (x >> 8) & 0xFFFF)
+    const int nob = 3 + RND() % 3;
+    for (int j = 0; j < nob; j++) {
+        ob[j].rx = 2.0 + RND() % 40 / 10.0; ob[j].ry = 2.0 + RND() % 40 / 10.0;
+        ob[j].cx = RND() % wmb; ob[j].cy = RND() % hmb;
+        ob[j].lx = wmb - 1; ob[j].ly = hmb - 1;
+        ob[j].mx = 1 + RND() % 3; ob[j].my = RND() % 3;
+        ob[j].px = RND() % 1000 / 500.0; ob[j].py = RND() % 1000 / 500.0;
+    }
+    for (int k = 0; k < n; k++) {
+        GstMapInfo m;
+        bufs[k] = gst_buffer_new_allocate(NULL, (gsize)wmb * hmb * 4, NULL);
+        gst_buffer_map(bufs[k], &m, GST_MAP_WRITE);
+        for (int q = 0; q < wmb * hmb; q++) {
+            const unsigned r = RND();
+            m.data[4 * q] = (r & 7) < 2 ? (r >> 4) % 7 : 0;
+            m.data[4 * q + 1] = (r >> 8) % 10 == 0 ? 1 + (r >> 3) % 3 : 0;
+            m.data[4 * q + 2] = (r >> 12) % 10 == 0 ? 1 + (r >> 5) % 3 : 0;
+            m.data[4 * q + 3] = (guint8)r;
+        }
+        for (int j = 0; j < nob; j++) {
+            /* m bounces across the span per cycle of n frames: the position is periodic in n */
+            const double cx = ob[j].lx * tri_wave(ob[j].px + 2.0 * ob[j].mx * k / n), cy = ob[j].ly * tri_wave(ob[j].py + 2.0 * ob[j].my * k / n);
+            for (int yy = (int)(cy - ob[j].ry) - 1; yy <= (int)(cy + ob[j].ry) + 1; yy++)
+                for (int xx = (int)(cx - ob[j].rx) - 1; xx <= (int)(cx + ob[j].rx) + 1; xx++) {
+                    if (yy < 0 || yy >= hmb || xx < 0 || xx >= wmb) continue;
+                    const double dx = (xx - cx) / ob[j].rx, dy = (yy - cy) / ob[j].ry;
+                    if (dx * dx + dy * dy > 1.0) continue;
+                    const unsigned r = RND();
+                    guint8 *px = m.data + 4 * (yy * wmb + xx);
+                    px[0] = 1 + r % 7; px[1] = 1 + (r >> 4) % 12; px[2] = 1 + (r >> 8) % 12;
+                }
+        }
+        gst_buffer_unmap(bufs[k], &m);
+    }
+#undef RND
+}
+static int run_chainbench(const char *desc, const char *cova_props, int n_pads, int w_px, int h_px, int frames_per_pad) {
+    GError *err = NULL;
+    GstElement *e = gst_parse_launch(desc, &err);
+    GstElement *cova[64];
+    bench_feed_t feeds[64];
+    enc_feed_t encs[64];
+    static chain_out_t outs[64];
+    GThread *th[64], *eth[64];
+    gchar *caps = g_strdup_printf("video/x-raw,format=I420,width=%d,height=%d,framerate=30/1", w_px, h_px);
+    gchar *cdesc = g_strdup_printf("cova %s", cova_props);
+    guint64 batches = 0;
+    const int cycle = 256;
+    if (!e || n_pads > 64) { fprintf(stderr, "chainbench setup failed: %s\n", err ? err->message : "?"); return 2; }
+    for (int i = 0; i < n_pads; i++) {
+        GstPad *esink = gst_element_get_request_pad(e, "sink_%u");
+        gchar *sn = g_strdup_printf("src_%d", i);
+        GstPad *esrc = gst_element_get_static_pad(e, sn);
+        GstPad *tsink = gst_pad_new("out", GST_PAD_SINK);
+        g_free(sn);
+        cova[i] = gst_parse_launch(cdesc, &err);
+        if (!cova[i]) { fprintf(stderr, "cova: %s\n", err ? err->message : "?"); return 2; }
+        feeds[i].src = gst_pad_new("in", GST_PAD_SRC);
+        feeds[i].n_bufs = cycle;
+        feeds[i].bufs = g_new(GstBuffer *, cycle);
+        chain_make_frames(feeds[i].bufs, cycle, w_px / 16, h_px / 16, 1000u + (unsigned)i);
+        encs[i].src = gst_pad_new("enc", GST_PAD_SRC);
+        gst_pad_set_element_private(tsink, &outs[i]);
+        gst_pad_set_chain_function(tsink, chainb_chain);
+        gst_pad_set_chain_list_function(tsink, chainb_chain_list);
+        gst_pad_set_event_function(tsink, mux_sink_event);
+        gst_pad_set_active(tsink, TRUE);
+        if (!esink || !esrc || gst_pad_link(feeds[i].src, esink) != GST_PAD_LINK_OK ||
+            gst_pad_link(esrc, gst_element_get_static_pad(cova[i], "sink_mask")) != GST_PAD_LINK_OK ||
+            gst_pad_link(encs[i].src, gst_element_get_static_pad(cova[i], "sink_enc")) != GST_PAD_LINK_OK ||
+            gst_pad_link(gst_element_get_static_pad(cova[i], "src"), tsink) != GST_PAD_LINK_OK) { fprintf(stderr, "chainbench link failed\n"); return 2; }
+        gst_element_set_state(cova[i], GST_STATE_PLAYING);
+    }
+    gst_element_set_state(e, GST_STATE_PLAYING);
+    for (int i = 0; i < n_pads; i++) {
+        gchar *sid = g_strdup_printf("s%d", i);
+        start_pad(encs[i].src, sid, "video/x-h264");
+        start_pad(feeds[i].src, sid, caps);
+        g_free(sid);
+    }
+    const int warm = 2048 / n_pads + 8;
+    int rc = 0;
+    gint64 t0 = 0, t1 = 0;
+    for (int phase = 0; phase < 2; phase++) {
+        const int first = phase ? warm : 0, n = phase ? frames_per_pad : warm;
+        /* the encoded branch runs ahead of the mask branch (an unbounded queue in the reference, pipeline.py:237-253) */
+        for (int i = 0; i < n_pads; i++) { encs[i].first = first; encs[i].n_frames = n; encs[i].eos = phase; }
+        for (int i = 0; i < n_pads; i++) eth[i] = g_thread_new("enc", enc_feeder, &encs[i]);
+        for (int i = 0; i < n_pads; i++) g_thread_join(eth[i]);
+        for (int i = 0; i < n_pads; i++) { feeds[i].first = first; feeds[i].n_frames = n; feeds[i].eos = phase; }
+        if (phase) t0 = g_get_monotonic_time();
+        for (int i = 0; i < n_pads; i++) th[i] = g_thread_new("feed", bench_feeder, &feeds[i]);
+        for (int i = 0; i < n_pads; i++) g_thread_join(th[i]);
+        if (phase) t1 = g_get_monotonic_time(); else g_usleep(300000);
+    }
+    g_usleep(200000);   /* the last batches drain through the pusher threads */
+    g_object_get(e, "batches", &batches, NULL);
+    {
+        guint64 fwd = 0, d = 0, dd = 0, di = 0;
+        for (int i = 0; i < n_pads; i++) {
+            guint64 a = 0, b = 0, c = 0;
+            g_object_get(cova[i], "dropped", &a, "decoded-dependency", &b, "decoded-inference", &c, NULL);
+            d += a; dd += b; di += c; fwd += outs[i].bufs;
+        }
+        { gchar *tm = NULL; g_object_get(e, "timing", &tm, NULL); fprintf(stderr, "timing at the end:   %s\n", tm ? tm : "?"); g_free(tm); }
+        printf("{\"frames_per_s_full_chain\": %.1f, \"streams\": %d, \"frames_in\": %d, \"batches\": %llu, \"seconds\": %.4f, "
+               "\"aus_forwarded\": %llu, \"dropped\": %llu, \"decoded_dependency\": %llu, \"decoded_inference\": %llu, \"eos\": %d}\n",
+               (double)n_pads * frames_per_pad / ((t1 - t0) * 1e-6), n_pads, n_pads * frames_per_pad, (unsigned long long)batches,
+               (t1 - t0) * 1e-6, (unsigned long long)fwd, (unsigned long long)d, (unsigned long long)dd, (unsigned long long)di, mux_eos);
+    }
+    for (int i = 0; i < n_pads; i++) gst_element_set_state(cova[i], GST_STATE_NULL);
+    gst_element_set_state(e, GST_STATE_NULL);
+    g_free(caps); g_free(cdesc);
+    return rc;
+}
+
 int main(int argc, char **argv) {
     gst_init(&argc, &argv);
+    if (argc >= 8 && !strcmp(argv[1], "chainbench")) return run_chainbench(argv[2], argv[3], atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]));
     if (argc >= 7 && !strcmp(argv[1], "muxbench")) return run_muxbench(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
     if (argc >= 7 && !strcmp(argv[1], "mux")) return run_mux(argv[2], atoi(argv[3]), argv[4], argv[5], argv[6], argc > 7 ? atoi(argv[7]) : 0);
     if (argc >= 6 && !strcmp(argv[1], "harness")) return run_harness(argv[2], argv[3], argv[4], argv[5]);

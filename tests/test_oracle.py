@@ -86,3 +86,20 @@ def test_weights_roundtrip_and_count():
     np.testing.assert_array_equal(W.flatten(W.unflatten(flat)), flat)
     with pytest.raises(ValueError):
         W.from_bytes(b"\0" * 64 + flat.tobytes())
+
+
+def test_blob_like_weights_give_connected_blobs_over_the_moving_objects():
+    """cova_amd.weights.blob_like: the representative weight set of the element / pipe / chain legs of bench.py -- a few
+    connected components over the synthetic objects (whatever they cover: 1 .. 10 % here), nothing in the background."""
+    from cova_amd import weights as W
+    flat = W.blob_like(7)
+    h, w = 45, 80
+    fr = synth.carrier_frames(10, h, w, seed=5, n_objects=4)
+    stack = np.stack([np.concatenate([fr[i - k] for k in range(4)], axis=0) for i in range(3, 10)])
+    _, mask = ref.blobnet_forward(flat, stack, h, w)
+    for i in range(len(stack)):
+        cur = fr[i + 3]
+        moving = ndimage.binary_dilation((cur[..., 1] > 3) | (cur[..., 2] > 3), iterations=3)
+        assert not (mask[i].astype(bool) & ~moving).any()           # nothing outside the (dilated) objects
+        _, k = ndimage.label(mask[i], structure=np.ones((3, 3), int))
+        assert 1 <= k <= 6 and 0.005 < mask[i].mean() < 0.12   # (as much as the objects cover)
