@@ -371,7 +371,7 @@ def main():
             pre["through_gstreamer_elements"] = element_rate()
             # BASELINE config 4: metapreprocess -> BlobNet -> bboxcc -> cova (embedded SORT + GoP filter) per stream, the
             # experiment's tracker parameters, blob-like weights (a few boxes per frame, as a trained BlobNet gives)
-            chain = element_rate("chain_bench.sh", ("6000", "16"))
+            chain = element_rate("chain_bench.sh", ("20000", "16"))
             if "frames_per_s_full_chain" in chain:
                 t_cova = chain["seconds"] * min(16, os.cpu_count() or 1) / max(1, chain["frames_in"])
                 chain["limiter"] = ("host: the per-stream cova elements (SORT with the experiment's minhits 30 / maxage 60 keeps "
