@@ -343,6 +343,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=2,
                     help="batches in flight per GPU (covahip_ctx_set_lanes): 1 = one step after the other on one stream")
     ap.add_argument("--min-warmup-s", type=float, default=0.3, help="warm up for at least this long on top of --warmup steps")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="developer rehearsal of the multi-rank path on a box with fewer GPUs than ranks: rank r uses GPU r %% (GPUs present); "
+                         "the line then says so and its value is NOT a scaling result")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="only the timed workload (profiling runs)")
     args = ap.parse_args()
@@ -384,7 +387,9 @@ def main():
             pre["cpu_tracking"] = cpu_tracking_baseline()
 
     from cova_amd.multigpu import Group
-    grp = Group()            # torch.distributed (RCCL) only when WORLD_SIZE > 1: rendezvous/barrier/MAX
+    # torch.distributed (RCCL) only when WORLD_SIZE > 1: rendezvous/barrier/MAX (gloo in a rehearsal: two ranks cannot open
+    # one GPU as two RCCL devices)
+    grp = Group("gloo" if args.rehearse_on_one_gpu else None)
     rank, local_rank, world = grp.rank, grp.local_rank, grp.world
     if world != args.gpus:
         sys.exit(f"bench.py: world size {world} != --gpus {args.gpus}")
@@ -392,7 +397,14 @@ def main():
     from cova_amd import synth, weights as W
     from cova_amd.elements import BlobNetInfer, Context
 
-    ctx = Context(local_rank)
+    dev = local_rank
+    if args.rehearse_on_one_gpu:
+        import ctypes as C
+        from cova_amd import _lib as L
+        n_dev = C.c_int(0)
+        L.lib().covahip_device_count(C.byref(n_dev))
+        dev = local_rank % max(1, n_dev.value)
+    ctx = Context(dev)
     ctx.set_lanes(1)         # the extra legs and the per-kernel pass run one step after the other
     B = args.batch
     NL = max(1, min(4, args.lanes))
@@ -569,6 +581,7 @@ def main():
             "dtype": "f16",
             "data": "synthetic",
             "lanes": NL,
+            **({"rehearsal": f"{world} ranks shared the GPUs present on this box: not a scaling result"} if args.rehearse_on_one_gpu else {}),
             "ms_per_step_one_lane": round(serial_ms, 4),
             "shader_clock_mhz_under_load": round(clock_mhz, 1),
             "blobnet_mfma_util_whole_net": round(total_flop / step_s / 1e12 / MFMA_PEAK_TFLOPS, 4),
