@@ -102,6 +102,7 @@ PROTOTYPES = {
     "covahip_pipe_acquire": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(_P)]),
     "covahip_pipe_submit": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "covahip_pipe_wait": (C.c_int, [_P, C.c_int]),
+    "covahip_pipe_abort": (C.c_int, [_P, C.c_int]),
     "covahip_pipe_collect": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "covahip_pipe_release": (C.c_int, [_P, C.c_int]),
     "covahip_boxes_to_bbox": (None, [_P, C.c_int, _P]),

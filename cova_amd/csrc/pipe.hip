@@ -227,6 +227,12 @@ int covahip_pipe_wait(covahip_pipe *p, int slot) {
     return COVAHIP_OK;
 }
 
+int covahip_pipe_abort(covahip_pipe *p, int slot) {
+    if (!p || slot < 0 || slot >= p->n_slots || p->slots[slot].state != 1) return COVAHIP_ERR_INVALID_ARG;
+    p->slots[slot].state = 0;
+    return COVAHIP_OK;
+}
+
 int covahip_pipe_release(covahip_pipe *p, int slot) {
     if (!p || slot < 0 || slot >= p->n_slots || p->slots[slot].state != 3) return COVAHIP_ERR_INVALID_ARG;
     p->slots[slot].state = 0;

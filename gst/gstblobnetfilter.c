@@ -43,6 +43,7 @@ typedef struct {
     gint hist_pos[BF_TIMESTEP - 1];  /* their position in the slot being filled, -1 = not copied into it yet */
     guint n_seen;
     gboolean eos, caps_sent;
+    gint src_ret;                     /* last GstFlowReturn of a push on src that was neither OK nor NOT_LINKED (atomic) */
 } BfPad;
 
 typedef struct { guint pad; GstClockTime pts, duration; } BfMeta;
@@ -150,7 +151,7 @@ static gboolean bf_ensure_model(GstBlobNetFilter *s) {   /* lock held */
 /* One share of a finished batch: the boxes of every stack of this pusher's src pads as bincode Vec<Bbox> buffers with
  * the frame's PTS (bboxcc/imp.rs:232-272).  A src pad is served by exactly one pusher thread and every pusher takes the
  * batches in order: buffers leave every pad in order.  Whoever pushes the last share of a batch releases its slot. */
-static void bf_push_share(GstBlobNetFilter *s, BfFlight *fl, guint group, covahip_bbox *bb) {
+static void bf_push_share(GstBlobNetFilter *s, BfFlight *fl, guint group, covahip_bbox **bbp, gsize *bb_cap) {
     GstFlowReturn ret = GST_FLOW_OK;
     const gint64 t0 = g_get_monotonic_time();
     for (int i = 0; i < fl->n_stacks; i++) {
@@ -160,6 +161,15 @@ static void bf_push_share(GstBlobNetFilter *s, BfFlight *fl, guint group, covahi
         int st = 0;
         GstMapInfo m;
         BfPad *p = g_ptr_array_index(s->pads, mt->pad);
+        covahip_bbox *bb;
+        /* a src pad whose downstream has finished (EOS) takes no more buffers; the other streams go on */
+        if (g_atomic_int_get(&p->src_ret) == GST_FLOW_EOS) continue;
+        if ((gsize)n > *bb_cap) {   /* sized by what the batch holds, whatever max-boxes was when the thread started */
+            g_free(*bbp);
+            *bb_cap = (gsize)n + 64;
+            *bbp = g_new(covahip_bbox, *bb_cap);
+        }
+        bb = *bbp;
         if (fl->counts[i] > n) GST_WARNING_OBJECT(s, "frame with %d boxes truncated to max-boxes = %d", fl->counts[i], n);
         covahip_boxes_to_bbox(fl->boxes + fl->offsets[i], n, bb);                /* Bbox::new, process.rs:47 */
         const gsize len = covahip_bbox_serialize_vec(bb, (size_t)n, NULL, 0, NULL);
@@ -170,7 +180,13 @@ static void bf_push_share(GstBlobNetFilter *s, BfFlight *fl, guint group, covahi
         GST_BUFFER_PTS(b) = mt->pts;
         GST_BUFFER_DURATION(b) = mt->duration;
         const GstFlowReturn r = gst_pad_push(p->src, b);
-        if (r != GST_FLOW_OK && r != GST_FLOW_NOT_LINKED && ret == GST_FLOW_OK) ret = r;
+        if (r != GST_FLOW_OK && r != GST_FLOW_NOT_LINKED) {
+            /* EOS / FLUSHING concern this stream only (its own chain function returns them); errors stop the element */
+            g_atomic_int_set(&p->src_ret, (gint)r);
+            if (r != GST_FLOW_EOS && r != GST_FLOW_FLUSHING && ret == GST_FLOW_OK) ret = r;
+        } else if (g_atomic_int_get(&p->src_ret) == GST_FLOW_FLUSHING) {
+            g_atomic_int_set(&p->src_ret, GST_FLOW_OK);   /* the flush is over */
+        }
     }
     g_atomic_int_add(&s->pushers_us, (gint)(g_get_monotonic_time() - t0));
     const gboolean last = g_atomic_int_dec_and_test(&fl->shares_left);
@@ -197,10 +213,11 @@ static void bf_push_share(GstBlobNetFilter *s, BfFlight *fl, guint group, covahi
 static gpointer bf_pusher(gpointer data) {
     BfPusher *pu = data;
     GstBlobNetFilter *s = pu->s;
-    covahip_bbox *bb = g_new(covahip_bbox, s->max_boxes ? s->max_boxes : 1);
+    covahip_bbox *bb = NULL;
+    gsize bb_cap = 0;
     gpointer item;
     while ((item = g_async_queue_pop(pu->q)) != (gpointer)pu)   /* the pusher's own address is the stop token */
-        bf_push_share(s, item, pu->group, bb);
+        bf_push_share(s, item, pu->group, &bb, &bb_cap);
     g_free(bb);
     return NULL;
 }
@@ -218,6 +235,7 @@ static gpointer bf_submitter(gpointer data) {
         g_mutex_unlock(&s->lock);
         g_mutex_lock(&s->pipe_lock);
         rc = covahip_pipe_submit(s->pipe, fl->slot, fl->n_frames, fl->n_stacks, (int)fl->cc_threshold);
+        if (rc != COVAHIP_OK) covahip_pipe_abort(s->pipe, fl->slot);   /* the slot goes back to the pool */
         g_mutex_unlock(&s->pipe_lock);
         if (rc != COVAHIP_OK)
             GST_ELEMENT_ERROR(s, LIBRARY, FAILED, ("covahip_pipe_submit: %s (%s)", covahip_strerror(rc), covahip_last_hip_error(s->ctx)), (NULL));
@@ -310,6 +328,7 @@ static GstFlowReturn bf_flush(GstBlobNetFilter *s) {   /* caller: lock held, s->
      * `flushing` keeps the other streaming threads out meanwhile).  Frames without a complete stack yet (stream start)
      * stay where they are and the same slot goes on being filled. */
     while (s->slot < 0 && ret == GST_FLOW_OK) {
+        if (s->push_ret != GST_FLOW_OK) { ret = s->push_ret; break; }   /* a failed element waits for nothing */
         g_mutex_lock(&s->pipe_lock);
         rc = covahip_pipe_acquire(s->pipe, &s->slot, &s->pf, &s->pi);
         g_mutex_unlock(&s->pipe_lock);
@@ -403,6 +422,10 @@ static GstFlowReturn bf_chain(GstPad *pad, GstObject *parent, GstBuffer *buf) {
     uint8_t *pf = NULL;
     int pos = 0, taken = 0;
     gboolean full = FALSE;
+    {   /* this stream's own downstream has finished or is flushing: say so upstream, the other streams are not affected */
+        const gint own = g_atomic_int_get(&p->src_ret);
+        if (own == GST_FLOW_EOS || own == GST_FLOW_FLUSHING) { gst_buffer_unref(buf); return (GstFlowReturn)own; }
+    }
     if (gst_buffer_get_size(buf) < s->frame_bytes || !s->frame_bytes) {
         GST_ELEMENT_ERROR(s, STREAM, FORMAT, ("carrier frame of %" G_GSIZE_FORMAT " bytes, need %" G_GSIZE_FORMAT " (caps set?)",
                                               gst_buffer_get_size(buf), s->frame_bytes), (NULL));
@@ -468,7 +491,10 @@ static gpointer bf_timer(gpointer data) {
             else if (g_get_monotonic_time() >= due) bf_flush(s);
             else g_cond_wait_until(&s->cond, &s->lock, due);
         } else {
-            g_cond_wait_until(&s->cond, &s->lock, g_get_monotonic_time() + 50 * G_TIME_SPAN_MILLISECOND);
+            /* the wake-up of the first stack of a batch is sent without the lock (lock-free path) and may be missed: with a
+             * timeout configured the thread looks again after a quarter of it (at most 50 ms) */
+            const gint64 nap = s->timeout_us > 0 ? MIN((gint64)s->timeout_us / 4 + 1, 50 * G_TIME_SPAN_MILLISECOND) : 50 * G_TIME_SPAN_MILLISECOND;
+            g_cond_wait_until(&s->cond, &s->lock, g_get_monotonic_time() + nap);
         }
     }
     g_mutex_unlock(&s->lock);

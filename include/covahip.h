@@ -194,6 +194,9 @@ int covahip_pipe_create(covahip_ctx *ctx, int max_batch, int max_frames, int max
 void covahip_pipe_destroy(covahip_pipe *pipe);
 int covahip_pipe_acquire(covahip_pipe *pipe, int *slot, uint8_t **frames, int32_t **stack_index);
 int covahip_pipe_submit(covahip_pipe *pipe, int slot, int n_frames, int batch, int area_thresh);
+/* Gives an ACQUIRED slot back without submitting it (after a failed covahip_pipe_submit, or when the caller shuts down with
+ * a partly filled batch). */
+int covahip_pipe_abort(covahip_pipe *pipe, int slot);
 int covahip_pipe_wait(covahip_pipe *pipe, int slot);
 int covahip_pipe_collect(covahip_pipe *pipe, int slot, const int32_t **counts, const int32_t **offsets,
                          const covahip_box **boxes, const uint8_t **mask);
