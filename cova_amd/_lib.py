@@ -50,7 +50,7 @@ H264_INFO_DTYPE = np.dtype([(n, "<i4") for n in ("width_mbs", "height_mbs", "n_s
                                                 "weighted_bipred", "poc_type")])
 H264_SLICE_DTYPE = np.dtype([("nal_offset", "<u8"), ("nal_bytes", "<u4"), ("data_bit_offset", "<u4")] +
                             [(n, "<i4") for n in ("nal_type", "slice_type", "first_mb", "frame_num", "idr", "poc_lsb", "qp",
-                                                  "cabac_init_idc", "num_ref_l0", "num_ref_l1", "direct_spatial")] + [("_pad", "<u4")])
+                                                  "cabac_init_idc", "num_ref_l0", "num_ref_l1", "direct_spatial", "nal_ref_idc", "has_mmco5")] + [("_pad", "<u4")])
 
 KERNEL_TIME_DTYPE = np.dtype([("name", "S48"), ("total_ms", "<f8"), ("launches", "<i8")])
 
@@ -128,6 +128,7 @@ PROTOTYPES = {
     "covahip_h264_sample": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "covahip_h264_sample_slices": (C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
     "covahip_h264_decode_records": (C.c_int, [_P, C.c_int, _P, _SZ]),
+    "covahip_h264_display_order": (C.c_int, [_P, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "covahip_carrier_write_records": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _SZ]),
     "covahip_stack_new": (C.c_int, [_SZ, C.c_uint, C.c_uint, C.POINTER(_P)]),
     "covahip_stack_free": (None, [_P]),

@@ -1,0 +1,35 @@
+// Macroblock-layer parsing of one CABAC slice (h264_cabac.cpp), used by covahip_h264_decode_records (h264_front.cpp).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "covahip.h"
+
+namespace h264 {
+
+struct SliceParams {
+    int slice_type = 2;          // 0 P, 1 B, 2 I
+    int first_mb = 0;
+    int qp = 26;                 // SliceQPY
+    int cabac_init_idc = 0;
+    int num_ref_l0 = 1, num_ref_l1 = 1;
+    int width_mbs = 0, height_mbs = 0;
+    int transform_8x8 = 0;       // PPS transform_8x8_mode_flag
+    int direct_8x8_inference = 0;
+    int chroma_format = 1;
+};
+
+// Parses slice_data() of one slice that covers a whole frame picture.  rbsp: the NAL unit's payload behind its header byte
+// with the emulation-prevention bytes removed; bit_offset: first bit of slice_data() (covahip_h264_slice.data_bit_offset).
+// records (may be NULL): width_mbs * height_mbs entries of 4 bytes,
+//   [0] macroblock class: 0 P_Skip / B_Skip, 1 inter 16x16, 2 inter 16x8 / 8x16, 3 inter 8x8 (sub-partitions), 4 B_Direct_16x16,
+//       5 intra NxN (4x4 / 8x8), 6 intra 16x16, 7 I_PCM;
+//   [1], [2] the largest |mvd_x|, |mvd_y| of the macroblock's partitions in full pixels (rounded from quarter pixels, <= 255).
+//       These are motion vector DIFFERENCES as coded, not motion vectors: prediction (median, skip, direct) is not performed;
+//   [3] 0.
+// Returns COVAHIP_OK only if exactly width_mbs * height_mbs macroblocks were decoded, end_of_slice_flag came with the last one and
+// nothing but trailing bits followed.  *why (may be NULL) names the first inconsistency otherwise.
+int parse_slice_cabac(const uint8_t *rbsp, size_t len, size_t bit_offset, const SliceParams &sp, uint8_t *records, std::string *why);
+
+}  // namespace h264

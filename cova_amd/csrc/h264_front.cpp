@@ -1,24 +1,30 @@
-// Entropy-decode front end, container and header layer.
+// Entropy-decode front end: container, headers, picture order; the macroblock layer is
+// h264_cabac.cpp.
 //
 // The reference feeds its filter from a patched FFmpeg `avdec_h264` that stops after entropy decoding and writes one
 // 4-byte record [mb_type, mv_x, mv_y, -] per macroblock into the first bytes of its I420 output frame (README.md:94-114,
 // pipeline/cova/pipeline.py:84-99; consumers: metapreprocess/imp.rs:233,311-312, tfrecordsink/imp.rs:105-112).  That
-// decoder is an un-vendored submodule.  What is built here is the part of such a front end that can be verified in this
-// image against the reference's own demo/1m.mp4:
+// decoder is an un-vendored submodule, so what its record bytes mean exactly is not known here; the
+// layout is.  Built, and verified against the reference's own demo/1m.mp4 (tests/test_host_h264.py):
 //   * ISO-BMFF demux of the video track (avcC, stsz / stsc / stco / co64 / stss): access units with their key-frame flag,
 //   * NAL unit split (length prefixed), emulation-prevention removal,
 //   * SPS / PPS parse, slice header parse up to the first bit of slice_data() (ITU-T H.264 7.3.2.1, 7.3.2.2, 7.3.3),
+//   * picture order counts (8.2.1, types 0 and 2) and the output (display) order of the access units -- avdec_h264 hands
+//     frames downstream in that order, and metapreprocess stacks consecutive OUTPUT frames,
+//   * covahip_h264_decode_records: CABAC macroblock layer of a whole-picture slice -> records (h264_cabac.h says what the
+//     three bytes are: macroblock class and the coded motion vector differences, no prediction),
 //   * the carrier layout writer (covahip_carrier_write_records).
-// NOT built: macroblock-layer parsing.  demo/1m.mp4 is High profile with CABAC (entropy_coding_mode_flag = 1, 8x8
-// transform, B slices, weighted prediction); a CABAC parser needs the 1,024 x 4 context-initialisation pairs of the
-// standard's tables 9-12 .. 9-33, and nothing in this image (no libavcodec, no x264, no network) holds them to check a
-// transcription against -- one wrong value silently desynchronises the arithmetic decoder.  covahip_h264_decode_records
-// therefore returns COVAHIP_ERR_UNSUPPORTED for CABAC streams, loudly, instead of emitting unverified records.
+// Refused loudly (COVAHIP_ERR_UNSUPPORTED), never faked: CAVLC, field / MBAFF coding, several slices per picture, FMO,
+// scaling matrices, chroma formats other than 4:2:0, cabac_init_idc 1 / 2.
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <vector>
 
 #include "covahip.h"
+#include "h264_cabac.h"
 
 namespace {
 
@@ -63,12 +69,14 @@ std::vector<uint8_t> unescape(const uint8_t *d, size_t n) {   // 7.4.1: drop emu
 }
 
 struct Sps {
+    int id = 0;
     int profile = 0, level = 0, chroma_format = 1, log2_max_frame_num = 4, poc_type = 0, log2_max_poc_lsb = 4;
     int delta_pic_order_always_zero = 0, num_ref_frames = 0, width_mbs = 0, height_map_units = 0, frame_mbs_only = 1, mbaff = 0;
     int direct_8x8 = 0;
     bool ok = false;
 };
 struct Pps {
+    int id = 0, sps_id = 0;
     int entropy_cabac = 0, bottom_field_pic_order = 0, num_slice_groups = 1, num_ref_l0 = 1, num_ref_l1 = 1, weighted_pred = 0,
         weighted_bipred = 0, pic_init_qp = 26, deblocking_control = 0, redundant_pic_cnt = 0, transform_8x8 = 0;
     bool ok = false;
@@ -78,7 +86,7 @@ bool parse_sps(const std::vector<uint8_t> &rbsp, Sps &s) {
     if (rbsp.size() < 5) return false;
     BitReader r(rbsp.data() + 1, rbsp.size() - 1);
     s.profile = (int)r.u(8); r.u(8); s.level = (int)r.u(8);
-    r.ue();   // seq_parameter_set_id
+    s.id = (int)r.ue();
     if (s.profile == 100 || s.profile == 110 || s.profile == 122 || s.profile == 244 || s.profile == 44 || s.profile == 83 ||
         s.profile == 86 || s.profile == 118 || s.profile == 128) {
         s.chroma_format = (int)r.ue();
@@ -110,7 +118,8 @@ bool parse_sps(const std::vector<uint8_t> &rbsp, Sps &s) {
 bool parse_pps(const std::vector<uint8_t> &rbsp, Pps &p) {
     if (rbsp.size() < 3) return false;
     BitReader r(rbsp.data() + 1, rbsp.size() - 1);
-    r.ue(); r.ue();
+    p.id = (int)r.ue();
+    p.sps_id = (int)r.ue();
     p.entropy_cabac = (int)r.u(1);
     p.bottom_field_pic_order = (int)r.u(1);
     p.num_slice_groups = (int)r.ue() + 1;
@@ -149,6 +158,8 @@ struct covahip_h264 {
     Sps sps;
     Pps pps;
     std::vector<Sample> samples;
+    std::vector<int64_t> order_key;     // per sample: (IDR period << 32) + picture order count + 2^31; empty when not computable
+    std::vector<int32_t> display;       // sample indices in output order
 };
 
 namespace {
@@ -176,10 +187,12 @@ int parse_slice_header(const covahip_h264 *h, const uint8_t *nal, size_t n, cova
     const Sps &sp = h->sps;
     const Pps &pp = h->pps;
     s->nal_type = nal_type;
+    s->nal_ref_idc = nal_ref_idc;
+    s->has_mmco5 = 0;
     s->first_mb = (int)r.ue();
     const int st = (int)r.ue();
     s->slice_type = st % 5;   // 0 P, 1 B, 2 I, 3 SP, 4 SI
-    r.ue();                   // pic_parameter_set_id
+    if (r.ue() != (uint32_t)pp.id) return COVAHIP_ERR_UNSUPPORTED;   // pic_parameter_set_id: only the first PPS of avcC is kept
     s->frame_num = (int)r.u(sp.log2_max_frame_num);
     if (!sp.frame_mbs_only) return COVAHIP_ERR_UNSUPPORTED;   // field / MBAFF coding
     s->idr = nal_type == 5;
@@ -234,9 +247,11 @@ int parse_slice_header(const covahip_h264 *h, const uint8_t *nal, size_t n, cova
             uint32_t op;
             do {
                 op = r.ue();
-                if (op == 1 || op == 3) r.ue();
-                if (op == 2) r.ue();
-                if (op == 3 || op == 4) r.ue();
+                if (op == 1 || op == 3) r.ue();   // difference_of_pic_nums_minus1
+                if (op == 2) r.ue();              // long_term_pic_num
+                if (op == 3 || op == 6) r.ue();   // long_term_frame_idx
+                if (op == 4) r.ue();              // max_long_term_frame_idx_plus1
+                if (op == 5) s->has_mmco5 = 1;    // resets the picture order count (8.2.1)
             } while (op != 0 && !r.bad);
         }
     }
@@ -259,9 +274,58 @@ int parse_slice_header(const covahip_h264 *h, const uint8_t *nal, size_t n, cova
     return COVAHIP_OK;
 }
 
+// Picture order count of every access unit (8.2.1.1 type 0, 8.2.1.3 type 2; frames only) and the output order: within an IDR
+// period pictures leave the decoder by ascending POC.  Leaves `display` empty when a header does not parse or for type 1.
+void compute_display_order(covahip_h264 *h) {
+    const size_t n = h->samples.size();
+    h->order_key.assign(n, 0);
+    const Sps &sp = h->sps;
+    if (sp.poc_type == 1) { h->order_key.clear(); return; }
+    const int64_t max_lsb = 1ll << sp.log2_max_poc_lsb, max_fn = 1ll << sp.log2_max_frame_num;
+    int64_t prev_msb = 0, prev_lsb = 0, period = -1, fn_off = 0, prev_fn = 0;
+    for (size_t i = 0; i < n; i++) {
+        covahip_h264_slice sl[1];
+        int cnt = 0;
+        const int rc = covahip_h264_sample_slices(h, (int)i, sl, 1, &cnt);
+        if ((rc != COVAHIP_OK && rc != COVAHIP_ERR_OVERFLOW) || cnt < 1) { h->order_key.clear(); return; }
+        const bool idr = sl[0].idr != 0, ref = sl[0].nal_ref_idc != 0;
+        int64_t poc;
+        if (idr) { period++; prev_msb = prev_lsb = 0; fn_off = 0; }
+        if (period < 0) period = 0;
+        if (sp.poc_type == 0) {
+            const int64_t lsb = sl[0].poc_lsb;
+            int64_t msb = prev_msb;
+            if (lsb < prev_lsb && prev_lsb - lsb >= max_lsb / 2) msb = prev_msb + max_lsb;
+            else if (lsb > prev_lsb && lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
+            poc = msb + lsb;
+            if (ref) {
+                if (sl[0].has_mmco5) { prev_msb = 0; prev_lsb = poc; }   // after memory_management_control_operation 5 (frames: tempPicOrderCnt)
+                else { prev_msb = msb; prev_lsb = lsb; }
+            }
+        } else {
+            if (!idr && sl[0].frame_num < prev_fn) fn_off += max_fn;
+            poc = 2 * (fn_off + sl[0].frame_num) - (ref ? 0 : 1);
+            if (idr) poc = 0;
+        }
+        prev_fn = sl[0].frame_num;
+        h->order_key[i] = (period << 32) + poc + (1ll << 31);
+    }
+    h->display.resize(n);
+    for (size_t i = 0; i < n; i++) h->display[i] = (int32_t)i;
+    std::stable_sort(h->display.begin(), h->display.end(), [&](int32_t a, int32_t b) { return h->order_key[a] < h->order_key[b]; });
+}
+
 }  // namespace
 
 extern "C" {
+
+int covahip_h264_display_order(const covahip_h264 *h, int32_t *samples, int cap, int *n) {
+    if (!h || !n || (!samples && cap)) return COVAHIP_ERR_INVALID_ARG;
+    if (h->display.empty()) return COVAHIP_ERR_UNSUPPORTED;
+    *n = (int)h->display.size();
+    for (int i = 0; i < cap && i < *n; i++) samples[i] = h->display[i];
+    return cap < *n ? COVAHIP_ERR_OVERFLOW : COVAHIP_OK;
+}
 
 int covahip_h264_open_mp4(const uint8_t *file, size_t len, covahip_h264 **out) {
     if (!file || !out || len < 16) return COVAHIP_ERR_INVALID_ARG;
@@ -303,6 +367,7 @@ int covahip_h264_open_mp4(const uint8_t *file, size_t len, covahip_h264 **out) {
             p += 2 + l;
         }
         if (!h->sps.ok || !h->pps.ok) { delete h; return COVAHIP_ERR_BAD_DATA; }
+        if (h->pps.sps_id != h->sps.id) { delete h; return COVAHIP_ERR_UNSUPPORTED; }   // only the first SPS / PPS of avcC are kept
         // sample sizes, chunk offsets, samples per chunk, sync samples
         size_t zb, ze, cb, ce, scb, sce;
         if (!find_box(file, sb, se, "stsz", zb, ze) || !find_box(file, sb, se, "stsc", scb, sce)) { delete h; return COVAHIP_ERR_BAD_DATA; }
@@ -314,12 +379,10 @@ int covahip_h264_open_mp4(const uint8_t *file, size_t len, covahip_h264 **out) {
         if (ns > (1u << 26) || nchunks > (1u << 26) || nsc > (1u << 20)) { delete h; return COVAHIP_ERR_BAD_DATA; }
         if ((!fixed && zb + 12 + 4ull * ns > ze) || cb + 8 + (co64 ? 8ull : 4ull) * nchunks > ce || scb + 8 + 12ull * nsc > sce) { delete h; return COVAHIP_ERR_BAD_DATA; }
         h->samples.resize(ns);
-        uint32_t si = 0;
+        uint32_t si = 0, sck = 0, per = 0;
         for (uint32_t c = 0; c < nchunks && si < ns; c++) {
-            // samples per chunk: the last stsc entry whose first_chunk <= c + 1
-            uint32_t per = 0;
-            for (uint32_t k = 0; k < nsc; k++)
-                if (be32(file + scb + 8 + 12 * k) <= c + 1) per = be32(file + scb + 8 + 12 * k + 4);
+            // samples per chunk: the last stsc entry whose first_chunk <= c + 1 (entries are in chunk order: one running index)
+            while (sck < nsc && be32(file + scb + 8 + 12 * sck) <= c + 1) per = be32(file + scb + 8 + 12 * sck++ + 4);
             uint64_t off = co64 ? be64(file + cb + 8 + 8ull * c) : be32(file + cb + 8 + 4ull * c);
             for (uint32_t k = 0; k < per && si < ns; k++, si++) {
                 const uint32_t sz = fixed ? fixed : be32(file + zb + 12 + 4ull * si);
@@ -342,6 +405,7 @@ int covahip_h264_open_mp4(const uint8_t *file, size_t len, covahip_h264 **out) {
         found = true;
     }
     if (!found) { delete h; return COVAHIP_ERR_BAD_DATA; }
+    compute_display_order(h);
     *out = h;
     return COVAHIP_OK;
 }
@@ -405,11 +469,33 @@ int covahip_h264_sample_slices(const covahip_h264 *h, int sample, covahip_h264_s
 
 int covahip_h264_decode_records(const covahip_h264 *h, int sample, uint8_t *records, size_t cap) {
     if (!h || sample < 0 || sample >= (int)h->samples.size()) return COVAHIP_ERR_INVALID_ARG;
-    (void)records;
-    (void)cap;
-    // macroblock_layer(): CABAC is not built (see the header of this file); CAVLC streams are not accepted either, so that no
-    // caller mistakes a partial decoder for a complete one
-    return COVAHIP_ERR_UNSUPPORTED;
+    const int wmb = h->sps.width_mbs, hmb = h->sps.height_map_units;
+    if (records && cap < (size_t)wmb * hmb * 4) return COVAHIP_ERR_OVERFLOW;
+    // CAVLC streams, field / MBAFF coding, several slices per picture: not built -- refused, never faked
+    if (!h->pps.entropy_cabac || !h->sps.frame_mbs_only) return COVAHIP_ERR_UNSUPPORTED;
+    covahip_h264_slice sl[2];
+    int n = 0;
+    int rc = covahip_h264_sample_slices(h, sample, sl, 2, &n);
+    if (rc == COVAHIP_ERR_OVERFLOW || n != 1) return COVAHIP_ERR_UNSUPPORTED;
+    if (rc) return rc;
+    const std::vector<uint8_t> rbsp = unescape(h->data + sl[0].nal_offset + 1, sl[0].nal_bytes - 1);
+    h264::SliceParams sp;
+    sp.slice_type = sl[0].slice_type;
+    sp.first_mb = sl[0].first_mb;
+    sp.qp = sl[0].qp;
+    sp.cabac_init_idc = sl[0].cabac_init_idc < 0 ? 0 : sl[0].cabac_init_idc;
+    sp.num_ref_l0 = sl[0].num_ref_l0;
+    sp.num_ref_l1 = sl[0].num_ref_l1;
+    sp.width_mbs = wmb;
+    sp.height_mbs = hmb;
+    sp.transform_8x8 = h->pps.transform_8x8;
+    sp.direct_8x8_inference = h->sps.direct_8x8;
+    sp.chroma_format = h->sps.chroma_format;
+    if (sl[0].slice_type != 2 && sl[0].cabac_init_idc != 0) return COVAHIP_ERR_UNSUPPORTED;
+    std::string why;
+    rc = h264::parse_slice_cabac(rbsp.data(), rbsp.size(), sl[0].data_bit_offset, sp, records, &why);
+    if (rc && getenv("COVAHIP_H264_DEBUG")) fprintf(stderr, "covahip_h264_decode_records: sample %d: %s\n", sample, why.c_str());
+    return rc;
 }
 
 int covahip_carrier_write_records(const uint8_t *mb_type, const uint8_t *mv_x, const uint8_t *mv_y, int width_mbs, int height_mbs,

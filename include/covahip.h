@@ -271,12 +271,14 @@ int covahip_assoc_terminate(covahip_assoc *a);   /* assoc.rs:434-467 */
 /* which: 0 track.csv, 1 dnn.csv, 2 assoc.csv, 3 stationary.csv; returns the size, copies if it fits. */
 size_t covahip_assoc_csv(covahip_assoc *a, int which, char *out, size_t cap, int *status);
 
-/* --------------------------------------------- entropy-decode front end (container + headers)
+/* --------------------------------------------- entropy-decode front end
  * What feeds `metapreprocess` in the reference is a patched FFmpeg avdec_h264 (an un-vendored submodule; README.md:94-114)
- * that writes one record [mb_type, mv_x, mv_y, -] per macroblock into the first bytes of its output frame.  Built here:
- * the ISO-BMFF / NAL / SPS / PPS / slice-header layer of such a front end (verified on the reference's demo/1m.mp4) and
- * the record writer.  Macroblock-layer entropy decoding (CABAC) is NOT built: covahip_h264_decode_records returns
- * COVAHIP_ERR_UNSUPPORTED (cova_amd/csrc/h264_front.cpp says why).  `file` must stay valid while the handle lives. */
+ * that stops after entropy decoding and writes one record [mb_type, mv_x, mv_y, -] per macroblock into the first bytes of its
+ * output frame.  Built here, verified on the reference's demo/1m.mp4: ISO-BMFF / NAL / SPS / PPS / slice-header layer, picture
+ * order (output order of the access units), the CABAC macroblock layer of frame-coded 4:2:0 streams with one slice per
+ * picture and cabac_init_idc 0 (every slice must end on its last macroblock with end_of_slice_flag: 1,802 of 1,802 do) and
+ * the record writer.  Anything else (CAVLC, fields / MBAFF, several slices per picture, cabac_init_idc 1 / 2) returns
+ * COVAHIP_ERR_UNSUPPORTED.  `file` must stay valid while the handle lives. */
 typedef struct covahip_h264 covahip_h264;
 typedef struct covahip_h264_info {
     int32_t width_mbs, height_mbs, n_samples;
@@ -290,6 +292,7 @@ typedef struct covahip_h264_slice {
     int32_t nal_type;          /* 1 non-IDR, 5 IDR */
     int32_t slice_type;        /* 0 P, 1 B, 2 I (slice_type % 5) */
     int32_t first_mb, frame_num, idr, poc_lsb, qp, cabac_init_idc /* -1: none */, num_ref_l0, num_ref_l1, direct_spatial;
+    int32_t nal_ref_idc, has_mmco5;  /* reference picture?  memory_management_control_operation 5 present (resets the POC)? */
 } covahip_h264_slice;
 int covahip_h264_open_mp4(const uint8_t *file, size_t len, covahip_h264 **out);
 void covahip_h264_close(covahip_h264 *h);
@@ -298,7 +301,16 @@ int covahip_h264_get_info(const covahip_h264 *h, covahip_h264_info *info);
 int covahip_h264_sample(const covahip_h264 *h, int sample, uint64_t *offset, uint32_t *size, int *is_sync);
 /* Slice headers of the access unit (up to cap; *n = number of slice NAL units). */
 int covahip_h264_sample_slices(const covahip_h264 *h, int sample, covahip_h264_slice *out, int cap, int *n);
-/* Would fill records u8 [height_mbs][width_mbs][4]; returns COVAHIP_ERR_UNSUPPORTED (macroblock layer not built). */
+/* Access units in OUTPUT order (ascending picture order count inside every IDR period, 8.2.1): the order in which a decoder
+ * hands frames downstream, i.e. the order metapreprocess stacks them in.  samples: sample indices (decode order). */
+int covahip_h264_display_order(const covahip_h264 *h, int32_t *samples, int cap, int *n);
+/* Entropy-decodes access unit `sample` (decode order) into records u8 [height_mbs][width_mbs][4] (may be NULL: parse only) --
+ * the first width_mbs * height_mbs * 4 bytes of the carrier frame.  Byte 0: macroblock class (0 P_Skip / B_Skip, 1 inter 16x16,
+ * 2 inter 16x8 / 8x16, 3 inter 8x8, 4 B_Direct_16x16, 5 intra NxN, 6 intra 16x16, 7 I_PCM); bytes 1 / 2: the largest |mvd_x| /
+ * |mvd_y| of the macroblock's partitions in full pixels -- the motion vector DIFFERENCES as coded, motion vector prediction is
+ * not performed; byte 3: 0.  What the reference's patched decoder puts into these bytes is not known here (SURVEY.md row A0:
+ * unpinned); a BlobNet has to be trained on the front end it runs behind.  COVAHIP_OK only if the slice decoded exactly
+ * width_mbs * height_mbs macroblocks, ended there with end_of_slice_flag and left only trailing bits. */
 int covahip_h264_decode_records(const covahip_h264 *h, int sample, uint8_t *records, size_t cap);
 /* The carrier layout: interleaves per-macroblock mb_type / mv_x / mv_y into the first width_mbs * height_mbs * 4 bytes of
  * `frame` (metapreprocess/imp.rs:233,311-312; tfrecordsink/imp.rs:105-112). */

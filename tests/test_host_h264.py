@@ -1,7 +1,9 @@
-"""Entropy-decode front end, container + header layer on the reference's own demo video.
-No reference output exists for this stage (the patched FFmpeg is an un-vendored submodule), so the checks are
-structural: what the container and the H.264 headers of demo/1m.mp4 must say (README.md:94-114: 1280x720, 1,802
-frames, GoP 250, High@3.1)."""
+"""Entropy-decode front end on the reference's own demo video: container, headers, picture
+order and the CABAC macroblock layer.  No reference output exists for this stage (the patched FFmpeg is an un-vendored
+submodule), so the checks are structural -- and strong: what the container and the H.264 headers of demo/1m.mp4 must say
+(README.md:94-114: 1280x720, 1,802 frames, GoP 250, High@3.1); every one of its 1,802 slices must entropy-decode to exactly
+3,600 macroblocks with end_of_slice_flag at the last one (a wrong CABAC table value or context rule cannot survive that);
+the output order computed from picture order counts must be the order of the container's composition times."""
 import ctypes as C
 import os
 
@@ -66,11 +68,130 @@ def test_every_access_unit_has_one_slice_and_key_frames_every_250(demo):
     assert types.count(2) == 8 and types.count(0) + types.count(1) == 1794 and types.count(1) > types.count(0)
 
 
-def test_macroblock_layer_is_refused_not_faked(demo):
+def _decode_all(demo):
     lib, h, _ = demo
-    rec = np.zeros(80 * 45 * 4, np.uint8)
-    assert lib.covahip_h264_decode_records(h, 0, rec.ctypes.data, rec.size) == 5    # COVAHIP_ERR_UNSUPPORTED
-    assert not rec.any()
+    sl = np.zeros(4, dtype=L.H264_SLICE_DTYPE)
+    n = C.c_int()
+    recs = np.zeros((1802, 45, 80, 4), np.uint8)
+    types = np.zeros(1802, np.int32)
+    for s in range(1802):
+        assert lib.covahip_h264_sample_slices(h, s, sl.ctypes.data, 4, C.byref(n)) == 0
+        types[s] = sl[0]["slice_type"]
+        assert lib.covahip_h264_decode_records(h, s, recs[s].ctypes.data, recs[s].nbytes) == 0, f"access unit {s} (slice type {types[s]})"
+    return recs, types
+
+
+@pytest.fixture(scope="module")
+def decoded(demo):
+    return _decode_all(demo)
+
+
+def test_every_slice_entropy_decodes_to_its_last_macroblock(decoded):
+    """covahip_h264_decode_records returns OK only when the slice decoded exactly 3,600 macroblocks, end_of_slice_flag came with
+    the last one and only trailing bits followed: 8 I + 564 P + 1,230 B slices, 6.49 M macroblocks, 4 MB of CABAC data."""
+    recs, types = decoded
+    assert (np.bincount(types, minlength=3) == [564, 1230, 8]).all()
+    cls = recs[..., 0]
+    assert cls.max() <= 7 and not recs[..., 3].any()
+    # I pictures: intra classes only, and both kinds occur
+    icls = cls[types == 2]
+    assert set(np.unique(icls)) <= {5, 6, 7} and (icls == 5).any() and (icls == 6).any()
+    # P pictures: mostly skipped or predicted, some intra; B pictures: overwhelmingly skipped / direct (307 bytes per picture on average)
+    pcls, bcls = cls[types == 0], cls[types == 1]
+    assert (pcls == 0).mean() > 0.5 and 0.01 < np.isin(pcls, (1, 2, 3)).mean() < 0.5 and np.isin(pcls, (5, 6)).mean() < 0.1
+    assert not (pcls == 4).any()                                    # B_Direct_16x16 cannot occur in a P slice
+    assert np.isin(bcls, (0, 4)).mean() > 0.9 and np.isin(bcls, (1, 2, 3)).any()
+    # skipped, direct and intra macroblocks carry no motion vector difference; predicted ones mostly small ones
+    mv = recs[..., 1:3]
+    assert not mv[np.isin(cls, (0, 4, 5, 6, 7))].any()
+    inter = np.isin(cls, (1, 2, 3))
+    assert mv[inter].any() and np.median(mv[inter].max(axis=-1)) <= 2 and mv[inter].max() < 160
+
+
+def test_output_order_from_picture_order_counts_is_the_containers_composition_order(demo):
+    """covahip_h264_display_order (POC type 0, 8.2.1.1, from the slice headers) against an independent source in the same
+    file: decode time (stts) + composition offset (ctts) of every sample."""
+    import struct
+    lib, h, data = demo
+    order = np.zeros(1802, np.int32)
+    n = C.c_int()
+    assert lib.covahip_h264_display_order(h, order.ctypes.data, 1802, C.byref(n)) == 0 and n.value == 1802
+    assert sorted(order.tolist()) == list(range(1802))
+    raw = data.tobytes()
+
+    def table(tag, entry):
+        at = raw.rfind(tag)
+        cnt = struct.unpack(">I", raw[at + 8:at + 12])[0]
+        return [struct.unpack(entry, raw[at + 12 + struct.calcsize(entry) * i:at + 12 + struct.calcsize(entry) * (i + 1)]) for i in range(cnt)]
+    dts, t = [], 0
+    for cnt, delta in table(b"stts", ">II"):
+        for _ in range(cnt):
+            dts.append(t)
+            t += delta
+    off = [o for cnt, o in table(b"ctts", ">Ii") for _ in range(cnt)]
+    assert len(dts) == len(off) == 1802
+    cts = np.array(dts) + np.array(off)
+    assert len(set(cts.tolist())) == 1802
+    np.testing.assert_array_equal(order, np.argsort(cts, kind="stable"))
+    assert (order[:1] == [0]).all() and (np.abs(order - np.arange(1802)) <= 8).all()      # reordering stays within a few frames
+    assert not (order == np.arange(1802)).all()                                          # and there is some (B pictures)
+
+
+def test_config_1_demo_video_through_metapreprocess_into_tfrecords(demo, decoded):
+    """BASELINE config 1: demo/1m.mp4 -> entropy decode -> metapreprocess -> tfrecordsink, here through the C-ABI objects behind
+    those elements (cova_amd.elements): carrier frames in OUTPUT order, timestep 4, one tf.train.Example per emitted frame whose
+    three features are bytes 0 / 1 / 2 of the CURRENT frame's records (tfrecordsink/imp.rs:105-112 splits the first w*h pixels)."""
+    from cova_amd import elements as E
+    from tests.test_host_formats import _parse_example
+    lib, h, _ = demo
+    recs, _ = decoded
+    order = np.zeros(1802, np.int32)
+    n = C.c_int()
+    assert lib.covahip_h264_display_order(h, order.ctypes.data, 1802, C.byref(n)) == 0
+    w_mb, h_mb, t = 80, 45, 4
+    mp = E.MetaPreprocess(timestep=t, gamma=1)
+    assert mp.set_caps(1280, 720) == (w_mb, h_mb * t)
+    frame = np.zeros(1280 * 720 * 3 // 2, np.uint8)             # the I420 buffer avdec_h264 would push: records in its first bytes
+    emitted = 0
+    for k in range(40):
+        frame[:w_mb * h_mb * 4] = recs[order[k]].reshape(-1)
+        flow, out = mp.transform(frame)
+        if k < t - 1:
+            assert flow != E.FLOW_OK
+            continue
+        assert flow == E.FLOW_OK
+        stack = out.reshape(t * h_mb, w_mb, 4)
+        for j in range(t):                                     # row block j = the frame j steps back in OUTPUT order
+            np.testing.assert_array_equal(stack[j * h_mb:(j + 1) * h_mb], recs[order[k - j]])
+        ex = _parse_example(E.tfrecord_example(stack[:h_mb].reshape(1, h_mb, w_mb, 4))[12:-4])
+        for ch, name in enumerate(("mb_type", "mv_x", "mv_y")):
+            assert ex[name] == [recs[order[k]][..., ch].tobytes()]
+        emitted += 1
+    assert emitted == 40 - (t - 1)
+
+
+def test_corrupted_slice_data_never_crashes(demo):
+    """The macroblock layer reads untrusted bytes: flipping bytes inside an access unit must end in an error status (or in
+    records, when the damage happens to decode), never in a fault or a hang."""
+    lib, _, data = demo
+    rng = np.random.default_rng(7)
+    rec = np.zeros(45 * 80 * 4, np.uint8)
+    off, size, sync = C.c_uint64(), C.c_uint32(), C.c_int()
+    outcomes = {0: 0, "err": 0}
+    for trial in range(120):
+        d = data.copy()
+        hh = C.c_void_p()
+        assert lib.covahip_h264_open_mp4(d.ctypes.data, d.size, C.byref(hh)) == 0
+        s = int(rng.choice([0, 1, 2, 3, 5, 250, 251, 260, 1801]))
+        lib.covahip_h264_sample(hh, s, C.byref(off), C.byref(size), C.byref(sync))
+        for _ in range(int(rng.integers(1, 6))):
+            d[off.value + 8 + int(rng.integers(0, max(1, size.value - 8)))] = rng.integers(0, 256)
+        rc = lib.covahip_h264_decode_records(hh, s, rec.ctypes.data, rec.size)
+        outcomes[0 if rc == 0 else "err"] += 1
+        # a buffer that is too small is refused before anything is written
+        assert lib.covahip_h264_decode_records(hh, s, rec.ctypes.data, 100) == 7
+        lib.covahip_h264_close(hh)
+    assert outcomes["err"] > 60      # almost every hit desynchronises the arithmetic decoder, and that is noticed
 
 
 def test_truncated_and_foreign_files_are_rejected(demo):
