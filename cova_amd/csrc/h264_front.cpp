@@ -160,6 +160,7 @@ struct covahip_h264 {
     std::vector<Sample> samples;
     std::vector<int64_t> order_key;     // per sample: (IDR period << 32) + picture order count + 2^31; empty when not computable
     std::vector<int32_t> display;       // sample indices in output order
+    struct PocState { int64_t prev_msb = 0, prev_lsb = 0, period = -1, fn_off = 0, prev_fn = 0; } poc;   // stream form (covahip_h264_decode_au)
 };
 
 namespace {
@@ -274,45 +275,130 @@ int parse_slice_header(const covahip_h264 *h, const uint8_t *nal, size_t n, cova
     return COVAHIP_OK;
 }
 
-// Picture order count of every access unit (8.2.1.1 type 0, 8.2.1.3 type 2; frames only) and the output order: within an IDR
-// period pictures leave the decoder by ascending POC.  Leaves `display` empty when a header does not parse or for type 1.
+// Picture order count of the next access unit in decode order (8.2.1.1 type 0, 8.2.1.3 type 2; frames only) as a key whose
+// ascending order is the output order: (IDR period << 32) + POC + 2^31.  false for POC type 1.
+bool poc_step(const Sps &sp, covahip_h264::PocState &st, const covahip_h264_slice &sl, int64_t &key) {
+    if (sp.poc_type == 1) return false;
+    const int64_t max_lsb = 1ll << sp.log2_max_poc_lsb, max_fn = 1ll << sp.log2_max_frame_num;
+    const bool idr = sl.idr != 0, ref = sl.nal_ref_idc != 0;
+    int64_t poc;
+    if (idr) { st.period++; st.prev_msb = st.prev_lsb = 0; st.fn_off = 0; }
+    if (st.period < 0) st.period = 0;
+    if (sp.poc_type == 0) {
+        const int64_t lsb = sl.poc_lsb;
+        int64_t msb = st.prev_msb;
+        if (lsb < st.prev_lsb && st.prev_lsb - lsb >= max_lsb / 2) msb = st.prev_msb + max_lsb;
+        else if (lsb > st.prev_lsb && lsb - st.prev_lsb > max_lsb / 2) msb = st.prev_msb - max_lsb;
+        poc = msb + lsb;
+        if (ref) {
+            if (sl.has_mmco5) { st.prev_msb = 0; st.prev_lsb = poc; }   // after memory_management_control_operation 5 (frames: tempPicOrderCnt)
+            else { st.prev_msb = msb; st.prev_lsb = lsb; }
+        }
+    } else {
+        if (!idr && sl.frame_num < st.prev_fn) st.fn_off += max_fn;
+        poc = idr ? 0 : 2 * (st.fn_off + sl.frame_num) - (ref ? 0 : 1);
+    }
+    st.prev_fn = sl.frame_num;
+    key = (st.period << 32) + poc + (1ll << 31);
+    return true;
+}
+
+// Output order of a file's access units: within an IDR period pictures leave the decoder by ascending POC.  Leaves `display`
+// empty when a header does not parse or for POC type 1.
 void compute_display_order(covahip_h264 *h) {
     const size_t n = h->samples.size();
     h->order_key.assign(n, 0);
-    const Sps &sp = h->sps;
-    if (sp.poc_type == 1) { h->order_key.clear(); return; }
-    const int64_t max_lsb = 1ll << sp.log2_max_poc_lsb, max_fn = 1ll << sp.log2_max_frame_num;
-    int64_t prev_msb = 0, prev_lsb = 0, period = -1, fn_off = 0, prev_fn = 0;
+    covahip_h264::PocState st;
     for (size_t i = 0; i < n; i++) {
         covahip_h264_slice sl[1];
         int cnt = 0;
         const int rc = covahip_h264_sample_slices(h, (int)i, sl, 1, &cnt);
-        if ((rc != COVAHIP_OK && rc != COVAHIP_ERR_OVERFLOW) || cnt < 1) { h->order_key.clear(); return; }
-        const bool idr = sl[0].idr != 0, ref = sl[0].nal_ref_idc != 0;
-        int64_t poc;
-        if (idr) { period++; prev_msb = prev_lsb = 0; fn_off = 0; }
-        if (period < 0) period = 0;
-        if (sp.poc_type == 0) {
-            const int64_t lsb = sl[0].poc_lsb;
-            int64_t msb = prev_msb;
-            if (lsb < prev_lsb && prev_lsb - lsb >= max_lsb / 2) msb = prev_msb + max_lsb;
-            else if (lsb > prev_lsb && lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
-            poc = msb + lsb;
-            if (ref) {
-                if (sl[0].has_mmco5) { prev_msb = 0; prev_lsb = poc; }   // after memory_management_control_operation 5 (frames: tempPicOrderCnt)
-                else { prev_msb = msb; prev_lsb = lsb; }
-            }
-        } else {
-            if (!idr && sl[0].frame_num < prev_fn) fn_off += max_fn;
-            poc = 2 * (fn_off + sl[0].frame_num) - (ref ? 0 : 1);
-            if (idr) poc = 0;
+        if ((rc != COVAHIP_OK && rc != COVAHIP_ERR_OVERFLOW) || cnt < 1 || !poc_step(h->sps, st, sl[0], h->order_key[i])) {
+            h->order_key.clear();
+            return;
         }
-        prev_fn = sl[0].frame_num;
-        h->order_key[i] = (period << 32) + poc + (1ll << 31);
     }
     h->display.resize(n);
     for (size_t i = 0; i < n; i++) h->display[i] = (int32_t)i;
     std::stable_sort(h->display.begin(), h->display.end(), [&](int32_t a, int32_t b) { return h->order_key[a] < h->order_key[b]; });
+}
+
+// Slice NAL units of one access unit (length-prefixed NAL units at au[0, len)); nal_offset = base + offset inside au.
+int au_slices(const covahip_h264 *h, const uint8_t *au, size_t len, uint64_t base, covahip_h264_slice *out, int cap, int *n) {
+    size_t p = 0;
+    int cnt = 0;
+    while (p + h->nal_len_size <= len) {
+        size_t l = 0;
+        for (int k = 0; k < h->nal_len_size; k++) l = (l << 8) | au[p + k];
+        p += h->nal_len_size;
+        if (l == 0 || l > len - p) return COVAHIP_ERR_BAD_DATA;
+        const int t = au[p] & 31;
+        if (t == 1 || t == 5) {
+            if (cnt < cap) {
+                covahip_h264_slice sl;
+                std::memset(&sl, 0, sizeof sl);
+                int rc = parse_slice_header(h, au + p, l, &sl);
+                if (rc) return rc;
+                sl.nal_offset = base + (uint64_t)p;
+                out[cnt] = sl;
+            }
+            cnt++;
+        }
+        p += l;
+    }
+    if (p != len) return COVAHIP_ERR_BAD_DATA;
+    *n = cnt;
+    return cnt > cap ? COVAHIP_ERR_OVERFLOW : COVAHIP_OK;
+}
+
+// SPS / PPS of an AVCDecoderConfigurationRecord (the avcC box payload = the codec_data of video/x-h264,stream-format=avc caps)
+int parse_avcc(covahip_h264 *h, const uint8_t *a, size_t n) {
+    if (n < 7 || a[0] != 1) return COVAHIP_ERR_BAD_DATA;
+    h->nal_len_size = (a[4] & 3) + 1;
+    size_t p = 5;
+    const int nsps = a[p++] & 31;
+    for (int k = 0; k < nsps && p + 2 <= n; k++) {
+        const size_t l = ((size_t)a[p] << 8) | a[p + 1];
+        if (p + 2 + l > n) break;
+        if (k == 0 && !parse_sps(unescape(a + p + 2, l), h->sps)) return COVAHIP_ERR_UNSUPPORTED;
+        p += 2 + l;
+    }
+    const int npps = p < n ? a[p++] : 0;
+    for (int k = 0; k < npps && p + 2 <= n; k++) {
+        const size_t l = ((size_t)a[p] << 8) | a[p + 1];
+        if (p + 2 + l > n) break;
+        if (k == 0 && !parse_pps(unescape(a + p + 2, l), h->pps)) return COVAHIP_ERR_UNSUPPORTED;
+        p += 2 + l;
+    }
+    if (!h->sps.ok || !h->pps.ok) return COVAHIP_ERR_BAD_DATA;
+    if (h->pps.sps_id != h->sps.id) return COVAHIP_ERR_UNSUPPORTED;   // only the first SPS / PPS are kept
+    return COVAHIP_OK;
+}
+
+// Entropy-decodes the single whole-picture slice `sl` whose NAL unit starts at nal.
+int decode_slice_records(const covahip_h264 *h, const uint8_t *nal, const covahip_h264_slice &sl, uint8_t *records, size_t cap) {
+    const int wmb = h->sps.width_mbs, hmb = h->sps.height_map_units;
+    if (records && cap < (size_t)wmb * hmb * 4) return COVAHIP_ERR_OVERFLOW;
+    // CAVLC streams, field / MBAFF coding: not built -- refused, never faked
+    if (!h->pps.entropy_cabac || !h->sps.frame_mbs_only) return COVAHIP_ERR_UNSUPPORTED;
+    if (sl.slice_type != 2 && sl.cabac_init_idc != 0) return COVAHIP_ERR_UNSUPPORTED;
+    const std::vector<uint8_t> rbsp = unescape(nal + 1, sl.nal_bytes - 1);
+    h264::SliceParams sp;
+    sp.slice_type = sl.slice_type;
+    sp.first_mb = sl.first_mb;
+    sp.qp = sl.qp;
+    sp.cabac_init_idc = sl.cabac_init_idc < 0 ? 0 : sl.cabac_init_idc;
+    sp.num_ref_l0 = sl.num_ref_l0;
+    sp.num_ref_l1 = sl.num_ref_l1;
+    sp.width_mbs = wmb;
+    sp.height_mbs = hmb;
+    sp.transform_8x8 = h->pps.transform_8x8;
+    sp.direct_8x8_inference = h->sps.direct_8x8;
+    sp.chroma_format = h->sps.chroma_format;
+    std::string why;
+    const int rc = h264::parse_slice_cabac(rbsp.data(), rbsp.size(), sl.data_bit_offset, sp, records, &why);
+    if (rc && getenv("COVAHIP_H264_DEBUG")) fprintf(stderr, "covahip h264: %s\n", why.c_str());
+    return rc;
 }
 
 }  // namespace
@@ -350,24 +436,10 @@ int covahip_h264_open_mp4(const uint8_t *file, size_t len, covahip_h264 **out) {
         for (size_t i = db; i + 8 < de; i++)
             if (std::memcmp(file + i, "avcC", 4) == 0) { a = i + 4; break; }
         if (!a || a + 8 > de) continue;
-        h->nal_len_size = (file[a + 4] & 3) + 1;
-        size_t p = a + 5;
-        const int nsps = file[p++] & 31;
-        for (int k = 0; k < nsps && p + 2 <= de; k++) {
-            const size_t l = ((size_t)file[p] << 8) | file[p + 1];
-            if (p + 2 + l > de) break;
-            if (k == 0 && !parse_sps(unescape(file + p + 2, l), h->sps)) { delete h; return COVAHIP_ERR_UNSUPPORTED; }
-            p += 2 + l;
+        {
+            const int rc = parse_avcc(h, file + a, de - a);
+            if (rc) { delete h; return rc; }
         }
-        const int npps = p < de ? file[p++] : 0;
-        for (int k = 0; k < npps && p + 2 <= de; k++) {
-            const size_t l = ((size_t)file[p] << 8) | file[p + 1];
-            if (p + 2 + l > de) break;
-            if (k == 0 && !parse_pps(unescape(file + p + 2, l), h->pps)) { delete h; return COVAHIP_ERR_UNSUPPORTED; }
-            p += 2 + l;
-        }
-        if (!h->sps.ok || !h->pps.ok) { delete h; return COVAHIP_ERR_BAD_DATA; }
-        if (h->pps.sps_id != h->sps.id) { delete h; return COVAHIP_ERR_UNSUPPORTED; }   // only the first SPS / PPS of avcC are kept
         // sample sizes, chunk offsets, samples per chunk, sync samples
         size_t zb, ze, cb, ce, scb, sce;
         if (!find_box(file, sb, se, "stsz", zb, ze) || !find_box(file, sb, se, "stsc", scb, sce)) { delete h; return COVAHIP_ERR_BAD_DATA; }
@@ -440,62 +512,48 @@ int covahip_h264_sample(const covahip_h264 *h, int sample, uint64_t *offset, uin
 int covahip_h264_sample_slices(const covahip_h264 *h, int sample, covahip_h264_slice *out, int cap, int *n) {
     if (!h || !n || sample < 0 || sample >= (int)h->samples.size() || (!out && cap)) return COVAHIP_ERR_INVALID_ARG;
     const Sample &s = h->samples[sample];
-    size_t p = s.off;
-    const size_t end = s.off + s.size;
-    int cnt = 0;
-    while (p + h->nal_len_size <= end) {
-        size_t l = 0;
-        for (int k = 0; k < h->nal_len_size; k++) l = (l << 8) | h->data[p + k];
-        p += h->nal_len_size;
-        if (l == 0 || p + l > end) return COVAHIP_ERR_BAD_DATA;
-        const int t = h->data[p] & 31;
-        if (t == 1 || t == 5) {
-            if (cnt < cap) {
-                covahip_h264_slice sl;
-                std::memset(&sl, 0, sizeof sl);
-                int rc = parse_slice_header(h, h->data + p, l, &sl);
-                if (rc) return rc;
-                sl.nal_offset = (uint64_t)p;
-                out[cnt] = sl;
-            }
-            cnt++;
-        }
-        p += l;
-    }
-    if (p != end) return COVAHIP_ERR_BAD_DATA;
-    *n = cnt;
-    return cnt > cap ? COVAHIP_ERR_OVERFLOW : COVAHIP_OK;
+    return au_slices(h, h->data + s.off, s.size, s.off, out, cap, n);
 }
 
 int covahip_h264_decode_records(const covahip_h264 *h, int sample, uint8_t *records, size_t cap) {
     if (!h || sample < 0 || sample >= (int)h->samples.size()) return COVAHIP_ERR_INVALID_ARG;
-    const int wmb = h->sps.width_mbs, hmb = h->sps.height_map_units;
-    if (records && cap < (size_t)wmb * hmb * 4) return COVAHIP_ERR_OVERFLOW;
-    // CAVLC streams, field / MBAFF coding, several slices per picture: not built -- refused, never faked
-    if (!h->pps.entropy_cabac || !h->sps.frame_mbs_only) return COVAHIP_ERR_UNSUPPORTED;
+    if (records && cap < (size_t)h->sps.width_mbs * h->sps.height_map_units * 4) return COVAHIP_ERR_OVERFLOW;
     covahip_h264_slice sl[2];
     int n = 0;
-    int rc = covahip_h264_sample_slices(h, sample, sl, 2, &n);
-    if (rc == COVAHIP_ERR_OVERFLOW || n != 1) return COVAHIP_ERR_UNSUPPORTED;
+    const int rc = covahip_h264_sample_slices(h, sample, sl, 2, &n);
+    if (rc == COVAHIP_ERR_OVERFLOW || (rc == COVAHIP_OK && n != 1)) return COVAHIP_ERR_UNSUPPORTED;   // several slices per picture
     if (rc) return rc;
-    const std::vector<uint8_t> rbsp = unescape(h->data + sl[0].nal_offset + 1, sl[0].nal_bytes - 1);
-    h264::SliceParams sp;
-    sp.slice_type = sl[0].slice_type;
-    sp.first_mb = sl[0].first_mb;
-    sp.qp = sl[0].qp;
-    sp.cabac_init_idc = sl[0].cabac_init_idc < 0 ? 0 : sl[0].cabac_init_idc;
-    sp.num_ref_l0 = sl[0].num_ref_l0;
-    sp.num_ref_l1 = sl[0].num_ref_l1;
-    sp.width_mbs = wmb;
-    sp.height_mbs = hmb;
-    sp.transform_8x8 = h->pps.transform_8x8;
-    sp.direct_8x8_inference = h->sps.direct_8x8;
-    sp.chroma_format = h->sps.chroma_format;
-    if (sl[0].slice_type != 2 && sl[0].cabac_init_idc != 0) return COVAHIP_ERR_UNSUPPORTED;
-    std::string why;
-    rc = h264::parse_slice_cabac(rbsp.data(), rbsp.size(), sl[0].data_bit_offset, sp, records, &why);
-    if (rc && getenv("COVAHIP_H264_DEBUG")) fprintf(stderr, "covahip_h264_decode_records: sample %d: %s\n", sample, why.c_str());
-    return rc;
+    return decode_slice_records(h, h->data + sl[0].nal_offset, sl[0], records, cap);
+}
+
+int covahip_h264_open_avcc(const uint8_t *avcc, size_t len, covahip_h264 **out) {
+    if (!avcc || !out) return COVAHIP_ERR_INVALID_ARG;
+    *out = nullptr;
+    covahip_h264 *h = new (std::nothrow) covahip_h264();
+    if (!h) return COVAHIP_ERR_INVALID_ARG;
+    const int rc = parse_avcc(h, avcc, len);
+    if (rc) { delete h; return rc; }
+    *out = h;
+    return COVAHIP_OK;
+}
+
+int covahip_h264_decode_au(covahip_h264 *h, const uint8_t *au, size_t len, uint8_t *records, size_t cap, covahip_h264_slice *hdr,
+                           int64_t *order_key) {
+    if (!h || !au) return COVAHIP_ERR_INVALID_ARG;
+    if (records && cap < (size_t)h->sps.width_mbs * h->sps.height_map_units * 4) return COVAHIP_ERR_OVERFLOW;
+    covahip_h264_slice sl[2];
+    int n = 0;
+    const int rc = au_slices(h, au, len, 0, sl, 2, &n);
+    if (rc == COVAHIP_ERR_OVERFLOW || (rc == COVAHIP_OK && n != 1)) return COVAHIP_ERR_UNSUPPORTED;
+    if (rc) return rc;
+    int64_t key = 0;
+    const bool have_key = poc_step(h->sps, h->poc, sl[0], key);
+    if (order_key) {
+        if (!have_key) return COVAHIP_ERR_UNSUPPORTED;
+        *order_key = key;
+    }
+    if (hdr) *hdr = sl[0];
+    return decode_slice_records(h, au + sl[0].nal_offset, sl[0], records, cap);
 }
 
 int covahip_carrier_write_records(const uint8_t *mb_type, const uint8_t *mv_x, const uint8_t *mv_y, int width_mbs, int height_mbs,

@@ -77,7 +77,8 @@ static int run_harness(const char *launch, const char *srccaps, const char *in_p
 
 /* ---- sink elements (bboxsink, tfrecordsink): push 'B' records (flags bit 0 = DELTA_UNIT), EOS, tear down ---- */
 static int run_sink(const char *launch, const char *srccaps, const char *in_path) {
-    GstElement *e = gst_parse_launch(launch, NULL);
+    /* a chain "a ! b ! sink" becomes a bin whose unlinked sink pad is ghosted */
+    GstElement *e = strchr(launch, '!') ? gst_parse_bin_from_description(launch, TRUE, NULL) : gst_parse_launch(launch, NULL);
     GstHarness *h = e ? gst_harness_new_with_element(e, "sink", NULL) : NULL;
     FILE *fi = fopen(in_path, "rb");
     rec_t r;

@@ -13,6 +13,7 @@
  *   bboxsink        <- cova-rs/gst-plugins/src/bboxsink/imp.rs         (BaseSink: bincode boxes -> CSV file)
  *   tfrecordsink    <- cova-rs/gst-plugins/src/tfrecordsink/imp.rs     (BaseSink: RGBA metadata frames + ground
  *                      truth file -> TFRecord file of tf.train.Example, one per frame or per GoP)
+ *   h264entropydec  <- the patched avdec_h264 of README.md:94-114 (gstentropydec.c): access units -> record frames
  *
  * The reference elements are Rust (gstreamer-rs); Rust is not available in this build image, so
  * the elements are written in C against the same GStreamer base classes.  All arithmetic and all
@@ -35,6 +36,7 @@
 GST_DEBUG_CATEGORY(cova_debug);
 GType gst_blobnetfilter_get_type_public(void);   /* gstblobnetfilter.c */
 GType gst_maskcopy_get_type_public(void);
+GType gst_entropydec_get_type_public(void);      /* gstentropydec.c */
 #define GST_CAT_DEFAULT cova_debug
 
 #define BBOX_CAPS "bbox, width=(int)[0,2147483647], height=(int)[0,2147483647]"
@@ -1027,7 +1029,8 @@ static gboolean plugin_init(GstPlugin *plugin) {
            gst_element_register(plugin, "sorttracker", GST_RANK_NONE, gst_sorttracker_get_type()) &&
            gst_element_register(plugin, "cova", GST_RANK_NONE, gst_cova_get_type()) &&
            gst_element_register(plugin, "bboxsink", GST_RANK_NONE, gst_bboxsink_get_type()) &&
-           gst_element_register(plugin, "tfrecordsink", GST_RANK_NONE, gst_tfrecordsink_get_type());
+           gst_element_register(plugin, "tfrecordsink", GST_RANK_NONE, gst_tfrecordsink_get_type()) &&
+           gst_element_register(plugin, "h264entropydec", GST_RANK_NONE, gst_entropydec_get_type_public());
 }
 #define PACKAGE "covahip"
 GST_PLUGIN_DEFINE(GST_VERSION_MAJOR, GST_VERSION_MINOR, cova, "CoVA compressed-domain filter elements (MI355X / covahip)",

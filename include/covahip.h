@@ -312,6 +312,13 @@ int covahip_h264_display_order(const covahip_h264 *h, int32_t *samples, int cap,
  * unpinned); a BlobNet has to be trained on the front end it runs behind.  COVAHIP_OK only if the slice decoded exactly
  * width_mbs * height_mbs macroblocks, ended there with end_of_slice_flag and left only trailing bits. */
 int covahip_h264_decode_records(const covahip_h264 *h, int sample, uint8_t *records, size_t cap);
+/* Stream form (what an element in the place of avdec_h264 uses): parameter sets from the AVCDecoderConfigurationRecord (avcC box
+ * payload = codec_data of video/x-h264,stream-format=avc caps), then access units IN DECODE ORDER (length-prefixed NAL units).
+ * records / cap as covahip_h264_decode_records; hdr (may be NULL) gets the slice header; *order_key (may be NULL) a key whose
+ * ascending order is the output order of the pictures (IDR period << 32 | picture order count + 2^31). */
+int covahip_h264_open_avcc(const uint8_t *avcc, size_t len, covahip_h264 **out);
+int covahip_h264_decode_au(covahip_h264 *h, const uint8_t *au, size_t len, uint8_t *records, size_t cap, covahip_h264_slice *hdr,
+                           int64_t *order_key);
 /* The carrier layout: interleaves per-macroblock mb_type / mv_x / mv_y into the first width_mbs * height_mbs * 4 bytes of
  * `frame` (metapreprocess/imp.rs:233,311-312; tfrecordsink/imp.rs:105-112). */
 int covahip_carrier_write_records(const uint8_t *mb_type, const uint8_t *mv_x, const uint8_t *mv_y, int width_mbs, int height_mbs,

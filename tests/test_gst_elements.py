@@ -69,7 +69,7 @@ def test_inspect_lists_reference_elements_and_properties(tmp_path):
             "blobnetinfer": ["model-weights-file", "gpu-id"], "bboxsink": ["location"],
             "blobnetfilter": ["model-weights-file", "gpu-id", "batch-size", "batched-push-timeout", "cc-threshold"],
             "maskcopy": ["unique-id", "gpu-id", "timestep"],
-            "tfrecordsink": ["location", "gt", "gop"]}
+            "tfrecordsink": ["location", "gt", "gop"], "h264entropydec": ["max-threads"]}
     for el, props in want.items():
         r = subprocess.run([insp, el], env=_env(tmp_path), capture_output=True, text=True, timeout=60)
         assert r.returncode == 0, r.stdout + r.stderr
@@ -344,3 +344,68 @@ def test_blobnetfilter_concurrent_streams(tmp_path, weights_flat, n_streams, bat
     assert many["buffers_out"] == n_streams * (n + warm - 3) and many["eos"] == n_streams
     assert many["in_order"] and many["pads_agree"]
     assert many["pad0_sum"] == alone["pad0_sum"]
+
+
+DEMO = "/root/reference/demo/1m.mp4"
+
+
+@pytest.mark.skipif(not os.path.exists(DEMO), reason="reference demo video not present (GPU box)")
+def test_config_1_through_the_elements_entropy_decoder_metapreprocess_tfrecordsink(tmp_path):
+    """BASELINE config 1 through the plugin: the access units of demo/1m.mp4 (decode order, as qtdemux ! h264parse would hand them
+    over) -> h264entropydec -> metapreprocess timestep=4 -> tfrecordsink.  The decoder element reorders into output order; every
+    Example's features are the record bytes of the current output frame (checked against the C-ABI front end on the file)."""
+    import ctypes as C
+    from tests.test_host_formats import _parse_example, _masked
+    lib = L.lib()
+    data = np.fromfile(DEMO, dtype=np.uint8)
+    h = C.c_void_p()
+    assert lib.covahip_h264_open_mp4(data.ctypes.data, data.size, C.byref(h)) == 0
+    n_au = 300                                   # the first GoP and the start of the second: one IDR in the middle of the run
+    raw = data.tobytes()
+    at = raw.find(b"avcC")
+    avcc = raw[at + 4:at - 4 + struct.unpack(">I", raw[at - 4:at])[0]]
+    recs_in = []
+    off, size, sync = C.c_uint64(), C.c_uint32(), C.c_int()
+    for s in range(n_au):
+        lib.covahip_h264_sample(h, s, C.byref(off), C.byref(size), C.byref(sync))
+        recs_in.append(("B", s * CLK, 0 if sync.value else 1, raw[off.value:off.value + size.value]))
+    _write(tmp_path / "in.rec", recs_in)
+    caps = f"video/x-h264,stream-format=avc,alignment=au,framerate=30/1,codec_data=(buffer){avcc.hex()}"
+    info = _run(["harness", "h264entropydec max-threads=1 ! metapreprocess timestep=4", caps, str(tmp_path / "in.rec"),
+                 str(tmp_path / "out.rec")], tmp_path)
+    assert "width=(int)80" in info["out_caps"] and "height=(int)180" in info["out_caps"] and "RGBA" in info["out_caps"]
+    outs = _read(tmp_path / "out.rec")
+    assert len(outs) == n_au - 3
+    # what the C-ABI front end says: records per access unit and the output order
+    order = np.zeros(1802, np.int32)
+    n = C.c_int()
+    assert lib.covahip_h264_display_order(h, order.ctypes.data, 1802, C.byref(n)) == 0
+    order = [int(s) for s in order if s < n_au]
+    assert sorted(order[:n_au]) == list(range(n_au))       # the first 300 access units are the first 300 output pictures (closed GoPs)
+    rec = np.zeros((n_au, 45, 80, 4), np.uint8)
+    for s in range(n_au):
+        assert lib.covahip_h264_decode_records(h, s, rec[s].ctypes.data, rec[s].nbytes) == 0
+    for k, (kind, pts, flags, payload) in enumerate(outs):
+        cur = k + 3
+        assert pts == order[cur] * CLK                      # the stacked frame carries the timestamp of its current picture
+        stack = np.frombuffer(payload, np.uint8).reshape(4 * 45, 80, 4)
+        for j in range(4):
+            np.testing.assert_array_equal(stack[j * 45:(j + 1) * 45], rec[order[cur - j]])
+    lib.covahip_h264_close(h)
+    # the same chain into the sink: one Example per emitted frame
+    out = tmp_path / "out.tfrecord"
+    gt = np.random.default_rng(0).integers(0, 2, (n_au, 45 * 80), dtype=np.uint8)      # the ground-truth file the sink reads beside the frames
+    (tmp_path / "gt.bin").write_bytes(gt.tobytes())
+    _run(["sink", f"h264entropydec ! metapreprocess timestep=1 ! tfrecordsink location={out} gt={tmp_path / 'gt.bin'} async=false sync=false",
+          caps, str(tmp_path / "in.rec")], tmp_path)
+    raw_out, o, k = out.read_bytes(), 0, 0
+    while o < len(raw_out):
+        (length,) = struct.unpack_from("<Q", raw_out, o)
+        assert struct.unpack_from("<I", raw_out, o + 8)[0] == _masked(raw_out[o:o + 8])
+        ex = _parse_example(raw_out[o + 12:o + 12 + length])
+        for ch, name in enumerate(("mb_type", "mv_x", "mv_y")):
+            assert ex[name] == [rec[order[k]][..., ch].tobytes()]
+        assert ex["gt"] == [gt[k].tobytes()]
+        o += 16 + length
+        k += 1
+    assert k == n_au
