@@ -1,7 +1,7 @@
 // Entropy-decode front end, macroblock layer: CABAC parsing of slice_data() (ITU-T H.264 7.3.4, 7.3.5, 9.3) for
 // frame-coded 4:2:0 streams -- what the reference's patched FFmpeg `avdec_h264` does before it writes its
 // [mb_type, mv_x, mv_y, -] records (README.md:94-114; consumers metapreprocess/imp.rs:233,311-312,
-// tfrecordsink/imp.rs:105-112).  Parsing only: no prediction, no reconstruction.
+// tfrecordsink/imp.rs:105-112).  Parsing and motion vector prediction; no reconstruction.
 //
 // What can be verified in this image, and is (tests/test_host_h264.py): every one of the 1,802 slices of the reference's
 // demo/1m.mp4 (High@3.1, CABAC, 8x8 transform, P and B slices, one slice per picture) must decode exactly
@@ -201,6 +201,10 @@ struct Mb {
     int8_t ref[2][4];           // ref_idx per list and 8x8 block as PARSED (0 for inferred / unused, see direct8)
     uint8_t direct8 = 0;        // bit b8: the 8x8 block is predicted in direct mode (B_Skip, B_Direct_16x16, direct sub-block)
     uint8_t mvd[2][16][2];      // |mvd| per list, 4x4 block, component, clipped to 70
+    // motion as predicted + coded (8.4.1): reference index per list and 8x8 block (-1: list not used / intra) and the motion
+    // vector of every 4x4 block in quarter pixels
+    int8_t aref[2][4];
+    int16_t mv[2][16][2];
 };
 
 struct SliceCtx {
@@ -216,6 +220,75 @@ struct SliceCtx {
 };
 
 bool is_intra(uint8_t k) { return k == K_INXN || k == K_I16 || k == K_PCM; }
+
+// ---- motion vector prediction (8.4.1.3; neighbours 6.4.11.7)
+inline int blk_order(int x, int y) { return ((y >> 1) * 2 + (x >> 1)) * 4 + (y & 1) * 2 + (x & 1); }   // decoding order of the 4x4 blocks
+struct Nb { bool avail; int ref, mx, my; };
+// 4x4 block (bx, by) relative to macroblock (mbx, mby), bx / by in -1 .. 4; blocks of the current macroblock count only when they
+// come before `cur_order` in decoding order
+Nb nb_block(const SliceCtx &s, int list, int mbx, int mby, int bx, int by, int cur_order) {
+    int nx = mbx, ny = mby;
+    if (by < 0) { ny--; by = 3; if (bx < 0) { nx--; bx = 3; } else if (bx > 3) { nx++; bx = 0; } }
+    else if (bx < 0) { nx--; bx = 3; }
+    else if (bx > 3) return Nb{false, -1, 0, 0};   // the macroblock to the right is not decoded yet
+    else if (blk_order(bx, by) >= cur_order) return Nb{false, -1, 0, 0};
+    if (nx < 0 || ny < 0 || nx >= s.W) return Nb{false, -1, 0, 0};
+    const Mb &n = s.mbs[(size_t)ny * s.W + nx];
+    if (n.kind == K_NONE) return Nb{false, -1, 0, 0};
+    const int r = n.aref[list][(by >> 1) * 2 + (bx >> 1)];
+    if (r < 0) return Nb{true, -1, 0, 0};
+    return Nb{true, r, n.mv[list][by * 4 + bx][0], n.mv[list][by * 4 + bx][1]};
+}
+inline int median3(int a, int b, int c) { return std::max(std::min(a, b), std::min(std::max(a, b), c)); }
+// shape: 0 none, 1 / 2 upper / lower 16x8 partition, 3 / 4 left / right 8x16 partition
+void predict_mv(const SliceCtx &s, int list, int mbx, int mby, int x, int y, int w, int ref, int shape, int cur_order, int &px, int &py) {
+    const Nb A = nb_block(s, list, mbx, mby, x - 1, y, cur_order);
+    Nb B = nb_block(s, list, mbx, mby, x, y - 1, cur_order);
+    Nb C = nb_block(s, list, mbx, mby, x + w, y - 1, cur_order);
+    if (!C.avail) C = nb_block(s, list, mbx, mby, x - 1, y - 1, cur_order);
+    if (shape == 1 && B.ref == ref) { px = B.mx; py = B.my; return; }
+    if (shape == 2 && A.ref == ref) { px = A.mx; py = A.my; return; }
+    if (shape == 3 && A.ref == ref) { px = A.mx; py = A.my; return; }
+    if (shape == 4 && C.ref == ref) { px = C.mx; py = C.my; return; }
+    if (!B.avail && !C.avail && A.avail) { px = A.mx; py = A.my; return; }
+    const int n = (A.ref == ref) + (B.ref == ref) + (C.ref == ref);
+    if (n == 1) {
+        const Nb &m = A.ref == ref ? A : (B.ref == ref ? B : C);
+        px = m.mx; py = m.my;
+        return;
+    }
+    px = median3(A.mx, B.mx, C.mx);
+    py = median3(A.my, B.my, C.my);
+}
+inline void fill_mv(Mb &m, int list, int x, int y, int w, int h, int mx, int my) {
+    for (int yy = y; yy < y + h; yy++)
+        for (int xx = x; xx < x + w; xx++) { m.mv[list][yy * 4 + xx][0] = (int16_t)mx; m.mv[list][yy * 4 + xx][1] = (int16_t)my; }
+}
+// P_Skip (8.4.1.1)
+void p_skip_motion(const SliceCtx &s, int mbx, int mby, Mb &m) {
+    const Nb A = nb_block(s, 0, mbx, mby, -1, 0, 0), B = nb_block(s, 0, mbx, mby, 0, -1, 0);
+    int mx = 0, my = 0;
+    if (A.avail && B.avail && !(A.ref == 0 && A.mx == 0 && A.my == 0) && !(B.ref == 0 && B.mx == 0 && B.my == 0))
+        predict_mv(s, 0, mbx, mby, 0, 0, 4, 0, 0, 0, mx, my);
+    for (int b8 = 0; b8 < 4; b8++) { m.aref[0][b8] = 0; m.aref[1][b8] = -1; }
+    fill_mv(m, 0, 0, 0, 4, 4, mx, my);
+}
+// B_Skip / B_Direct_16x16 / direct sub-blocks, spatial direct mode (8.4.1.2.2) on the macroblock's own neighbours.  NOT done: the
+// colZeroFlag test against the co-located picture (a direct block over static background keeps the predicted vector instead of
+// zero); temporal direct slices take this path too.
+void b_direct_motion(const SliceCtx &s, int mbx, int mby, int ref_out[2], int mv_out[2][2]) {
+    for (int list = 0; list < 2; list++) {
+        const Nb A = nb_block(s, list, mbx, mby, -1, 0, 0), B = nb_block(s, list, mbx, mby, 0, -1, 0);
+        Nb C = nb_block(s, list, mbx, mby, 4, -1, 0);
+        if (!C.avail) C = nb_block(s, list, mbx, mby, -1, -1, 0);
+        auto minpos = [](int a, int b) { return (a >= 0 && b >= 0) ? std::min(a, b) : std::max(a, b); };
+        ref_out[list] = minpos(A.ref, minpos(B.ref, C.ref));
+    }
+    mv_out[0][0] = mv_out[0][1] = mv_out[1][0] = mv_out[1][1] = 0;
+    if (ref_out[0] < 0 && ref_out[1] < 0) { ref_out[0] = ref_out[1] = 0; return; }
+    for (int list = 0; list < 2; list++)
+        if (ref_out[list] >= 0) predict_mv(s, list, mbx, mby, 0, 0, 4, ref_out[list], 0, 0, mv_out[list][0], mv_out[list][1]);
+}
 
 // ---- mb_type of an intra macroblock (ffmpeg's numbering: 0 I_NxN, 1..24 I_16x16, 25 I_PCM); base 3 in I slices (prefix
 // with neighbour context), 17 in P, 32 in B (9.3.2.5, 9.3.3.1.1.3)
@@ -357,6 +430,18 @@ int dc_of(const Mb *n, bool cur_intra, int bit) {
 
 struct MbOut { uint8_t cls; int mvd_max[2]; };
 
+void mb_motion_record(const Mb &m, int &ax, int &ay) {   // mean motion vector of the macroblock (list 0 where it is used, else list 1)
+    int sx = 0, sy = 0, n = 0;
+    for (int b = 0; b < 16; b++) {
+        const int b8 = (b >> 3) * 2 + ((b & 3) >> 1);
+        const int list = m.aref[0][b8] >= 0 ? 0 : (m.aref[1][b8] >= 0 ? 1 : -1);
+        if (list < 0) continue;
+        sx += m.mv[list][b][0]; sy += m.mv[list][b][1]; n++;
+    }
+    ax = n ? std::abs(sx) / n : 0;
+    ay = n ? std::abs(sy) / n : 0;
+}
+
 // One macroblock_layer() (7.3.5) that is not skipped.  Fills `m`; returns false on a syntax error.
 bool macroblock(SliceCtx &s, int mbx, int mby, Mb &m, MbOut &out) {
     Cabac &c = s.c;
@@ -405,6 +490,8 @@ bool macroblock(SliceCtx &s, int mbx, int mby, Mb &m, MbOut &out) {
 
     std::memset(m.ref, 0, sizeof m.ref);
     std::memset(m.mvd, 0, sizeof m.mvd);
+    std::memset(m.aref, -1, sizeof m.aref);
+    std::memset(m.mv, 0, sizeof m.mv);
     m.direct8 = 0; m.t8x8 = 0; m.cbp = 0; m.chroma_mode = 0; m.nz_luma = 0; m.nz_cb = m.nz_cr = 0; m.dc = 0;
     out.mvd_max[0] = out.mvd_max[1] = 0;
     bool dct8_ok = sp.transform_8x8 != 0;   // transform_size_8x8_flag may follow the coded_block_pattern
@@ -452,6 +539,14 @@ bool macroblock(SliceCtx &s, int mbx, int mby, Mb &m, MbOut &out) {
         m.kind = K_DIRECT16;
         out.cls = 4;
         m.direct8 = 0xF;
+        {
+            int dr[2], dm[2][2];
+            b_direct_motion(s, mbx, mby, dr, dm);
+            for (int list = 0; list < 2; list++) {
+                for (int b8 = 0; b8 < 4; b8++) m.aref[list][b8] = (int8_t)dr[list];
+                if (dr[list] >= 0) fill_mv(m, list, 0, 0, 4, 4, dm[list][0], dm[list][1]);
+            }
+        }
         dct8_ok = dct8_ok && sp.direct_8x8_inference;
     } else {
         m.kind = K_INTER;
@@ -475,6 +570,16 @@ bool macroblock(SliceCtx &s, int mbx, int mby, Mb &m, MbOut &out) {
                     if (sub_shape[b8] != 0) dct8_ok = false;
                 }
             }
+        }
+        if (m.direct8) {   // direct sub-blocks: the macroblock's own neighbours decide (8.4.1.2.2), before anything else of this macroblock
+            int dr[2], dm[2][2];
+            b_direct_motion(s, mbx, mby, dr, dm);
+            for (int b8 = 0; b8 < 4; b8++)
+                if ((m.direct8 >> b8) & 1)
+                    for (int list = 0; list < 2; list++) {
+                        m.aref[list][b8] = (int8_t)dr[list];
+                        if (dr[list] >= 0) fill_mv(m, list, 2 * (b8 & 1), 2 * (b8 >> 1), 2, 2, dm[list][0], dm[list][1]);
+                    }
         }
         const int nref[2] = {sp.num_ref_l0, sp.num_ref_l1};
         // neighbour lookups on the 4x4 grid, across the macroblock border
@@ -514,7 +619,11 @@ bool macroblock(SliceCtx &s, int mbx, int mby, Mb &m, MbOut &out) {
                     }
                 }
                 for (int yy = 0; yy < h8; yy++)
-                    for (int xx = 0; xx < w8; xx++) m.ref[list][((y4 >> 1) + yy) * 2 + (x4 >> 1) + xx] = (int8_t)r;
+                    for (int xx = 0; xx < w8; xx++) {
+                        const int b8i = ((y4 >> 1) + yy) * 2 + (x4 >> 1) + xx;
+                        m.ref[list][b8i] = (int8_t)r;
+                        if ((lists >> list) & 1) m.aref[list][b8i] = (int8_t)r;
+                    }
             }
         }
         // ---- mvd_l0 of every (sub-)partition, then mvd_l1
@@ -538,10 +647,10 @@ bool macroblock(SliceCtx &s, int mbx, int mby, Mb &m, MbOut &out) {
                 }
             for (const Part &p : parts) {
                 if (!((p.lists >> list) & 1)) continue;
-                int ab[2];
+                int ab[2], sd[2];
                 for (int comp = 0; comp < 2; comp++) {
                     const int sum = mvd_at(list, p.x - 1, p.y, comp) + mvd_at(list, p.x, p.y - 1, comp);
-                    mvd_component(s, comp ? 47 : 40, sum, ab[comp]);
+                    sd[comp] = mvd_component(s, comp ? 47 : 40, sum, ab[comp]);
                     if (ab[comp] < 0) { s.why = "mvd escape code runs away"; return false; }
                     out.mvd_max[comp] = std::max(out.mvd_max[comp], ab[comp]);
                 }
@@ -550,6 +659,12 @@ bool macroblock(SliceCtx &s, int mbx, int mby, Mb &m, MbOut &out) {
                         m.mvd[list][(p.y + yy) * 4 + p.x + xx][0] = (uint8_t)std::min(ab[0], 70);
                         m.mvd[list][(p.y + yy) * 4 + p.x + xx][1] = (uint8_t)std::min(ab[1], 70);
                     }
+                {   // motion vector = prediction from the neighbours + the coded difference
+                    int px, py;
+                    const int hint = shape == 1 ? (p.y == 0 ? 1 : 2) : (shape == 2 ? (p.x == 0 ? 3 : 4) : 0);
+                    predict_mv(s, list, mbx, mby, p.x, p.y, p.w, m.aref[list][(p.y >> 1) * 2 + (p.x >> 1)], hint, blk_order(p.x, p.y), px, py);
+                    fill_mv(m, list, p.x, p.y, p.w, p.h, px + sd[0], py + sd[1]);
+                }
             }
         }
     }
@@ -662,10 +777,23 @@ int parse_slice_cabac(const uint8_t *rbsp, size_t len, size_t bit_offset, const 
         }
         if (skipped) {
             m = Mb();
-            m.kind = K_SKIP;
-            m.direct8 = sp.slice_type == 1 ? 0xF : 0;
+            m.kind = K_NONE;     // (its own blocks are not neighbours of itself)
             std::memset(m.ref, 0, sizeof m.ref);
             std::memset(m.mvd, 0, sizeof m.mvd);
+            std::memset(m.aref, -1, sizeof m.aref);
+            std::memset(m.mv, 0, sizeof m.mv);
+            if (sp.slice_type == 0) {
+                p_skip_motion(s, x, y, m);
+            } else {
+                int dr[2], dm[2][2];
+                b_direct_motion(s, x, y, dr, dm);
+                for (int list = 0; list < 2; list++) {
+                    for (int b8 = 0; b8 < 4; b8++) m.aref[list][b8] = (int8_t)dr[list];
+                    if (dr[list] >= 0) fill_mv(m, list, 0, 0, 4, 4, dm[list][0], dm[list][1]);
+                }
+            }
+            m.kind = K_SKIP;
+            m.direct8 = sp.slice_type == 1 ? 0xF : 0;
             s.last_dqp_nonzero = 0;
             out.cls = 0;
         } else if (!macroblock(s, x, y, m, out)) {
@@ -673,10 +801,12 @@ int parse_slice_cabac(const uint8_t *rbsp, size_t len, size_t bit_offset, const 
         }
         if (s.c.overrun) return fail(COVAHIP_ERR_BAD_DATA, "macroblock " + std::to_string(addr) + ": slice data exhausted");
         if (records) {
-            // [mb_type class, |mvd_x|, |mvd_y|, 0]: see h264_cabac.h for what these are and are not
+            // [macroblock class, |mv_x|, |mv_y|, 0]: see h264_cabac.h for what these are and are not
+            int ax, ay;
+            mb_motion_record(m, ax, ay);
             records[4 * addr] = out.cls;
-            records[4 * addr + 1] = (uint8_t)std::min(255, (out.mvd_max[0] + 2) >> 2);
-            records[4 * addr + 2] = (uint8_t)std::min(255, (out.mvd_max[1] + 2) >> 2);
+            records[4 * addr + 1] = (uint8_t)std::min(255, ax);
+            records[4 * addr + 2] = (uint8_t)std::min(255, ay);
             records[4 * addr + 3] = 0;
         }
         const int end = s.c.terminate();

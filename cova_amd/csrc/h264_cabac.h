@@ -18,6 +18,7 @@ struct SliceParams {
     int transform_8x8 = 0;       // PPS transform_8x8_mode_flag
     int direct_8x8_inference = 0;
     int chroma_format = 1;
+    int direct_spatial = 1;      // direct_spatial_mv_pred_flag (B slices); 0 = temporal direct, predicted spatially here
 };
 
 // Parses slice_data() of one slice that covers a whole frame picture.  rbsp: the NAL unit's payload behind its header byte
@@ -25,8 +26,11 @@ struct SliceParams {
 // records (may be NULL): width_mbs * height_mbs entries of 4 bytes,
 //   [0] macroblock class: 0 P_Skip / B_Skip, 1 inter 16x16, 2 inter 16x8 / 8x16, 3 inter 8x8 (sub-partitions), 4 B_Direct_16x16,
 //       5 intra NxN (4x4 / 8x8), 6 intra 16x16, 7 I_PCM;
-//   [1], [2] the largest |mvd_x|, |mvd_y| of the macroblock's partitions in full pixels (rounded from quarter pixels, <= 255).
-//       These are motion vector DIFFERENCES as coded, not motion vectors: prediction (median, skip, direct) is not performed;
+//   [1], [2] |mean motion vector| of the macroblock's sixteen 4x4 blocks, x and y, in quarter pixels (<= 255); list 0 where the block
+//       uses it, else list 1.  Motion vectors are the standard's: median / directional prediction from the neighbours (8.4.1.3) plus
+//       the coded difference, P_Skip inference (8.4.1.1), spatial direct prediction for B_Skip / B_Direct (8.4.1.2.2) -- with two
+//       stated gaps: the colZeroFlag test against the co-located picture is not made (no decoded picture buffer is kept), and
+//       temporal direct slices are predicted spatially;
 //   [3] 0.
 // Returns COVAHIP_OK only if exactly width_mbs * height_mbs macroblocks were decoded, end_of_slice_flag came with the last one and
 // nothing but trailing bits followed.  *why (may be NULL) names the first inconsistency otherwise.

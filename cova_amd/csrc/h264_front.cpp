@@ -395,6 +395,7 @@ int decode_slice_records(const covahip_h264 *h, const uint8_t *nal, const covahi
     sp.transform_8x8 = h->pps.transform_8x8;
     sp.direct_8x8_inference = h->sps.direct_8x8;
     sp.chroma_format = h->sps.chroma_format;
+    sp.direct_spatial = sl.direct_spatial;
     std::string why;
     const int rc = h264::parse_slice_cabac(rbsp.data(), rbsp.size(), sl.data_bit_offset, sp, records, &why);
     if (rc && getenv("COVAHIP_H264_DEBUG")) fprintf(stderr, "covahip h264: %s\n", why.c_str());

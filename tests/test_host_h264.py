@@ -101,11 +101,21 @@ def test_every_slice_entropy_decodes_to_its_last_macroblock(decoded):
     assert (pcls == 0).mean() > 0.5 and 0.01 < np.isin(pcls, (1, 2, 3)).mean() < 0.5 and np.isin(pcls, (5, 6)).mean() < 0.1
     assert not (pcls == 4).any()                                    # B_Direct_16x16 cannot occur in a P slice
     assert np.isin(bcls, (0, 4)).mean() > 0.9 and np.isin(bcls, (1, 2, 3)).any()
-    # skipped, direct and intra macroblocks carry no motion vector difference; predicted ones mostly small ones
+    # motion bytes: |mean motion vector| of the macroblock in quarter pixels (prediction + coded difference).  Intra macroblocks have
+    # none; a few per cent of the macroblocks of this traffic scene move by a pixel or more, and they form blobs, not salt and pepper:
+    # most moving macroblocks have a 4-neighbour that moves alike (a wrong median / skip / direct prediction would scatter them)
     mv = recs[..., 1:3]
-    assert not mv[np.isin(cls, (0, 4, 5, 6, 7))].any()
-    inter = np.isin(cls, (1, 2, 3))
-    assert mv[inter].any() and np.median(mv[inter].max(axis=-1)) <= 2 and mv[inter].max() < 160
+    assert not mv[cls >= 5].any()
+    for t, lo in ((0, 0.4), (1, 0.6)):
+        mag = mv[types == t].astype(int).max(axis=-1)
+        mov = mag >= 4
+        assert 0.005 < mov.mean() < 0.2
+        agree = np.zeros_like(mov)
+        for dy, dx in ((0, 1), (0, -1), (1, 0), (-1, 0)):
+            agree |= np.roll(mov, (dy, dx), axis=(1, 2)) & (np.abs(np.roll(mag, (dy, dx), axis=(1, 2)) - mag) <= 2)
+        assert (agree & mov).sum() / mov.sum() > lo
+    pskip = (cls == 0) & (types == 0)[:, None, None]
+    assert 0 < (mv.max(axis=-1)[pskip] > 0).mean() < 0.05          # P_Skip inherits its neighbours' motion, rarely a moving one
 
 
 def test_output_order_from_picture_order_counts_is_the_containers_composition_order(demo):
