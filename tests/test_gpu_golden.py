@@ -189,3 +189,34 @@ def test_lanes_order_behind_and_before_primary_stream_work(ctx, weights_flat):
         ctx.free(d_in)
         for p in out:
             ctx.free(p)
+
+
+def test_real_video_records_through_the_hot_path(ctx):
+    """Real compressed-domain input: the records of 64 consecutive output pictures of the reference's demo/1m.mp4 (entropy-decoded
+    here by this build's front end, tests/golden/gen_demo_records.py; the video itself cannot travel to the GPU box) as ONE stream
+    through the carrier-frame entry point with the blob-like weight set, against the oracle; the vehicle that crosses the scene
+    comes out as boxes."""
+    import os
+    from cova_amd import weights as W
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "demo_records_excerpt.npz"))
+    frames = z["records"]
+    n, h, w = frames.shape[0], 45, 80
+    flat = W.blob_like(7)
+    net = BlobNetInfer(ctx, flat, h, w, max_batch=n)
+    boxes, counts, mask, logits = net.filter_frames(frames, None, 1, max_boxes=512, want_mask=True, want_logits=True)
+    stack = np.stack([np.concatenate([frames[i - k] for k in range(4)], axis=0) for i in range(3, n)])
+    ref_logits, _ = ref.blobnet_forward(flat, stack, h, w)
+    atol, rtol = blobnet_tolerance(ref_logits)
+    assert (np.abs(logits - ref_logits) <= atol + rtol * np.abs(ref_logits)).all()
+    assert (np.abs(ref_logits[mask != (ref_logits > 0)]) <= atol).all()
+    _same_boxes(boxes, counts, *ref.regionprops_batch(mask, 1, 512))
+    # P pictures carry the motion (B pictures of this stream are almost entirely skipped / direct): while the vehicle is in the scene
+    # (the first 25 pictures) every P picture has a blob of >= 12 macroblocks
+    big = [int(boxes[i, :counts[i]]["area_px"].max()) if counts[i] else 0 for i in range(len(counts))]
+    assert sum(a >= 12 for a in big) >= 12 and all(a >= 12 for a in big[0:25:2])
+    # ... and where the blob is, the stream's own motion bytes are large
+    i = int(np.argmax(big))
+    b = boxes[i, :counts[i]][int(np.argmax(boxes[i, :counts[i]]["area_px"]))]
+    cur = frames[i + 3]
+    inside = cur[b["top"]:b["top"] + b["height"], b["left"]:b["left"] + b["width"], 1:3].max(axis=-1)
+    assert np.median(inside) >= 4
