@@ -280,6 +280,29 @@ def extra_legs(ctx, flat, steps):
     out["gamma_sign_mixed_b256_68x120"] = {"frames_per_s": round(BATCH / ms * 1e3, 1), "ms_per_step": round(ms, 4)}
     for p in (d_st, d_b, d_c):
         ctx.free(p)
+    # the timed workload with a representative weight set (cova_amd.weights.blob_like: a few connected blobs per frame instead of
+    # the ~500 one-macroblock components the seed-1234 random weights of `value` emit): bboxcc inside the fused tail has less to do
+    net = BlobNetInfer(ctx, W.blob_like(7), H_MB, W_MB, max_batch=BATCH)
+    frames, index = synth.carrier_batch(BATCH, H_MB, W_MB, seed=8, streams=8)
+    d_fr = ctx.malloc(frames.nbytes)
+    ctx.h2d(d_fr, frames)
+    outs = [(ctx.malloc(BATCH * 256 * 20), ctx.malloc(BATCH * 4)) for _ in range(2)]
+    turn = [0]
+
+    def step():
+        k = turn[0] = 1 - turn[0]
+        net.filter_frames_device(d_fr, frames.shape[0], index, BATCH, CC_THRESHOLD, outs[k][0], outs[k][1], 256)
+    ms1 = timed_steps(ctx, step, steps)
+    ctx.set_lanes(2)
+    ms2 = timed_steps(ctx, step, 2 * steps)
+    ctx.set_lanes(1)
+    cnt = np.zeros(BATCH, dtype=np.int32)
+    ctx.d2h(cnt, outs[0][1])
+    out["blob_like_weights_b256_68x120"] = {"frames_per_s": round(BATCH / ms2 * 1e3, 1), "ms_per_step": round(ms2, 4),
+                                            "ms_per_step_one_lane": round(ms1, 4), "boxes_per_frame_mean": round(float(cnt.mean()), 2)}
+    ctx.free(d_fr)
+    for o in outs:
+        ctx.free(o[0]); ctx.free(o[1])
     return out
 
 

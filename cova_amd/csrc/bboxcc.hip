@@ -98,7 +98,9 @@ __global__ __launch_bounds__(WV_WAVES * 64) void bboxcc_wave_kernel(const uint8_
                                          counts + frame, max_boxes, lane);
         if (lane == 0) {
             if (n > g.cap) ovf_list[atomicAdd(ovf_n, 1)] = frame;   // more runs than the LDS region holds
-            if (n_big && n > base_cap) atomicAdd(n_big, 1);        // (statistics for the next call's plan; pass 1 only)
+            // statistics for the next call's plan (pass 1 only), SAMPLED: one frame in sixteen -- an atomic per frame on one
+            // address cost more than the rest of the kernel when most frames had many runs (52 k same-address atomics = 0.5 ms)
+            if (n_big && (frame & 15) == 0 && n > base_cap) atomicAdd(n_big + (n > 2 * base_cap ? 1 : 0), 1);   // [0]: 128 < n <= 256, [1]: n > 256
         }
     };
     if (!list) {
@@ -135,8 +137,9 @@ int open_lds(covahip_ctx *ctx, K kernel, size_t lds) {
 //     frames in flight per CU); frames with more runs -- many objects, noise -- are collected in an overflow list and get a
 //     SECOND CHANCE on the wave kernel at four times the capacity (persistent launch over the list); what overflows that too
 //     goes to a persistent launch of the workgroup-per-frame kernel.  Passes 2 and 3 exit at once when their list is empty.
-//     The first pass's capacity adapts: when more than a quarter of the previous call's frames (same lane) overflowed, the
-//     next call starts at the larger capacity and skips the wasted first read of those frames.
+//     The first pass's capacity adapts: the kernel counts (on one frame in sixteen) the frames with more than 128 / more than
+//     256 runs; when a quarter of the previous call's frames (same lane) had that many, the next call starts at 256 / 512 and
+//     skips the wasted first read of those frames (256 runs: 7.2 KB of LDS per wave, twenty frames in flight per CU).
 // Everything else runs the workgroup-per-frame kernel.
 constexpr int WAVE_CAP = 128;
 int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, int h, int w, int area_thresh,
@@ -156,8 +159,10 @@ int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, in
         if (batch > 3 * num_cu) {
             // the previous call's statistics, when they have arrived (pinned host words behind an event): frames with more
             // than WAVE_CAP runs; until then the last decision stands
-            if (ln.cc_stat && ln.cc_stat_batch > 0 && hipEventQuery(ln.cc_stat_ev) == hipSuccess)
-                ln.cc_first_cap = 4 * (int64_t)ln.cc_stat[2] > ln.cc_stat_batch ? 4 * WAVE_CAP : WAVE_CAP;
+            if (ln.cc_stat && ln.cc_stat_batch > 0 && hipEventQuery(ln.cc_stat_ev) == hipSuccess) {   // (one frame in sixteen is counted; [2]: more than WAVE_CAP runs but at most twice that, [3]: more)
+                const int64_t mid = 16 * (int64_t)ln.cc_stat[2], big = 16 * (int64_t)ln.cc_stat[3];
+                ln.cc_first_cap = 4 * big > ln.cc_stat_batch ? 4 * WAVE_CAP : (4 * (mid + big) > ln.cc_stat_batch ? 2 * WAVE_CAP : WAVE_CAP);
+            }
             cap = ln.cc_first_cap ? ln.cc_first_cap : WAVE_CAP;
         }
     }

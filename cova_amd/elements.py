@@ -293,6 +293,10 @@ class FilterPipe:
         L.check(self._lib.covahip_pipe_submit(self._h, slot, n_frames, batch, cc_threshold), "covahip_pipe_submit", self.net.ctx.handle)
         self._batch[slot] = batch
 
+    def abort(self, slot: int):
+        """Gives an acquired, unsubmitted slot back (covahip_pipe_abort)."""
+        L.check(self._lib.covahip_pipe_abort(self._h, slot), "covahip_pipe_abort")
+
     def collect(self, slot: int):
         """-> (counts [B], offsets [B+1], packed boxes [offsets[B]], mask [B][h][w] | None): views, valid until the next
         acquire()."""

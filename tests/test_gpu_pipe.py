@@ -85,3 +85,31 @@ def test_pipe_argument_checks(ctx, weights_flat):
     assert lib.covahip_pipe_collect(pipe._h, slot, None, None, None, None) == 1        # nothing submitted
     assert lib.covahip_pipe_release(pipe._h, slot) == 1                                # nothing collected
     pipe.close()
+
+
+def test_abort_returns_an_acquired_slot_and_bad_submits_leave_the_pipe_usable(ctx, weights_flat):
+    """covahip_pipe_abort: an acquired slot that is not submitted (a failed submit, a shutdown with a partly filled batch) goes back
+    to the pool; a submit with impossible sizes is refused before anything is enqueued and the slot stays acquired."""
+    h, w, b = 45, 80, 8
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=8)
+    frames, index = synth.carrier_batch(b, h, w, seed=9, streams=2)
+    pipe = FilterPipe(net, max_batch=8, max_frames=16, max_boxes=64, n_slots=2)
+    a = pipe.acquire()
+    c = pipe.acquire()
+    assert a is not None and c is not None and pipe.acquire() is None           # both slots taken
+    assert pipe._lib.covahip_pipe_submit(pipe._h, a[0], 3, b, 1) == 1            # fewer than four frames: refused
+    assert pipe._lib.covahip_pipe_submit(pipe._h, a[0], frames.shape[0], 99, 1) == 1
+    assert pipe._lib.covahip_pipe_abort(pipe._h, 7) == 1                          # no such slot
+    pipe.abort(a[0])
+    assert pipe._lib.covahip_pipe_abort(pipe._h, a[0]) == 1                       # not acquired any more
+    again = pipe.acquire()
+    assert again is not None and again[0] == a[0]
+    slot, pf, pi = again
+    pf[:frames.shape[0]] = frames
+    pi[:b] = index
+    pipe.submit(slot, frames.shape[0], b, 2)
+    counts, offsets, boxes, _ = pipe.collect(slot)
+    rboxes, rcounts, _, _ = net.filter_frames(frames, index, 2, max_boxes=64)
+    np.testing.assert_array_equal(counts, rcounts)
+    pipe.abort(c[0])
+    pipe.close()

@@ -8,7 +8,7 @@
 #include <string.h>
 #include <time.h>
 
-#include "covahip.h"
+#include "covahip_dev.h"
 
 static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
@@ -32,6 +32,7 @@ static void *worker(void *arg) {
         for (int j = 0; j < PER; j++)
             for (int k = 0; k < 4; k++) idx[(j * S + s) * 4 + k] = s * (PER + 3) + j + 3 - k;
     if (covahip_ctx_set_lanes(ctx, g_lanes)) exit(4);
+    if (getenv("PROBE_IMPL") && covahip_blobnet_set_impl(ctx, atoi(getenv("PROBE_IMPL")))) exit(4);   /* developer switch: 4 = three-launch decoder */
     void *d_frames, *d_boxes[4], *d_counts[4];   // one output set per lane: concurrent calls must not share them
     if (covahip_malloc(ctx, NF * fb, &d_frames)) exit(4);
     for (int l = 0; l < 4; l++)
