@@ -121,44 +121,75 @@ const int LAST_BASE[6] = {166, 181, 195, 210, 213, 417};
 const int ABS_BASE[6] = {227, 237, 247, 257, 266, 426};
 const int MAX_COEFF[6] = {16, 15, 16, 4, 15, 64};
 
+// state byte (pStateIdx << 1 | valMPS) after the more ([0]) / less ([1]) probable symbol (9.3.3.2.1.1, table 9-45)
+struct NextState {
+    uint8_t t[2][128];
+    NextState() {
+        for (int s = 0; s < 128; s++) {
+            const int st = s >> 1, mps = s & 1;
+            t[0][s] = (uint8_t)(((st < 62 ? st + 1 : 62) << 1) | mps);
+            t[1][s] = (uint8_t)((TRANS_LPS[st] << 1) | (st == 0 ? (mps ^ 1) : mps));
+        }
+    }
+    const uint8_t *operator[](int k) const { return t[k]; }
+};
+const NextState NEXT_STATE;
 // ---------------------------------------------------------------------------------------------- arithmetic decoder (9.3.3.2)
 struct Cabac {
     const uint8_t *p = nullptr;
-    size_t nbits = 0, pos = 0;
+    size_t nbits = 0;     // always whole bytes
+    size_t next = 0;      // the next byte the reservoir takes
+    uint64_t res = 0;     // its low `nres` bits are the stream bits not consumed yet, the first of them highest
+    int nres = 0;
     uint32_t range = 510, offset = 0;
-    bool overrun = false;
     uint8_t state[460];   // pStateIdx << 1 | valMPS
-    uint32_t bit() {
-        if (pos >= nbits) { overrun = true; pos++; return 0; }
-        const uint32_t b = (p[pos >> 3] >> (7 - (pos & 7))) & 1;
-        pos++;
-        return b;
+    size_t pos() const { return next * 8 - (size_t)nres; }      // bits consumed so far
+    bool overrun() const { return pos() > nbits; }              // zeros are read behind the end; this tells
+    void refill() {
+        const size_t nbytes = nbits >> 3;
+        if (nres <= 32 && next + 4 <= nbytes) {
+            res = (res << 32) | ((uint32_t)p[next] << 24 | (uint32_t)p[next + 1] << 16 | (uint32_t)p[next + 2] << 8 | p[next + 3]);
+            next += 4;
+            nres += 32;
+            return;
+        }
+        while (nres <= 56) {
+            res = (res << 8) | (next < nbytes ? p[next] : 0);
+            next++;
+            nres += 8;
+        }
     }
+    void seek(size_t bitpos) {
+        next = bitpos >> 3;
+        res = 0;
+        nres = 0;
+        if (bitpos & 7) { refill(); nres -= (int)(bitpos & 7); }
+    }
+    // n <= 9 bits at once (renormalisation after a less probable symbol shifts up to 7 bits in)
+    uint32_t bits(int n) {
+        if (nres < n) refill();
+        nres -= n;
+        return (uint32_t)(res >> nres) & ((1u << n) - 1);
+    }
+    uint32_t bit() { return bits(1); }
     void start() {
         range = 510;
-        offset = 0;
-        for (int i = 0; i < 9; i++) offset = (offset << 1) | bit();
+        offset = bits(9);
     }
+    // DecodeDecision (9.3.3.2.1) without data-dependent branches: which of the two symbols comes is close to a coin toss for
+    // many contexts, and a mispredicted branch costs more than the arithmetic of both sides
     int decision(int ctx) {
-        uint8_t &s = state[ctx];
-        const uint32_t st = s >> 1, mps = s & 1;
-        const uint32_t lps = RANGE_LPS[st][(range >> 6) & 3];
-        int b;
+        const uint32_t s = state[ctx];
+        const uint32_t lps = RANGE_LPS[s >> 1][(range >> 6) & 3];
         range -= lps;
-        if (offset >= range) {
-            b = (int)(mps ^ 1);
-            offset -= range;
-            range = lps;
-            s = (uint8_t)((TRANS_LPS[st] << 1) | (st == 0 ? (mps ^ 1) : mps));
-        } else {
-            b = (int)mps;
-            s = (uint8_t)(((st < 62 ? st + 1 : 62) << 1) | mps);
-        }
-        while (range < 256) {
-            range <<= 1;
-            offset = (offset << 1) | bit();
-        }
-        return b;
+        const uint32_t less = (uint32_t)-(int32_t)(offset >= range);   // all ones: the less probable symbol
+        offset -= range & less;
+        range += (lps - range) & less;
+        state[ctx] = NEXT_STATE[less & 1][s];
+        const int sh = __builtin_clz(range) - 23;   // 0 .. 7: range back into [256, 510]
+        range <<= sh;
+        offset = (offset << sh) | bits(sh);
+        return (int)((s ^ less) & 1);
     }
     int bypass() {
         offset = (offset << 1) | bit();
@@ -210,11 +241,17 @@ struct Mb {
 struct SliceCtx {
     const SliceParams &sp;
     Cabac c;
-    std::vector<Mb> mbs;
+    Mb *mbs;                    // the calling thread's scratch (one slice at a time per thread): only `kind` is reset per slice
     int W, H;
     int last_dqp_nonzero = 0;
     std::string why;
-    explicit SliceCtx(const SliceParams &s) : sp(s), mbs((size_t)s.width_mbs * s.height_mbs), W(s.width_mbs), H(s.height_mbs) {}
+    explicit SliceCtx(const SliceParams &s) : sp(s), W(s.width_mbs), H(s.height_mbs) {
+        static thread_local std::vector<Mb> scratch;
+        const size_t n = (size_t)W * H;
+        if (scratch.size() < n) scratch.resize(n);
+        mbs = scratch.data();
+        for (size_t i = 0; i < n; i++) mbs[i].kind = K_NONE;
+    }
     const Mb *left(int x, int y) const { return x > 0 && mbs[(size_t)y * W + x - 1].kind != K_NONE ? &mbs[(size_t)y * W + x - 1] : nullptr; }
     const Mb *top(int x, int y) const { return y > 0 && mbs[(size_t)(y - 1) * W + x].kind != K_NONE ? &mbs[(size_t)(y - 1) * W + x] : nullptr; }
 };
@@ -264,30 +301,69 @@ inline void fill_mv(Mb &m, int list, int x, int y, int w, int h, int mx, int my)
     for (int yy = y; yy < y + h; yy++)
         for (int xx = x; xx < x + w; xx++) { m.mv[list][yy * 4 + xx][0] = (int16_t)mx; m.mv[list][yy * 4 + xx][1] = (int16_t)my; }
 }
+// The neighbours of a whole macroblock (a 16x16 partition: skip and direct prediction): A = block 3 of the left macroblock,
+// B = block 12 of the one above, C = block 12 of the one above to the right or, where that one is missing, D = block 15 of the
+// one above to the left -- nb_block / predict_mv for (x, y, w) = (0, 0, 4) without the per-block address arithmetic
+struct MbNb { const Mb *a, *b, *c; int cblk; };
+inline MbNb mb_neighbours(const SliceCtx &s, int mbx, int mby) {
+    MbNb n{nullptr, nullptr, nullptr, 12};
+    const Mb *row = s.mbs + (size_t)mby * s.W;
+    if (mbx > 0 && row[mbx - 1].kind != K_NONE) n.a = &row[mbx - 1];
+    if (mby > 0) {
+        const Mb *up = row - s.W;
+        if (up[mbx].kind != K_NONE) n.b = &up[mbx];
+        if (mbx + 1 < s.W && up[mbx + 1].kind != K_NONE) n.c = &up[mbx + 1];
+        else if (mbx > 0 && up[mbx - 1].kind != K_NONE) { n.c = &up[mbx - 1]; n.cblk = 15; }
+    }
+    return n;
+}
+inline Nb nb_of(const Mb *m, int list, int blk) {
+    if (!m) return Nb{false, -1, 0, 0};
+    const int r = m->aref[list][((blk >> 3) << 1) | ((blk & 3) >> 1)];
+    if (r < 0) return Nb{true, -1, 0, 0};
+    return Nb{true, r, m->mv[list][blk][0], m->mv[list][blk][1]};
+}
+inline void predict_16x16(const Nb &A, const Nb &B, const Nb &C, int ref, int &px, int &py) {
+    if (!B.avail && !C.avail && A.avail) { px = A.mx; py = A.my; return; }
+    const int n = (A.ref == ref) + (B.ref == ref) + (C.ref == ref);
+    if (n == 1) {
+        const Nb &m = A.ref == ref ? A : (B.ref == ref ? B : C);
+        px = m.mx; py = m.my;
+        return;
+    }
+    px = median3(A.mx, B.mx, C.mx);
+    py = median3(A.my, B.my, C.my);
+}
+inline void fill_mv_all(Mb &m, int list, int mx, int my) {
+    for (int b = 0; b < 16; b++) { m.mv[list][b][0] = (int16_t)mx; m.mv[list][b][1] = (int16_t)my; }
+}
 // P_Skip (8.4.1.1)
 void p_skip_motion(const SliceCtx &s, int mbx, int mby, Mb &m) {
-    const Nb A = nb_block(s, 0, mbx, mby, -1, 0, 0), B = nb_block(s, 0, mbx, mby, 0, -1, 0);
+    const MbNb nb = mb_neighbours(s, mbx, mby);
+    const Nb A = nb_of(nb.a, 0, 3), B = nb_of(nb.b, 0, 12);
     int mx = 0, my = 0;
     if (A.avail && B.avail && !(A.ref == 0 && A.mx == 0 && A.my == 0) && !(B.ref == 0 && B.mx == 0 && B.my == 0))
-        predict_mv(s, 0, mbx, mby, 0, 0, 4, 0, 0, 0, mx, my);
+        predict_16x16(A, B, nb_of(nb.c, 0, nb.cblk), 0, mx, my);
     for (int b8 = 0; b8 < 4; b8++) { m.aref[0][b8] = 0; m.aref[1][b8] = -1; }
-    fill_mv(m, 0, 0, 0, 4, 4, mx, my);
+    fill_mv_all(m, 0, mx, my);
 }
 // B_Skip / B_Direct_16x16 / direct sub-blocks, spatial direct mode (8.4.1.2.2) on the macroblock's own neighbours.  NOT done: the
 // colZeroFlag test against the co-located picture (a direct block over static background keeps the predicted vector instead of
 // zero); temporal direct slices take this path too.
 void b_direct_motion(const SliceCtx &s, int mbx, int mby, int ref_out[2], int mv_out[2][2]) {
+    const MbNb nb = mb_neighbours(s, mbx, mby);
+    Nb A[2], B[2], C[2];
     for (int list = 0; list < 2; list++) {
-        const Nb A = nb_block(s, list, mbx, mby, -1, 0, 0), B = nb_block(s, list, mbx, mby, 0, -1, 0);
-        Nb C = nb_block(s, list, mbx, mby, 4, -1, 0);
-        if (!C.avail) C = nb_block(s, list, mbx, mby, -1, -1, 0);
+        A[list] = nb_of(nb.a, list, 3);
+        B[list] = nb_of(nb.b, list, 12);
+        C[list] = nb_of(nb.c, list, nb.cblk);
         auto minpos = [](int a, int b) { return (a >= 0 && b >= 0) ? std::min(a, b) : std::max(a, b); };
-        ref_out[list] = minpos(A.ref, minpos(B.ref, C.ref));
+        ref_out[list] = minpos(A[list].ref, minpos(B[list].ref, C[list].ref));
     }
     mv_out[0][0] = mv_out[0][1] = mv_out[1][0] = mv_out[1][1] = 0;
     if (ref_out[0] < 0 && ref_out[1] < 0) { ref_out[0] = ref_out[1] = 0; return; }
     for (int list = 0; list < 2; list++)
-        if (ref_out[list] >= 0) predict_mv(s, list, mbx, mby, 0, 0, 4, ref_out[list], 0, 0, mv_out[list][0], mv_out[list][1]);
+        if (ref_out[list] >= 0) predict_16x16(A[list], B[list], C[list], ref_out[list], mv_out[list][0], mv_out[list][1]);
 }
 
 // ---- mb_type of an intra macroblock (ffmpeg's numbering: 0 I_NxN, 1..24 I_16x16, 25 I_PCM); base 3 in I slices (prefix
@@ -501,9 +577,9 @@ bool macroblock(SliceCtx &s, int mbx, int mby, Mb &m, MbOut &out) {
         m.kind = K_PCM;
         out.cls = 7;
         // (the decoder's register has already taken the encoder's closing 1; the rest of the byte is pcm_alignment_zero_bits)
-        c.pos = (c.pos + 7) & ~(size_t)7;
-        c.pos += 384 * 8;
-        if (c.pos > c.nbits) { s.why = "I_PCM: samples beyond the slice"; return false; }
+        const size_t behind = ((c.pos() + 7) & ~(size_t)7) + 384 * 8;
+        if (behind > c.nbits) { s.why = "I_PCM: samples beyond the slice"; return false; }
+        c.seek(behind);
         c.start();
         m.cbp = 0x2F; m.nz_luma = 0xFFFF; m.nz_cb = m.nz_cr = 0xF; m.dc = 7;
         s.last_dqp_nonzero = 0;
@@ -553,7 +629,8 @@ bool macroblock(SliceCtx &s, int mbx, int mby, Mb &m, MbOut &out) {
         out.cls = shape == 0 ? 1 : (shape == 3 ? 3 : 2);
         // geometry: per partition its 4x4 origin and size, its 8x8 blocks, its lists
         struct Part { int x, y, w, h, lists; };
-        std::vector<Part> parts;
+        Part parts[16];
+        int n_parts = 0;
         int sub_shape[4] = {0, 0, 0, 0}, sub_lists[4] = {1, 1, 1, 1};
         if (shape == 3) {
             for (int b8 = 0; b8 < 4; b8++) {
@@ -629,23 +706,24 @@ bool macroblock(SliceCtx &s, int mbx, int mby, Mb &m, MbOut &out) {
         // ---- mvd_l0 of every (sub-)partition, then mvd_l1
         for (int list = 0; list < 2; list++) {
             if (list == 1 && !bslice) break;
-            parts.clear();
-            if (shape == 0) parts.push_back({0, 0, 4, 4, plist[0]});
-            else if (shape == 1) { parts.push_back({0, 0, 4, 2, plist[0]}); parts.push_back({0, 2, 4, 2, plist[1]}); }
-            else if (shape == 2) { parts.push_back({0, 0, 2, 4, plist[0]}); parts.push_back({2, 0, 2, 4, plist[1]}); }
+            n_parts = 0;
+            if (shape == 0) parts[n_parts++] = Part{0, 0, 4, 4, plist[0]};
+            else if (shape == 1) { parts[n_parts++] = Part{0, 0, 4, 2, plist[0]}; parts[n_parts++] = Part{0, 2, 4, 2, plist[1]}; }
+            else if (shape == 2) { parts[n_parts++] = Part{0, 0, 2, 4, plist[0]}; parts[n_parts++] = Part{2, 0, 2, 4, plist[1]}; }
             else
                 for (int b8 = 0; b8 < 4; b8++) {
                     const int x0 = 2 * (b8 & 1), y0 = 2 * (b8 >> 1), l = sub_lists[b8];
                     if ((m.direct8 >> b8) & 1) continue;
                     switch (sub_shape[b8]) {
-                    case 0: parts.push_back({x0, y0, 2, 2, l}); break;
-                    case 1: parts.push_back({x0, y0, 2, 1, l}); parts.push_back({x0, y0 + 1, 2, 1, l}); break;
-                    case 2: parts.push_back({x0, y0, 1, 2, l}); parts.push_back({x0 + 1, y0, 1, 2, l}); break;
+                    case 0: parts[n_parts++] = Part{x0, y0, 2, 2, l}; break;
+                    case 1: parts[n_parts++] = Part{x0, y0, 2, 1, l}; parts[n_parts++] = Part{x0, y0 + 1, 2, 1, l}; break;
+                    case 2: parts[n_parts++] = Part{x0, y0, 1, 2, l}; parts[n_parts++] = Part{x0 + 1, y0, 1, 2, l}; break;
                     default:
-                        for (int k = 0; k < 4; k++) parts.push_back({x0 + (k & 1), y0 + (k >> 1), 1, 1, l});
+                        for (int k = 0; k < 4; k++) parts[n_parts++] = Part{x0 + (k & 1), y0 + (k >> 1), 1, 1, l};
                     }
                 }
-            for (const Part &p : parts) {
+            for (int pi = 0; pi < n_parts; pi++) {
+                const Part &p = parts[pi];
                 if (!((p.lists >> list) & 1)) continue;
                 int ab[2], sd[2];
                 for (int comp = 0; comp < 2; comp++) {
@@ -760,7 +838,7 @@ int parse_slice_cabac(const uint8_t *rbsp, size_t len, size_t bit_offset, const 
     SliceCtx s(sp);
     s.c.p = rbsp;
     s.c.nbits = len * 8;
-    s.c.pos = bit_offset;
+    s.c.seek(bit_offset);
     if (sp.slice_type == 2) init_contexts(s.c, INIT_I, sizeof INIT_I / sizeof INIT_I[0], sp.qp);
     else init_contexts(s.c, INIT_PB0, sizeof INIT_PB0 / sizeof INIT_PB0[0], sp.qp);
     s.c.start();
@@ -776,12 +854,7 @@ int parse_slice_cabac(const uint8_t *rbsp, size_t len, size_t bit_offset, const 
             skipped = s.c.decision((sp.slice_type == 0 ? 11 : 24) + inc) != 0;
         }
         if (skipped) {
-            m = Mb();
-            m.kind = K_NONE;     // (its own blocks are not neighbours of itself)
-            std::memset(m.ref, 0, sizeof m.ref);
-            std::memset(m.mvd, 0, sizeof m.mvd);
-            std::memset(m.aref, -1, sizeof m.aref);
-            std::memset(m.mv, 0, sizeof m.mv);
+            std::memset((void *)&m, 0, sizeof m);     // kind K_NONE: its own blocks are not neighbours of itself
             if (sp.slice_type == 0) {
                 p_skip_motion(s, x, y, m);
             } else {
@@ -789,7 +862,7 @@ int parse_slice_cabac(const uint8_t *rbsp, size_t len, size_t bit_offset, const 
                 b_direct_motion(s, x, y, dr, dm);
                 for (int list = 0; list < 2; list++) {
                     for (int b8 = 0; b8 < 4; b8++) m.aref[list][b8] = (int8_t)dr[list];
-                    if (dr[list] >= 0) fill_mv(m, list, 0, 0, 4, 4, dm[list][0], dm[list][1]);
+                    if (dr[list] >= 0) fill_mv_all(m, list, dm[list][0], dm[list][1]);
                 }
             }
             m.kind = K_SKIP;
@@ -799,7 +872,7 @@ int parse_slice_cabac(const uint8_t *rbsp, size_t len, size_t bit_offset, const 
         } else if (!macroblock(s, x, y, m, out)) {
             return fail(COVAHIP_ERR_BAD_DATA, "macroblock " + std::to_string(addr) + ": " + s.why);
         }
-        if (s.c.overrun) return fail(COVAHIP_ERR_BAD_DATA, "macroblock " + std::to_string(addr) + ": slice data exhausted");
+        if (s.c.overrun()) return fail(COVAHIP_ERR_BAD_DATA, "macroblock " + std::to_string(addr) + ": slice data exhausted");
         if (records) {
             // [macroblock class, |mv_x|, |mv_y|, 0]: see h264_cabac.h for what these are and are not
             int ax, ay;
@@ -818,9 +891,10 @@ int parse_slice_cabac(const uint8_t *rbsp, size_t len, size_t bit_offset, const 
     // (EncodeFlush writes ten bits behind the terminating bin, the decoder's nine-bit register has taken them all: 9.3.4.5);
     // what is left of that byte is alignment, then only cabac_zero_words.  (x264 puts a signature bit into the alignment
     // bits, so they are not required to be zero.)
-    if (s.c.pos == 0 || s.c.pos > s.c.nbits || !((rbsp[(s.c.pos - 1) >> 3] >> (7 - ((s.c.pos - 1) & 7))) & 1))
+    const size_t pos = s.c.pos();
+    if (pos == 0 || pos > s.c.nbits || !((rbsp[(pos - 1) >> 3] >> (7 - ((pos - 1) & 7))) & 1))
         return fail(COVAHIP_ERR_BAD_DATA, "rbsp_stop_one_bit");
-    for (size_t i = (s.c.pos + 7) / 8; i < len; i++)
+    for (size_t i = (pos + 7) / 8; i < len; i++)
         if (rbsp[i]) return fail(COVAHIP_ERR_BAD_DATA, "bytes behind the slice's trailing bits");
     return COVAHIP_OK;
 }
