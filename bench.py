@@ -113,6 +113,26 @@ def committed_traffic(kernel, entry="stack"):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baselines
+def effective_cores() -> int:
+    """CPUs this process may actually use: the smaller of the affinity mask and the cgroup's CPU quota (a GPU box shows
+    all 256 hardware threads to os.cpu_count() but grants a share of them -- /sys/fs/cgroup/cpu.max "1600000 100000" = 16;
+    OpenMP on 256 threads under that quota spends its time being throttled)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()])):
+        try:
+            quota, period = parse(open(path).read())
+            if quota != "max" and int(quota) > 0:
+                n = min(n, max(1, int(quota) // int(period)))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(flat, stack_sample, target_seconds=8.0):
     """CPU baseline on this host, on a bounded sample of the same workload.  Two ports of the reference
     path are timed and the FASTER one is reported as `value` (the reference itself -- Rust + OpenCV +
@@ -120,8 +140,8 @@ def cpu_baseline(flat, stack_sample, target_seconds=8.0):
       * the C oracle (oracle/blobnet_ref.c, OpenMP over frames, fp32) + oracle regionprops (1 thread);
       * the same graph in PyTorch-CPU (oneDNN convs, all cores) + oracle regionprops.
     Both are straightforward, untuned ports: a reported baseline, not a target."""
+    cores = effective_cores()
     from oracle import ref
-    cores = os.cpu_count() or 1
     n0 = min(len(stack_sample), max(2, cores))
     t0 = time.perf_counter()
     ref.blobnet_forward(flat, stack_sample[:n0], H_MB, W_MB)
@@ -213,7 +233,7 @@ def cpu_tracking_baseline(frames_per_stream=600):
     """SURVEY.md section 8(d) CPU leg (1): bboxcc + sorttracker on the host, one thread per stream -- at one thread and
     at N = min(cores, 32) independent streams in N processes."""
     import multiprocessing as mp
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     out = {}
     try:
         # worker processes, forked before this process has loaded the HIP library or touched the GPU
@@ -372,6 +392,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="only the timed workload (profiling runs)")
     args = ap.parse_args()
+    os.environ.setdefault("OMP_NUM_THREADS", str(effective_cores()))   # before anything loads libgomp (the oracle, torch)
 
     # ---- --gpus N without a launcher: start the N ranks ourselves, as a CHILD (this process has not touched the GPU and
     # never will), relay its output and exit with its code
@@ -399,7 +420,7 @@ def main():
             # experiment's tracker parameters, blob-like weights (a few boxes per frame, as a trained BlobNet gives)
             chain = element_rate("chain_bench.sh", ("20000", "16"))
             if "frames_per_s_full_chain" in chain:
-                t_cova = chain["seconds"] * min(16, os.cpu_count() or 1) / max(1, chain["frames_in"])
+                t_cova = chain["seconds"] * min(16, effective_cores()) / max(1, chain["frames_in"])
                 chain["limiter"] = ("host: the per-stream cova elements (SORT with the experiment's minhits 30 / maxage 60 keeps "
                                     "dozens of young trackers per stream alive); the GPU side of the same element runs at "
                                     "through_gstreamer_elements")
@@ -662,7 +683,7 @@ def main():
             if "frames_per_s_full_chain" in pre.get("full_filter_chain", {}):
                 fc = pre["full_filter_chain"]
                 fc["vs_cpu_full_chain"] = round(fc["frames_per_s_full_chain"] / cb.get("full_chain_frames_per_s", cb["value"]), 1)
-                fc["host_cores_one_gpu_would_need"] = int(line["value"] / max(1.0, fc["frames_per_s_full_chain"]) * min(16, os.cpu_count() or 1))
+                fc["host_cores_one_gpu_would_need"] = int(line["value"] / max(1.0, fc["frames_per_s_full_chain"]) * min(16, effective_cores()))
             line["gpu_over_cpu"] = round(line["value"] / world / line["cpu_baseline"]["value"], 1)
         # the long strings last, so that the numbers survive a truncated log
         line["config"] = {"workload": ("temporal stacking as a GPU gather + BlobNet + bboxcc fused (covahip_filter_forward_frames): carrier "
