@@ -129,6 +129,7 @@ PROTOTYPES = {
     "covahip_h264_sample_slices": (C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
     "covahip_h264_decode_records": (C.c_int, [_P, C.c_int, _P, _SZ]),
     "covahip_h264_display_order": (C.c_int, [_P, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "covahip_h264_colocated": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "covahip_h264_open_avcc": (C.c_int, [_P, _SZ, C.POINTER(_P)]),
     "covahip_h264_decode_au": (C.c_int, [_P, _P, _SZ, _P, _SZ, _P, C.POINTER(C.c_int64)]),
     "covahip_carrier_write_records": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _SZ]),

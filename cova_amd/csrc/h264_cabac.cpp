@@ -347,9 +347,9 @@ void p_skip_motion(const SliceCtx &s, int mbx, int mby, Mb &m) {
     for (int b8 = 0; b8 < 4; b8++) { m.aref[0][b8] = 0; m.aref[1][b8] = -1; }
     fill_mv_all(m, 0, mx, my);
 }
-// B_Skip / B_Direct_16x16 / direct sub-blocks, spatial direct mode (8.4.1.2.2) on the macroblock's own neighbours.  NOT done: the
-// colZeroFlag test against the co-located picture (a direct block over static background keeps the predicted vector instead of
-// zero); temporal direct slices take this path too.
+// B_Skip / B_Direct_16x16 / direct sub-blocks, spatial direct mode (8.4.1.2.2): reference indices and predicted vectors from the
+// macroblock's own neighbours; direct_fill applies them per 8x8 block with the colZeroFlag test.  Temporal direct slices take this
+// path too (stated gap).
 void b_direct_motion(const SliceCtx &s, int mbx, int mby, int ref_out[2], int mv_out[2][2]) {
     const MbNb nb = mb_neighbours(s, mbx, mby);
     Nb A[2], B[2], C[2];
@@ -364,6 +364,42 @@ void b_direct_motion(const SliceCtx &s, int mbx, int mby, int ref_out[2], int mv
     if (ref_out[0] < 0 && ref_out[1] < 0) { ref_out[0] = ref_out[1] = 0; return; }
     for (int list = 0; list < 2; list++)
         if (ref_out[list] >= 0) predict_16x16(A[list], B[list], C[list], ref_out[list], mv_out[list][0], mv_out[list][1]);
+}
+
+// Direct-mode motion of the 8x8 blocks in `mask` from the macroblock-level result of b_direct_motion: list X's vector is zero
+// where its reference index is 0 and the co-located block of RefPicList1[0] does not move (colZeroFlag; with
+// direct_8x8_inference_flag the co-located block of a quadrant is the macroblock's corner block of that quadrant)
+void direct_fill(const SliceCtx &s, Mb &m, int addr, int mask, const int dr[2], const int dm[2][2]) {
+    const unsigned still = (s.sp.col_still && s.sp.direct_spatial) ? s.sp.col_still[addr] : 0u;
+    for (int b8 = 0; b8 < 4; b8++) {
+        if (!((mask >> b8) & 1)) continue;
+        const int x0 = 2 * (b8 & 1), y0 = 2 * (b8 >> 1);
+        for (int list = 0; list < 2; list++) m.aref[list][b8] = (int8_t)dr[list];
+        for (int k = 0; k < 4; k++) {
+            const int x = x0 + (k & 1), y = y0 + (k >> 1), blk = y * 4 + x;
+            const int colblk = s.sp.direct_8x8_inference ? (y0 ? 12 : 0) + (x0 ? 3 : 0) : blk;
+            const bool cz = (still >> colblk) & 1;
+            for (int list = 0; list < 2; list++) {
+                if (dr[list] < 0) continue;
+                const bool zero = dr[list] == 0 && cz;
+                m.mv[list][blk][0] = (int16_t)(zero ? 0 : dm[list][0]);
+                m.mv[list][blk][1] = (int16_t)(zero ? 0 : dm[list][1]);
+            }
+        }
+    }
+}
+// "does not move" bits of a decoded macroblock (SliceParams::still_out)
+uint16_t still_bits(const Mb &m) {
+    if (is_intra(m.kind)) return 0;
+    uint16_t bits = 0;
+    for (int blk = 0; blk < 16; blk++) {
+        const int b8 = (blk >> 3) * 2 + ((blk & 3) >> 1);
+        const int list = m.aref[0][b8] >= 0 ? 0 : (m.aref[1][b8] >= 0 ? 1 : -1);
+        if (list < 0 || m.aref[list][b8] != 0) continue;
+        const int mx = m.mv[list][blk][0], my = m.mv[list][blk][1];
+        if (mx >= -1 && mx <= 1 && my >= -1 && my <= 1) bits |= (uint16_t)(1u << blk);
+    }
+    return bits;
 }
 
 // ---- mb_type of an intra macroblock (ffmpeg's numbering: 0 I_NxN, 1..24 I_16x16, 25 I_PCM); base 3 in I slices (prefix
@@ -618,10 +654,7 @@ bool macroblock(SliceCtx &s, int mbx, int mby, Mb &m, MbOut &out) {
         {
             int dr[2], dm[2][2];
             b_direct_motion(s, mbx, mby, dr, dm);
-            for (int list = 0; list < 2; list++) {
-                for (int b8 = 0; b8 < 4; b8++) m.aref[list][b8] = (int8_t)dr[list];
-                if (dr[list] >= 0) fill_mv(m, list, 0, 0, 4, 4, dm[list][0], dm[list][1]);
-            }
+            direct_fill(s, m, mby * s.W + mbx, 0xF, dr, dm);
         }
         dct8_ok = dct8_ok && sp.direct_8x8_inference;
     } else {
@@ -651,12 +684,7 @@ bool macroblock(SliceCtx &s, int mbx, int mby, Mb &m, MbOut &out) {
         if (m.direct8) {   // direct sub-blocks: the macroblock's own neighbours decide (8.4.1.2.2), before anything else of this macroblock
             int dr[2], dm[2][2];
             b_direct_motion(s, mbx, mby, dr, dm);
-            for (int b8 = 0; b8 < 4; b8++)
-                if ((m.direct8 >> b8) & 1)
-                    for (int list = 0; list < 2; list++) {
-                        m.aref[list][b8] = (int8_t)dr[list];
-                        if (dr[list] >= 0) fill_mv(m, list, 2 * (b8 & 1), 2 * (b8 >> 1), 2, 2, dm[list][0], dm[list][1]);
-                    }
+            direct_fill(s, m, mby * s.W + mbx, m.direct8, dr, dm);
         }
         const int nref[2] = {sp.num_ref_l0, sp.num_ref_l1};
         // neighbour lookups on the 4x4 grid, across the macroblock border
@@ -860,10 +888,7 @@ int parse_slice_cabac(const uint8_t *rbsp, size_t len, size_t bit_offset, const 
             } else {
                 int dr[2], dm[2][2];
                 b_direct_motion(s, x, y, dr, dm);
-                for (int list = 0; list < 2; list++) {
-                    for (int b8 = 0; b8 < 4; b8++) m.aref[list][b8] = (int8_t)dr[list];
-                    if (dr[list] >= 0) fill_mv_all(m, list, dm[list][0], dm[list][1]);
-                }
+                direct_fill(s, m, addr, 0xF, dr, dm);
             }
             m.kind = K_SKIP;
             m.direct8 = sp.slice_type == 1 ? 0xF : 0;
@@ -873,6 +898,7 @@ int parse_slice_cabac(const uint8_t *rbsp, size_t len, size_t bit_offset, const 
             return fail(COVAHIP_ERR_BAD_DATA, "macroblock " + std::to_string(addr) + ": " + s.why);
         }
         if (s.c.overrun()) return fail(COVAHIP_ERR_BAD_DATA, "macroblock " + std::to_string(addr) + ": slice data exhausted");
+        if (sp.still_out) sp.still_out[addr] = still_bits(m);
         if (records) {
             // [macroblock class, |mv_x|, |mv_y|, 0]: see h264_cabac.h for what these are and are not
             int ax, ay;

@@ -19,6 +19,12 @@ struct SliceParams {
     int direct_8x8_inference = 0;
     int chroma_format = 1;
     int direct_spatial = 1;      // direct_spatial_mv_pred_flag (B slices); 0 = temporal direct, predicted spatially here
+    // colZeroFlag input (8.4.1.2.2): per macroblock of RefPicList1[0] one bit per 4x4 block (bit y * 4 + x) = "the block does not
+    // move" (inter, reference index 0 of the list it uses -- list 0 first --, both vector components within +-1); NULL when the
+    // slice is not B, RefPicList1[0] is a long-term picture or its motion is not known: the test then reads "moving" everywhere
+    const uint16_t *col_still = nullptr;
+    // the same bits of THIS picture, for the pictures that will have it as RefPicList1[0] (may be NULL)
+    uint16_t *still_out = nullptr;
 };
 
 // Parses slice_data() of one slice that covers a whole frame picture.  rbsp: the NAL unit's payload behind its header byte
@@ -28,9 +34,9 @@ struct SliceParams {
 //       5 intra NxN (4x4 / 8x8), 6 intra 16x16, 7 I_PCM;
 //   [1], [2] |mean motion vector| of the macroblock's sixteen 4x4 blocks, x and y, in quarter pixels (<= 255); list 0 where the block
 //       uses it, else list 1.  Motion vectors are the standard's: median / directional prediction from the neighbours (8.4.1.3) plus
-//       the coded difference, P_Skip inference (8.4.1.1), spatial direct prediction for B_Skip / B_Direct (8.4.1.2.2) -- with two
-//       stated gaps: the colZeroFlag test against the co-located picture is not made (no decoded picture buffer is kept), and
-//       temporal direct slices are predicted spatially;
+//       the coded difference, P_Skip inference (8.4.1.1), spatial direct prediction for B_Skip / B_Direct (8.4.1.2.2) including
+//       the colZeroFlag test when the caller supplies col_still -- with one stated gap: temporal direct slices
+//       (direct_spatial_mv_pred_flag 0) are predicted spatially, without that test;
 //   [3] 0.
 // Returns COVAHIP_OK only if exactly width_mbs * height_mbs macroblocks were decoded, end_of_slice_flag came with the last one and
 // nothing but trailing bits followed.  *why (may be NULL) names the first inconsistency otherwise.

@@ -12,7 +12,9 @@
 //   * picture order counts (8.2.1, types 0 and 2) and the output (display) order of the access units -- avdec_h264 hands
 //     frames downstream in that order, and metapreprocess stacks consecutive OUTPUT frames,
 //   * covahip_h264_decode_records: CABAC macroblock layer of a whole-picture slice -> records (h264_cabac.h says what the
-//     three bytes are: macroblock class and the coded motion vector differences, no prediction),
+//     three bytes are: macroblock class and the |mean motion vector| as the standard reconstructs it),
+//   * what direct prediction needs of the reference pictures: reference marking (8.2.5), RefPicList1[0] (8.2.4.2.3, 8.2.4.3)
+//     and the co-located picture's "does not move" bits for colZeroFlag (8.4.1.2.2) -- no pixels,
 //   * the carrier layout writer (covahip_carrier_write_records).
 // Refused loudly (COVAHIP_ERR_UNSUPPORTED), never faked: CAVLC, field / MBAFF coding, several slices per picture, FMO,
 // scaling matrices, chroma formats other than 4:2:0, cabac_init_idc 1 / 2.
@@ -21,6 +23,9 @@
 #include <algorithm>
 #include <cstring>
 #include <new>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "covahip.h"
@@ -146,6 +151,123 @@ bool parse_pps(const std::vector<uint8_t> &rbsp, Pps &p) {
 
 struct Sample { uint64_t off; uint32_t size; bool sync; };
 
+// What the reference picture lists and the marking process need from a slice header beyond covahip_h264_slice (kept out of the
+// public struct): the list-1 modification commands (7.3.3.1) and dec_ref_pic_marking (7.3.3.3)
+struct RplOp { int idc; uint32_t val; };
+struct Mmco { int op; uint32_t a, b; };
+struct SliceExt {
+    std::vector<RplOp> l1;
+    std::vector<Mmco> mmco;
+    bool adaptive = false, long_term_reference = false;
+};
+
+// The reference pictures (frames only) as far as RefPicList1[0] needs them: decoded reference picture marking (8.2.5) and the
+// initialisation + modification of list 1 (8.2.4.2.3, 8.2.4.3).  `id` names a picture for the caller (sample index / running count).
+struct RefPic { int id; int frame_num; int64_t key; bool lt; int lt_idx; };
+struct Dpb {
+    std::vector<RefPic> refs;
+    // RefPicList1[0] of the B picture described by (sl, ext, key), before it is decoded.  false: no such picture.
+    bool list1_first(const Sps &sp, const covahip_h264_slice &sl, const SliceExt &ext, int64_t key, int &id, bool &short_term) const {
+        const int max_fn = 1 << sp.log2_max_frame_num;
+        auto pic_num = [&](const RefPic &r) { return r.frame_num > sl.frame_num ? r.frame_num - max_fn : r.frame_num; };
+        std::vector<int> before, after, lt;
+        for (int i = 0; i < (int)refs.size(); i++) (refs[i].lt ? lt : (refs[i].key < key ? before : after)).push_back(i);
+        std::sort(before.begin(), before.end(), [&](int a, int b) { return refs[a].key > refs[b].key; });
+        std::sort(after.begin(), after.end(), [&](int a, int b) { return refs[a].key < refs[b].key; });
+        std::sort(lt.begin(), lt.end(), [&](int a, int b) { return refs[a].lt_idx < refs[b].lt_idx; });
+        std::vector<int> l0 = before, l1 = after;
+        l0.insert(l0.end(), after.begin(), after.end());
+        l1.insert(l1.end(), before.begin(), before.end());
+        l0.insert(l0.end(), lt.begin(), lt.end());
+        l1.insert(l1.end(), lt.begin(), lt.end());
+        if (l1.size() > 1 && l1 == l0) std::swap(l1[0], l1[1]);
+        const size_t n1 = (size_t)std::max(1, sl.num_ref_l1);
+        l1.resize(n1, -1);
+        size_t at = 0;
+        int pred = sl.frame_num;   // CurrPicNum (frames)
+        for (const RplOp &op : ext.l1) {
+            int pick = -1;
+            if (op.idc == 0 || op.idc == 1) {
+                const int64_t d = (int64_t)op.val + 1;   // (a damaged header may carry any 32-bit value)
+                int64_t nw = op.idc == 0 ? (int64_t)pred - d : (int64_t)pred + d;
+                nw = ((nw % max_fn) + max_fn) % max_fn;
+                const int nowrap = (int)nw;
+                pred = nowrap;
+                const int pn = nowrap > sl.frame_num ? nowrap - max_fn : nowrap;
+                for (int i = 0; i < (int)refs.size(); i++)
+                    if (!refs[i].lt && pic_num(refs[i]) == pn) pick = i;
+            } else if (op.idc == 2) {
+                for (int i = 0; i < (int)refs.size(); i++)
+                    if (refs[i].lt && refs[i].lt_idx == (int)op.val) pick = i;
+            }
+            if (pick < 0 || at >= n1) continue;   // a command that names no reference picture: ignored
+            l1.insert(l1.begin() + (long)at, pick);
+            at++;
+            for (size_t k = at; k < l1.size(); k++)
+                if (l1[k] == pick) { l1.erase(l1.begin() + (long)k); break; }
+            l1.resize(n1, -1);
+        }
+        if (l1.empty() || l1[0] < 0) return false;
+        id = refs[(size_t)l1[0]].id;
+        short_term = !refs[(size_t)l1[0]].lt;
+        return true;
+    }
+    // after the picture (sl, ext) with identifier id has been decoded
+    void mark(const Sps &sp, const covahip_h264_slice &sl, const SliceExt &ext, int id, int64_t key) {
+        if (sl.nal_ref_idc == 0) return;
+        const int max_fn = 1 << sp.log2_max_frame_num;
+        auto pic_num = [&](const RefPic &r) { return r.frame_num > sl.frame_num ? r.frame_num - max_fn : r.frame_num; };
+        auto drop_lt_idx = [&](int idx) {
+            refs.erase(std::remove_if(refs.begin(), refs.end(), [&](const RefPic &r) { return r.lt && r.lt_idx == idx; }), refs.end());
+        };
+        RefPic cur{id, sl.frame_num, key, false, 0};
+        if (sl.idr) {
+            refs.clear();
+            if (ext.long_term_reference) { cur.lt = true; cur.lt_idx = 0; }
+        } else if (ext.adaptive) {
+            for (const Mmco &m : ext.mmco) {
+                if (m.op == 1 || m.op == 3) {
+                    const int64_t pn = (int64_t)sl.frame_num - ((int64_t)m.a + 1);
+                    for (size_t i = 0; i < refs.size(); i++)
+                        if (!refs[i].lt && pic_num(refs[i]) == pn) {
+                            if (m.op == 1) { refs.erase(refs.begin() + (long)i); }
+                            else {
+                                RefPic moved = refs[i];
+                                refs.erase(refs.begin() + (long)i);
+                                drop_lt_idx((int)m.b);
+                                moved.lt = true; moved.lt_idx = (int)m.b;
+                                refs.push_back(moved);
+                            }
+                            break;
+                        }
+                } else if (m.op == 2) {
+                    drop_lt_idx((int)m.a);
+                } else if (m.op == 4) {
+                    const int keep = (int)m.a - 1;   // MaxLongTermFrameIdx; -1: none
+                    refs.erase(std::remove_if(refs.begin(), refs.end(), [&](const RefPic &r) { return r.lt && r.lt_idx > keep; }), refs.end());
+                } else if (m.op == 5) {
+                    refs.clear();
+                    cur.frame_num = 0;
+                } else if (m.op == 6) {
+                    drop_lt_idx((int)m.a);
+                    cur.lt = true; cur.lt_idx = (int)m.a;
+                }
+            }
+        } else {
+            // sliding window (8.2.5.3): the short-term picture with the smallest FrameNumWrap goes when the buffer is full
+            const size_t cap = (size_t)std::max(1, sp.num_ref_frames);
+            while (refs.size() >= cap) {
+                int victim = -1;
+                for (int i = 0; i < (int)refs.size(); i++)
+                    if (!refs[i].lt && (victim < 0 || pic_num(refs[i]) < pic_num(refs[(size_t)victim]))) victim = i;
+                if (victim < 0) break;
+                refs.erase(refs.begin() + victim);
+            }
+        }
+        refs.push_back(cur);
+    }
+};
+
 uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 uint64_t be64(const uint8_t *p) { return ((uint64_t)be32(p) << 32) | be32(p + 4); }
 
@@ -161,6 +283,19 @@ struct covahip_h264 {
     std::vector<int64_t> order_key;     // per sample: (IDR period << 32) + picture order count + 2^31; empty when not computable
     std::vector<int32_t> display;       // sample indices in output order
     struct PocState { int64_t prev_msb = 0, prev_lsb = 0, period = -1, fn_off = 0, prev_fn = 0; } poc;   // stream form (covahip_h264_decode_au)
+    // colZeroFlag (8.4.1.2.2): per picture the "does not move" bits of its macroblocks (h264_cabac.h, SliceParams::col_still)
+    typedef std::shared_ptr<std::vector<uint16_t>> Still;
+    // file form: per sample the sample that is its RefPicList1[0] (-1: none / not B) and whether that is a short-term picture
+    // (from a pass over the slice headers at open); bits of decoded reference pictures are kept for the B pictures that follow
+    std::vector<int32_t> col_sample;
+    std::vector<uint8_t> col_short;
+    mutable std::mutex still_mu;
+    mutable std::map<int, Still> still_cache;
+    mutable std::vector<int> still_order;   // insertion order, oldest first
+    // stream form: the reference pictures so far and their bits, by running picture count
+    Dpb dpb;
+    int au_count = 0;
+    std::map<int, Still> still_live;
 };
 
 namespace {
@@ -179,7 +314,7 @@ bool find_box(const uint8_t *d, size_t off, size_t end, const char *type, size_t
     return false;
 }
 
-int parse_slice_header(const covahip_h264 *h, const uint8_t *nal, size_t n, covahip_h264_slice *s) {
+int parse_slice_header(const covahip_h264 *h, const uint8_t *nal, size_t n, covahip_h264_slice *s, SliceExt *ext = nullptr) {
     if (n < 2) return COVAHIP_ERR_BAD_DATA;
     const int nal_ref_idc = (nal[0] >> 5) & 3, nal_type = nal[0] & 31;
     // the header never needs more than a few dozen bytes; unescape a bounded prefix
@@ -225,7 +360,10 @@ int parse_slice_header(const covahip_h264 *h, const uint8_t *nal, size_t n, cova
                 uint32_t op;
                 do {
                     op = r.ue();
-                    if (op == 0 || op == 1 || op == 2) r.ue();
+                    if (op == 0 || op == 1 || op == 2) {
+                        const uint32_t v = r.ue();
+                        if (ext && list == 1) ext->l1.push_back(RplOp{(int)op, v});
+                    }
                 } while (op != 3 && !r.bad);
             }
     }
@@ -243,16 +381,23 @@ int parse_slice_header(const covahip_h264 *h, const uint8_t *nal, size_t n, cova
     }
     // dec_ref_pic_marking (7.3.3.3)
     if (nal_ref_idc != 0) {
-        if (s->idr) { r.u(1); r.u(1); }
-        else if (r.u(1)) {
+        if (s->idr) {
+            r.u(1);                                   // no_output_of_prior_pics_flag
+            const uint32_t ltr = r.u(1);              // long_term_reference_flag
+            if (ext) ext->long_term_reference = ltr != 0;
+        } else if (r.u(1)) {
+            if (ext) ext->adaptive = true;
             uint32_t op;
             do {
                 op = r.ue();
-                if (op == 1 || op == 3) r.ue();   // difference_of_pic_nums_minus1
-                if (op == 2) r.ue();              // long_term_pic_num
-                if (op == 3 || op == 6) r.ue();   // long_term_frame_idx
-                if (op == 4) r.ue();              // max_long_term_frame_idx_plus1
-                if (op == 5) s->has_mmco5 = 1;    // resets the picture order count (8.2.1)
+                Mmco m{(int)op, 0, 0};
+                if (op == 1 || op == 3) m.a = r.ue();   // difference_of_pic_nums_minus1
+                if (op == 2) m.a = r.ue();              // long_term_pic_num
+                if (op == 3) m.b = r.ue();              // long_term_frame_idx
+                if (op == 6) m.a = r.ue();              // long_term_frame_idx
+                if (op == 4) m.a = r.ue();              // max_long_term_frame_idx_plus1
+                if (op == 5) s->has_mmco5 = 1;          // resets the picture order count (8.2.1)
+                if (ext && op != 0) ext->mmco.push_back(m);
             } while (op != 0 && !r.bad);
         }
     }
@@ -303,20 +448,38 @@ bool poc_step(const Sps &sp, covahip_h264::PocState &st, const covahip_h264_slic
     return true;
 }
 
+int au_slices(const covahip_h264 *h, const uint8_t *au, size_t len, uint64_t base, covahip_h264_slice *out, int cap, int *n,
+              SliceExt *first_ext);
+
 // Output order of a file's access units: within an IDR period pictures leave the decoder by ascending POC.  Leaves `display`
 // empty when a header does not parse or for POC type 1.
 void compute_display_order(covahip_h264 *h) {
     const size_t n = h->samples.size();
     h->order_key.assign(n, 0);
+    h->col_sample.assign(n, -1);
+    h->col_short.assign(n, 0);
     covahip_h264::PocState st;
+    Dpb dpb;
     for (size_t i = 0; i < n; i++) {
         covahip_h264_slice sl[1];
+        SliceExt ext;
         int cnt = 0;
-        const int rc = covahip_h264_sample_slices(h, (int)i, sl, 1, &cnt);
+        const Sample &sm = h->samples[i];
+        const int rc = au_slices(h, h->data + sm.off, sm.size, sm.off, sl, 1, &cnt, &ext);
         if ((rc != COVAHIP_OK && rc != COVAHIP_ERR_OVERFLOW) || cnt < 1 || !poc_step(h->sps, st, sl[0], h->order_key[i])) {
             h->order_key.clear();
+            h->col_sample.assign(n, -1);
             return;
         }
+        // RefPicList1[0] of a B picture (the co-located picture of its direct prediction), then the marking of this picture
+        int64_t key = h->order_key[i];
+        if (sl[0].slice_type == 1) {
+            int id = -1;
+            bool st1 = false;
+            if (dpb.list1_first(h->sps, sl[0], ext, key, id, st1)) { h->col_sample[i] = id; h->col_short[i] = st1 ? 1 : 0; }
+        }
+        if (sl[0].has_mmco5) key = (st.period << 32) + (1ll << 31);   // tempPicOrderCnt subtracted: the picture's own count becomes 0
+        dpb.mark(h->sps, sl[0], ext, (int)i, key);
     }
     h->display.resize(n);
     for (size_t i = 0; i < n; i++) h->display[i] = (int32_t)i;
@@ -324,7 +487,8 @@ void compute_display_order(covahip_h264 *h) {
 }
 
 // Slice NAL units of one access unit (length-prefixed NAL units at au[0, len)); nal_offset = base + offset inside au.
-int au_slices(const covahip_h264 *h, const uint8_t *au, size_t len, uint64_t base, covahip_h264_slice *out, int cap, int *n) {
+int au_slices(const covahip_h264 *h, const uint8_t *au, size_t len, uint64_t base, covahip_h264_slice *out, int cap, int *n,
+              SliceExt *first_ext) {
     size_t p = 0;
     int cnt = 0;
     while (p + h->nal_len_size <= len) {
@@ -337,7 +501,7 @@ int au_slices(const covahip_h264 *h, const uint8_t *au, size_t len, uint64_t bas
             if (cnt < cap) {
                 covahip_h264_slice sl;
                 std::memset(&sl, 0, sizeof sl);
-                int rc = parse_slice_header(h, au + p, l, &sl);
+                int rc = parse_slice_header(h, au + p, l, &sl, cnt == 0 ? first_ext : nullptr);
                 if (rc) return rc;
                 sl.nal_offset = base + (uint64_t)p;
                 out[cnt] = sl;
@@ -376,7 +540,8 @@ int parse_avcc(covahip_h264 *h, const uint8_t *a, size_t n) {
 }
 
 // Entropy-decodes the single whole-picture slice `sl` whose NAL unit starts at nal.
-int decode_slice_records(const covahip_h264 *h, const uint8_t *nal, const covahip_h264_slice &sl, uint8_t *records, size_t cap) {
+int decode_slice_records(const covahip_h264 *h, const uint8_t *nal, const covahip_h264_slice &sl, uint8_t *records, size_t cap,
+                         const uint16_t *col_still = nullptr, uint16_t *still_out = nullptr) {
     const int wmb = h->sps.width_mbs, hmb = h->sps.height_map_units;
     if (records && cap < (size_t)wmb * hmb * 4) return COVAHIP_ERR_OVERFLOW;
     // CAVLC streams, field / MBAFF coding: not built -- refused, never faked
@@ -396,10 +561,54 @@ int decode_slice_records(const covahip_h264 *h, const uint8_t *nal, const covahi
     sp.direct_8x8_inference = h->sps.direct_8x8;
     sp.chroma_format = h->sps.chroma_format;
     sp.direct_spatial = sl.direct_spatial;
+    sp.col_still = sl.slice_type == 1 ? col_still : nullptr;
+    sp.still_out = still_out;
     std::string why;
     const int rc = h264::parse_slice_cabac(rbsp.data(), rbsp.size(), sl.data_bit_offset, sp, records, &why);
     if (rc && getenv("COVAHIP_H264_DEBUG")) fprintf(stderr, "covahip h264: %s\n", why.c_str());
     return rc;
+}
+
+// File form: the "does not move" bits of sample `sample` (a reference picture), decoding it -- and, for a B reference picture,
+// first the picture its own direct prediction looks at -- when no earlier call has left them in the cache.
+covahip_h264::Still still_of(const covahip_h264 *h, int sample, int depth);
+int decode_sample(const covahip_h264 *h, int sample, uint8_t *records, size_t cap, int depth) {
+    covahip_h264_slice sl[2];
+    int n = 0;
+    const int rc = covahip_h264_sample_slices(h, sample, sl, 2, &n);
+    if (rc == COVAHIP_ERR_OVERFLOW || (rc == COVAHIP_OK && n != 1)) return COVAHIP_ERR_UNSUPPORTED;   // several slices per picture
+    if (rc) return rc;
+    covahip_h264::Still col;
+    if (sl[0].slice_type == 1 && sl[0].direct_spatial && (size_t)sample < h->col_sample.size() && h->col_sample[(size_t)sample] >= 0 &&
+        h->col_short[(size_t)sample] && depth < 8)
+        col = still_of(h, h->col_sample[(size_t)sample], depth + 1);
+    covahip_h264::Still mine;
+    if (sl[0].nal_ref_idc != 0) mine = std::make_shared<std::vector<uint16_t>>((size_t)h->sps.width_mbs * h->sps.height_map_units, 0);
+    const int rc2 = decode_slice_records(h, h->data + sl[0].nal_offset, sl[0], records, cap, col ? col->data() : nullptr,
+                                         mine ? mine->data() : nullptr);
+    if (rc2 == COVAHIP_OK && mine) {
+        std::lock_guard<std::mutex> lock(h->still_mu);
+        if (!h->still_cache.count(sample)) {
+            h->still_cache[sample] = mine;
+            h->still_order.push_back(sample);
+            if (h->still_order.size() > 24) {   // a reference picture serves the B pictures up to the next one: a handful is plenty
+                h->still_cache.erase(h->still_order.front());
+                h->still_order.erase(h->still_order.begin());
+            }
+        }
+    }
+    return rc2;
+}
+covahip_h264::Still still_of(const covahip_h264 *h, int sample, int depth) {
+    {
+        std::lock_guard<std::mutex> lock(h->still_mu);
+        auto it = h->still_cache.find(sample);
+        if (it != h->still_cache.end()) return it->second;
+    }
+    if (decode_sample(h, sample, nullptr, 0, depth) != COVAHIP_OK) return nullptr;
+    std::lock_guard<std::mutex> lock(h->still_mu);
+    auto it = h->still_cache.find(sample);
+    return it != h->still_cache.end() ? it->second : nullptr;
 }
 
 }  // namespace
@@ -513,18 +722,21 @@ int covahip_h264_sample(const covahip_h264 *h, int sample, uint64_t *offset, uin
 int covahip_h264_sample_slices(const covahip_h264 *h, int sample, covahip_h264_slice *out, int cap, int *n) {
     if (!h || !n || sample < 0 || sample >= (int)h->samples.size() || (!out && cap)) return COVAHIP_ERR_INVALID_ARG;
     const Sample &s = h->samples[sample];
-    return au_slices(h, h->data + s.off, s.size, s.off, out, cap, n);
+    return au_slices(h, h->data + s.off, s.size, s.off, out, cap, n, nullptr);
 }
 
 int covahip_h264_decode_records(const covahip_h264 *h, int sample, uint8_t *records, size_t cap) {
     if (!h || sample < 0 || sample >= (int)h->samples.size()) return COVAHIP_ERR_INVALID_ARG;
     if (records && cap < (size_t)h->sps.width_mbs * h->sps.height_map_units * 4) return COVAHIP_ERR_OVERFLOW;
-    covahip_h264_slice sl[2];
-    int n = 0;
-    const int rc = covahip_h264_sample_slices(h, sample, sl, 2, &n);
-    if (rc == COVAHIP_ERR_OVERFLOW || (rc == COVAHIP_OK && n != 1)) return COVAHIP_ERR_UNSUPPORTED;   // several slices per picture
-    if (rc) return rc;
-    return decode_slice_records(h, h->data + sl[0].nal_offset, sl[0], records, cap);
+    return decode_sample(h, sample, records, cap, 0);
+}
+
+int covahip_h264_colocated(const covahip_h264 *h, int sample, int *col_sample, int *short_term) {
+    if (!h || sample < 0 || sample >= (int)h->samples.size() || !col_sample || !short_term) return COVAHIP_ERR_INVALID_ARG;
+    if (h->col_sample.size() != h->samples.size()) return COVAHIP_ERR_UNSUPPORTED;
+    *col_sample = h->col_sample[(size_t)sample];
+    *short_term = h->col_short[(size_t)sample];
+    return COVAHIP_OK;
 }
 
 int covahip_h264_open_avcc(const uint8_t *avcc, size_t len, covahip_h264 **out) {
@@ -543,8 +755,9 @@ int covahip_h264_decode_au(covahip_h264 *h, const uint8_t *au, size_t len, uint8
     if (!h || !au) return COVAHIP_ERR_INVALID_ARG;
     if (records && cap < (size_t)h->sps.width_mbs * h->sps.height_map_units * 4) return COVAHIP_ERR_OVERFLOW;
     covahip_h264_slice sl[2];
+    SliceExt ext;
     int n = 0;
-    const int rc = au_slices(h, au, len, 0, sl, 2, &n);
+    const int rc = au_slices(h, au, len, 0, sl, 2, &n, &ext);
     if (rc == COVAHIP_ERR_OVERFLOW || (rc == COVAHIP_OK && n != 1)) return COVAHIP_ERR_UNSUPPORTED;
     if (rc) return rc;
     int64_t key = 0;
@@ -554,7 +767,31 @@ int covahip_h264_decode_au(covahip_h264 *h, const uint8_t *au, size_t len, uint8
         *order_key = key;
     }
     if (hdr) *hdr = sl[0];
-    return decode_slice_records(h, au + sl[0].nal_offset, sl[0], records, cap);
+    // access units arrive in decoding order: the reference pictures so far give RefPicList1[0] of a B picture, whose "does
+    // not move" bits (kept while the picture is a reference) feed the colZeroFlag test of its direct prediction
+    covahip_h264::Still col, mine;
+    if (have_key && sl[0].slice_type == 1 && sl[0].direct_spatial) {
+        int id = -1;
+        bool st1 = false;
+        if (h->dpb.list1_first(h->sps, sl[0], ext, key, id, st1) && st1) {
+            auto it = h->still_live.find(id);
+            if (it != h->still_live.end()) col = it->second;
+        }
+    }
+    if (have_key && sl[0].nal_ref_idc != 0) mine = std::make_shared<std::vector<uint16_t>>((size_t)h->sps.width_mbs * h->sps.height_map_units, 0);
+    const int rc2 = decode_slice_records(h, au + sl[0].nal_offset, sl[0], records, cap, col ? col->data() : nullptr, mine ? mine->data() : nullptr);
+    if (have_key) {
+        const int id = h->au_count++;
+        if (sl[0].has_mmco5) key = (h->poc.period << 32) + (1ll << 31);
+        h->dpb.mark(h->sps, sl[0], ext, id, key);
+        if (mine && rc2 == COVAHIP_OK) h->still_live[id] = mine;
+        for (auto it = h->still_live.begin(); it != h->still_live.end();) {   // pictures that left the reference set
+            bool live = false;
+            for (const RefPic &r : h->dpb.refs) live = live || r.id == it->first;
+            it = live ? std::next(it) : h->still_live.erase(it);
+        }
+    }
+    return rc2;
 }
 
 int covahip_carrier_write_records(const uint8_t *mb_type, const uint8_t *mv_x, const uint8_t *mv_y, int width_mbs, int height_mbs,

@@ -307,12 +307,16 @@ int covahip_h264_display_order(const covahip_h264 *h, int32_t *samples, int cap,
 /* Entropy-decodes access unit `sample` (decode order) into records u8 [height_mbs][width_mbs][4] (may be NULL: parse only) --
  * the first width_mbs * height_mbs * 4 bytes of the carrier frame.  Byte 0: macroblock class (0 P_Skip / B_Skip, 1 inter 16x16,
  * 2 inter 16x8 / 8x16, 3 inter 8x8, 4 B_Direct_16x16, 5 intra NxN, 6 intra 16x16, 7 I_PCM); bytes 1 / 2: |mean motion vector| of
- * the macroblock, x / y, in quarter pixels (<= 255) -- the standard's prediction (median, P_Skip, spatial direct) plus the coded
- * difference; not done: the colZeroFlag test of direct blocks (no co-located picture is kept) and temporal direct (predicted
- * spatially); byte 3: 0.  What the reference's patched decoder puts into these bytes is not known here (SURVEY.md row A0:
+ * the macroblock, x / y, in quarter pixels (<= 255) -- the standard's prediction (median, P_Skip, spatial direct with the
+ * colZeroFlag test against RefPicList1[0], which is decoded on the way when no earlier call has) plus the coded difference; not
+ * done: temporal direct (direct_spatial 0: predicted spatially, without that test); byte 3: 0.  What the reference's patched decoder puts into these bytes is not known here (SURVEY.md row A0:
  * unpinned); a BlobNet has to be trained on the front end it runs behind.  COVAHIP_OK only if the slice decoded exactly
  * width_mbs * height_mbs macroblocks, ended there with end_of_slice_flag and left only trailing bits. */
 int covahip_h264_decode_records(const covahip_h264 *h, int sample, uint8_t *records, size_t cap);
+/* The co-located picture of a B picture's direct prediction: *col_sample = the sample that is RefPicList1[0] of `sample` (list
+ * initialisation 8.2.4.2.3 + modification 8.2.4.3 over the reference marking 8.2.5 of the access units before it), -1 when
+ * `sample` is not a B picture or has none; *short_term = 1 when that picture is a short-term reference. */
+int covahip_h264_colocated(const covahip_h264 *h, int sample, int *col_sample, int *short_term);
 /* Stream form (what an element in the place of avdec_h264 uses): parameter sets from the AVCDecoderConfigurationRecord (avcC box
  * payload = codec_data of video/x-h264,stream-format=avc caps), then access units IN DECODE ORDER (length-prefixed NAL units).
  * records / cap as covahip_h264_decode_records; hdr (may be NULL) gets the slice header; *order_key (may be NULL) a key whose
