@@ -371,6 +371,14 @@ void b_direct_motion(const SliceCtx &s, int mbx, int mby, int ref_out[2], int mv
 // direct_8x8_inference_flag the co-located block of a quadrant is the macroblock's corner block of that quadrant)
 void direct_fill(const SliceCtx &s, Mb &m, int addr, int mask, const int dr[2], const int dm[2][2]) {
     const unsigned still = (s.sp.col_still && s.sp.direct_spatial) ? s.sp.col_still[addr] : 0u;
+    if (mask == 0xF && (still == 0 || (dr[0] != 0 && dr[1] != 0) || !(dm[0][0] | dm[0][1] | dm[1][0] | dm[1][1]))) {
+        // nothing for the test to change (the usual case: a skipped macroblock of the background predicts a zero vector anyway)
+        for (int list = 0; list < 2; list++) {
+            for (int b8 = 0; b8 < 4; b8++) m.aref[list][b8] = (int8_t)dr[list];
+            if (dr[list] >= 0) fill_mv_all(m, list, dm[list][0], dm[list][1]);
+        }
+        return;
+    }
     for (int b8 = 0; b8 < 4; b8++) {
         if (!((mask >> b8) & 1)) continue;
         const int x0 = 2 * (b8 & 1), y0 = 2 * (b8 >> 1);
@@ -392,12 +400,15 @@ void direct_fill(const SliceCtx &s, Mb &m, int addr, int mask, const int dr[2], 
 uint16_t still_bits(const Mb &m) {
     if (is_intra(m.kind)) return 0;
     uint16_t bits = 0;
-    for (int blk = 0; blk < 16; blk++) {
-        const int b8 = (blk >> 3) * 2 + ((blk & 3) >> 1);
+    for (int b8 = 0; b8 < 4; b8++) {
         const int list = m.aref[0][b8] >= 0 ? 0 : (m.aref[1][b8] >= 0 ? 1 : -1);
         if (list < 0 || m.aref[list][b8] != 0) continue;
-        const int mx = m.mv[list][blk][0], my = m.mv[list][blk][1];
-        if (mx >= -1 && mx <= 1 && my >= -1 && my <= 1) bits |= (uint16_t)(1u << blk);
+        const int x0 = 2 * (b8 & 1), y0 = 2 * (b8 >> 1);
+        for (int k = 0; k < 4; k++) {
+            const int blk = (y0 + (k >> 1)) * 4 + x0 + (k & 1);
+            // both components in -1 .. 1
+            if ((unsigned)(m.mv[list][blk][0] + 1) <= 2u && (unsigned)(m.mv[list][blk][1] + 1) <= 2u) bits |= (uint16_t)(1u << blk);
+        }
     }
     return bits;
 }
@@ -898,7 +909,12 @@ int parse_slice_cabac(const uint8_t *rbsp, size_t len, size_t bit_offset, const 
             return fail(COVAHIP_ERR_BAD_DATA, "macroblock " + std::to_string(addr) + ": " + s.why);
         }
         if (s.c.overrun()) return fail(COVAHIP_ERR_BAD_DATA, "macroblock " + std::to_string(addr) + ": slice data exhausted");
-        if (sp.still_out) sp.still_out[addr] = still_bits(m);
+        if (sp.still_out) {
+            if (skipped && sp.slice_type == 0)   // P_Skip: reference 0 and one vector for all sixteen blocks
+                sp.still_out[addr] = ((unsigned)(m.mv[0][0][0] + 1) <= 2u && (unsigned)(m.mv[0][0][1] + 1) <= 2u) ? 0xFFFF : 0;
+            else
+                sp.still_out[addr] = still_bits(m);
+        }
         if (records) {
             // [macroblock class, |mv_x|, |mv_y|, 0]: see h264_cabac.h for what these are and are not
             int ax, ay;

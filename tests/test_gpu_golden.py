@@ -211,12 +211,14 @@ def test_real_video_records_through_the_hot_path(ctx):
     assert (np.abs(ref_logits[mask != (ref_logits > 0)]) <= atol).all()
     _same_boxes(boxes, counts, *ref.regionprops_batch(mask, 1, 512))
     # P pictures carry the motion (B pictures of this stream are almost entirely skipped / direct): while the vehicle is in the scene
-    # (the first 25 pictures) every P picture has a blob of >= 12 macroblocks
+    # (the first 21 pictures) every picture with content of its own -- this 60 Hz stream repeats every frame once, the repeats are
+    # B pictures without a vector -- has a blob of >= 20 macroblocks
     big = [int(boxes[i, :counts[i]]["area_px"].max()) if counts[i] else 0 for i in range(len(counts))]
-    assert sum(a >= 12 for a in big) >= 12 and all(a >= 12 for a in big[0:25:2])
-    # ... and where the blob is, the stream's own motion bytes are large
+    assert sum(a >= 12 for a in big) >= 11 and all(a >= 20 for a in big[0:21:2])
+    # ... and where the blob is, the stream's own motion bytes are large (a third of the box's macroblocks move by a pixel or more;
+    # 0.5 % of the picture's do)
     i = int(np.argmax(big))
     b = boxes[i, :counts[i]][int(np.argmax(boxes[i, :counts[i]]["area_px"]))]
     cur = frames[i + 3]
     inside = cur[b["top"]:b["top"] + b["height"], b["left"]:b["left"] + b["width"], 1:3].max(axis=-1)
-    assert np.median(inside) >= 4
+    assert (inside >= 4).mean() >= 0.3
