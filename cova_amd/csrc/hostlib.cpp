@@ -235,31 +235,20 @@ struct Mat7 {
 };
 
 // x' = F x with F = I + (x0 += x4, x1 += x5, x2 += x6)  (motion_model.rs:38-45,
-// nalgebra from_vec is column-major, so the literal is F transposed on the page).
+// nalgebra from_vec is column-major, so the literal is F transposed on the page); P' = F P F^T + Q.
+// The products are written out over F's non-zero entries in the order the dense row x column sums visit them (k ascending:
+// the diagonal 1, then the 1 at column k + 4 for the first three rows): a product with a zero entry adds +-0 and one with a 1
+// is exact, so the results are those of the dense 7x7x7 products bit for bit -- at 49 + 49 additions instead of 686
+// multiply-adds (SORT at the experiment's parameters updates dozens of young trackers per frame and stream).
 void kalman_predict(const P x[7], const Mat7 &Pm, P xo[7], Mat7 &Po) {
     static const P Q[7] = {1.f, 1.f, 1.f, 1.f, 0.01f, 0.01f, 0.0001f};  // motion_model.rs:48-55
-    P F[7][7];
-    for (int i = 0; i < 7; i++)
-        for (int j = 0; j < 7; j++) F[i][j] = (i == j) ? 1.f : 0.f;
-    F[0][4] = 1.f;
-    F[1][5] = 1.f;
-    F[2][6] = 1.f;
-    for (int i = 0; i < 7; i++) {
-        P a = 0.f;
-        for (int k = 0; k < 7; k++) a += F[i][k] * x[k];
-        xo[i] = a;
-    }
+    for (int i = 0; i < 7; i++) xo[i] = i < 3 ? (0.f + x[i]) + x[i + 4] : 0.f + x[i];
     P FP[7][7];
     for (int i = 0; i < 7; i++)
-        for (int j = 0; j < 7; j++) {
-            P a = 0.f;
-            for (int k = 0; k < 7; k++) a += F[i][k] * Pm.m[k][j];
-            FP[i][j] = a;
-        }
+        for (int j = 0; j < 7; j++) FP[i][j] = i < 3 ? (0.f + Pm.m[i][j]) + Pm.m[i + 4][j] : 0.f + Pm.m[i][j];
     for (int i = 0; i < 7; i++)
         for (int j = 0; j < 7; j++) {
-            P a = 0.f;
-            for (int k = 0; k < 7; k++) a += FP[i][k] * F[j][k];  // * F^T
+            const P a = j < 3 ? (0.f + FP[i][j]) + FP[i][j + 4] : 0.f + FP[i][j];   // * F^T
             Po.m[i][j] = a + (i == j ? Q[i] : 0.f);
         }
 }
@@ -267,6 +256,8 @@ void kalman_predict(const P x[7], const Mat7 &Pm, P xo[7], Mat7 &Po) {
 // adskalman ObservationModel::update, CovarianceUpdateMethod::JosephForm, with
 // H = [I4 0] (linear_observation_model.rs:33-40), R = diag(1,1,10,10) (:43-47).
 // Returns false when S is not positive definite (adskalman returns Err).
+// A = I - K H differs from the identity in its first four columns only: the sums over k stop at 4 and pick up the one
+// remaining unit entry at its place in the k order (same values as the dense sums, see kalman_predict).
 bool kalman_update(const P xp[7], const Mat7 &Pp, const P z[4], P xo[7], Mat7 &Po) {
     static const P R[4] = {1.f, 1.f, 10.f, 10.f};
     // S = H P H^T + R = P[0:4,0:4] + R
@@ -319,22 +310,27 @@ bool kalman_update(const P xp[7], const Mat7 &Pp, const P z[4], P xo[7], Mat7 &P
         xo[i] = xp[i] + a;
     }
     // (I - K H) P (I - K H)^T + K R K^T
-    P A[7][7];
+    P A4[7][4];   // the first four columns of A = I - K H; columns 4..6 are the identity's
     for (int i = 0; i < 7; i++)
-        for (int j = 0; j < 7; j++) A[i][j] = (i == j ? 1.f : 0.f) - (j < 4 ? K[i][j] : 0.f);
+        for (int j = 0; j < 4; j++) A4[i][j] = (i == j ? 1.f : 0.f) - K[i][j];
     P AP[7][7];
     for (int i = 0; i < 7; i++)
         for (int j = 0; j < 7; j++) {
             P a = 0.f;
-            for (int k = 0; k < 7; k++) a += A[i][k] * Pp.m[k][j];
+            for (int k = 0; k < 4; k++) a += A4[i][k] * Pp.m[k][j];
+            if (i >= 4) a += Pp.m[i][j];
             AP[i][j] = a;
         }
+    P KR[7][4];
+    for (int i = 0; i < 7; i++)
+        for (int k = 0; k < 4; k++) KR[i][k] = K[i][k] * R[k];
     for (int i = 0; i < 7; i++)
         for (int j = 0; j < 7; j++) {
             P a = 0.f;
-            for (int k = 0; k < 7; k++) a += AP[i][k] * A[j][k];
+            for (int k = 0; k < 4; k++) a += AP[i][k] * A4[j][k];
+            if (j >= 4) a += AP[i][j];
             P b = 0.f;
-            for (int k = 0; k < 4; k++) b += K[i][k] * R[k] * K[j][k];
+            for (int k = 0; k < 4; k++) b += KR[i][k] * K[j][k];
             Po.m[i][j] = a + b;
         }
     return true;
