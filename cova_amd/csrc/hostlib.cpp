@@ -550,19 +550,21 @@ struct Sort {  // sort/src/lib.rs:14-23
             if (!trackers[i].update(det)) return false;
         }
         for (auto &t : trackers) t.check_activate(min_hits);
-        std::vector<Tracker> keep;
-        keep.reserve(trackers.size());
-        for (auto &t : trackers) {
+        // retain (lib.rs:166-177) in place: nothing moves in the usual frame in which no tracker dies
+        size_t w = 0;
+        for (size_t i = 0; i < trackers.size(); i++) {
+            Tracker &t = trackers[i];
             if (!t.should_live(max_age)) {
                 if (t.active) {
                     t.trim_dead_history();
                     dead.push_back(std::move(t));
                 }
             } else {
-                keep.push_back(std::move(t));
+                if (w != i) trackers[w] = std::move(t);
+                w++;
             }
         }
-        trackers.swap(keep);
+        trackers.erase(trackers.begin() + (long)w, trackers.end());
         for (size_t j : unmatched) {
             trackers.emplace_back(id_counter, dets[j], pts);
             id_counter += 1;
