@@ -113,23 +113,40 @@ def committed_traffic(kernel, entry="stack"):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baselines
+def cpu_quota(text: str):
+    """CPUs granted by a cgroup v2 `cpu.max` line ("<quota> <period>" or "max <period>"): None when unlimited or unreadable."""
+    try:
+        quota, period = text.split()[:2]
+        if quota == "max" or int(quota) <= 0 or int(period) <= 0:
+            return None
+        return max(1, int(quota) // int(period))
+    except (ValueError, IndexError):
+        return None
+
+
 def effective_cores() -> int:
-    """CPUs this process may actually use: the smaller of the affinity mask and the cgroup's CPU quota (a GPU box shows
-    all 256 hardware threads to os.cpu_count() but grants a share of them -- /sys/fs/cgroup/cpu.max "1600000 100000" = 16;
-    OpenMP on 256 threads under that quota spends its time being throttled)."""
+    """CPUs this process may actually use: the smallest of os.cpu_count(), the affinity mask and the cgroup's CPU quota (a GPU
+    box shows all 256 hardware threads to os.cpu_count() but grants a share of them -- /sys/fs/cgroup/cpu.max "1600000 100000"
+    = 16; OpenMP on 256 threads under that quota spends its time being throttled)."""
     n = os.cpu_count() or 1
     try:
         n = min(n, len(os.sched_getaffinity(0)))
     except (AttributeError, OSError):
         pass
-    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
-                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()])):
-        try:
-            quota, period = parse(open(path).read())
-            if quota != "max" and int(quota) > 0:
-                n = min(n, max(1, int(quota) // int(period)))
-        except (OSError, ValueError, IndexError):
-            pass
+    texts = []
+    try:
+        texts.append(open("/sys/fs/cgroup/cpu.max").read())                                   # cgroup v2
+    except OSError:
+        pass
+    try:
+        texts.append(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read().strip() + " " +
+                     open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip())            # cgroup v1
+    except OSError:
+        pass
+    for t in texts:
+        q = cpu_quota(t)
+        if q:
+            n = min(n, q)
     return max(1, n)
 
 
