@@ -348,8 +348,8 @@ void p_skip_motion(const SliceCtx &s, int mbx, int mby, Mb &m) {
     fill_mv_all(m, 0, mx, my);
 }
 // B_Skip / B_Direct_16x16 / direct sub-blocks, spatial direct mode (8.4.1.2.2): reference indices and predicted vectors from the
-// macroblock's own neighbours; direct_fill applies them per 8x8 block with the colZeroFlag test.  Temporal direct slices take this
-// path too (stated gap).
+// macroblock's own neighbours; direct_fill applies them per 8x8 block with the colZeroFlag test.  (Temporal direct slices: temporal_fill;
+// they come here only when the caller has no co-located motion for them.)
 void b_direct_motion(const SliceCtx &s, int mbx, int mby, int ref_out[2], int mv_out[2][2]) {
     const MbNb nb = mb_neighbours(s, mbx, mby);
     Nb A[2], B[2], C[2];
@@ -396,6 +396,50 @@ void direct_fill(const SliceCtx &s, Mb &m, int addr, int mask, const int dr[2], 
         }
     }
 }
+// Temporal direct prediction (8.4.1.2.3) of the 8x8 blocks in `mask`: reference index 0 of list 1, the list-0 index of the picture
+// the co-located block refers to, the co-located vector scaled by the ratio of the picture order count distances.
+bool temporal_direct(const SliceCtx &s) {
+    return !s.sp.direct_spatial && s.sp.direct_8x8_inference && s.sp.col_motion && s.sp.col_to_l0 && s.sp.dist_scale;
+}
+void temporal_fill(const SliceCtx &s, Mb &m, int addr, int mask) {
+    const ColMb &col = s.sp.col_motion[addr];
+    for (int b8 = 0; b8 < 4; b8++) {
+        if (!((mask >> b8) & 1)) continue;
+        int ref0 = 0, mv0[2] = {0, 0}, mv1[2] = {0, 0};
+        if (col.ref[b8] >= 0) {
+            const int mapped = s.sp.col_to_l0[(col.list[b8] & 1) * 32 + (col.ref[b8] & 31)];
+            ref0 = mapped < 0 ? 0 : mapped;
+            const int dsf = s.sp.dist_scale[ref0 & 31];
+            for (int k = 0; k < 2; k++) {
+                const int mc = col.mv[b8][k];
+                if (dsf == DIST_SCALE_NONE) { mv0[k] = mc; mv1[k] = 0; }
+                else { mv0[k] = (dsf * mc + 128) >> 8; mv1[k] = mv0[k] - mc; }
+            }
+        }
+        m.aref[0][b8] = (int8_t)ref0;
+        m.aref[1][b8] = 0;
+        const int x0 = 2 * (b8 & 1), y0 = 2 * (b8 >> 1);
+        for (int k = 0; k < 4; k++) {
+            const int blk = (y0 + (k >> 1)) * 4 + x0 + (k & 1);
+            m.mv[0][blk][0] = (int16_t)mv0[0]; m.mv[0][blk][1] = (int16_t)mv0[1];
+            m.mv[1][blk][0] = (int16_t)mv1[0]; m.mv[1][blk][1] = (int16_t)mv1[1];
+        }
+    }
+}
+// this macroblock's entry of SliceParams::motion_out
+ColMb col_motion_of(const Mb &m) {
+    ColMb c;
+    for (int b8 = 0; b8 < 4; b8++) {
+        const int blk = (b8 >> 1 ? 12 : 0) + (b8 & 1 ? 3 : 0);   // the quadrant's corner block
+        const int list = is_intra(m.kind) ? -1 : (m.aref[0][b8] >= 0 ? 0 : (m.aref[1][b8] >= 0 ? 1 : -1));
+        c.ref[b8] = (int8_t)(list < 0 ? -1 : m.aref[list][b8]);
+        c.list[b8] = (uint8_t)(list < 0 ? 0 : list);
+        c.mv[b8][0] = list < 0 ? 0 : m.mv[list][blk][0];
+        c.mv[b8][1] = list < 0 ? 0 : m.mv[list][blk][1];
+    }
+    return c;
+}
+
 // "does not move" bits of a decoded macroblock (SliceParams::still_out)
 uint16_t still_bits(const Mb &m) {
     if (is_intra(m.kind)) return 0;
@@ -664,8 +708,12 @@ bool macroblock(SliceCtx &s, int mbx, int mby, Mb &m, MbOut &out) {
         m.direct8 = 0xF;
         {
             int dr[2], dm[2][2];
-            b_direct_motion(s, mbx, mby, dr, dm);
-            direct_fill(s, m, mby * s.W + mbx, 0xF, dr, dm);
+            if (temporal_direct(s)) {
+                temporal_fill(s, m, mby * s.W + mbx, 0xF);
+            } else {
+                b_direct_motion(s, mbx, mby, dr, dm);
+                direct_fill(s, m, mby * s.W + mbx, 0xF, dr, dm);
+            }
         }
         dct8_ok = dct8_ok && sp.direct_8x8_inference;
     } else {
@@ -694,8 +742,12 @@ bool macroblock(SliceCtx &s, int mbx, int mby, Mb &m, MbOut &out) {
         }
         if (m.direct8) {   // direct sub-blocks: the macroblock's own neighbours decide (8.4.1.2.2), before anything else of this macroblock
             int dr[2], dm[2][2];
-            b_direct_motion(s, mbx, mby, dr, dm);
-            direct_fill(s, m, mby * s.W + mbx, m.direct8, dr, dm);
+            if (temporal_direct(s)) {
+                temporal_fill(s, m, mby * s.W + mbx, m.direct8);
+            } else {
+                b_direct_motion(s, mbx, mby, dr, dm);
+                direct_fill(s, m, mby * s.W + mbx, m.direct8, dr, dm);
+            }
         }
         const int nref[2] = {sp.num_ref_l0, sp.num_ref_l1};
         // neighbour lookups on the 4x4 grid, across the macroblock border
@@ -898,8 +950,12 @@ int parse_slice_cabac(const uint8_t *rbsp, size_t len, size_t bit_offset, const 
                 p_skip_motion(s, x, y, m);
             } else {
                 int dr[2], dm[2][2];
-                b_direct_motion(s, x, y, dr, dm);
-                direct_fill(s, m, addr, 0xF, dr, dm);
+                if (temporal_direct(s)) {
+                    temporal_fill(s, m, addr, 0xF);
+                } else {
+                    b_direct_motion(s, x, y, dr, dm);
+                    direct_fill(s, m, addr, 0xF, dr, dm);
+                }
             }
             m.kind = K_SKIP;
             m.direct8 = sp.slice_type == 1 ? 0xF : 0;
@@ -909,6 +965,7 @@ int parse_slice_cabac(const uint8_t *rbsp, size_t len, size_t bit_offset, const 
             return fail(COVAHIP_ERR_BAD_DATA, "macroblock " + std::to_string(addr) + ": " + s.why);
         }
         if (s.c.overrun()) return fail(COVAHIP_ERR_BAD_DATA, "macroblock " + std::to_string(addr) + ": slice data exhausted");
+        if (sp.motion_out) sp.motion_out[addr] = col_motion_of(m);
         if (sp.still_out) {
             if (skipped && sp.slice_type == 0)   // P_Skip: reference 0 and one vector for all sixteen blocks
                 sp.still_out[addr] = ((unsigned)(m.mv[0][0][0] + 1) <= 2u && (unsigned)(m.mv[0][0][1] + 1) <= 2u) ? 0xFFFF : 0;

@@ -156,7 +156,7 @@ struct Sample { uint64_t off; uint32_t size; bool sync; };
 struct RplOp { int idc; uint32_t val; };
 struct Mmco { int op; uint32_t a, b; };
 struct SliceExt {
-    std::vector<RplOp> l1;
+    std::vector<RplOp> l0, l1;
     std::vector<Mmco> mmco;
     bool adaptive = false, long_term_reference = false;
 };
@@ -166,47 +166,72 @@ struct SliceExt {
 struct RefPic { int id; int frame_num; int64_t key; bool lt; int lt_idx; };
 struct Dpb {
     std::vector<RefPic> refs;
-    // RefPicList1[0] of the B picture described by (sl, ext, key), before it is decoded.  false: no such picture.
-    bool list1_first(const Sps &sp, const covahip_h264_slice &sl, const SliceExt &ext, int64_t key, int &id, bool &short_term) const {
+    // RefPicList0 / RefPicList1 of the P or B picture described by (sl, ext, key), before it is decoded: indices into `refs`,
+    // -1 where the list has no picture (8.2.4.2.1 / 8.2.4.2.3 initialisation, 8.2.4.3 modification; frames only)
+    void build_lists(const Sps &sp, const covahip_h264_slice &sl, const SliceExt &ext, int64_t key, std::vector<int> &l0,
+                     std::vector<int> &l1) const {
         const int max_fn = 1 << sp.log2_max_frame_num;
         auto pic_num = [&](const RefPic &r) { return r.frame_num > sl.frame_num ? r.frame_num - max_fn : r.frame_num; };
-        std::vector<int> before, after, lt;
-        for (int i = 0; i < (int)refs.size(); i++) (refs[i].lt ? lt : (refs[i].key < key ? before : after)).push_back(i);
-        std::sort(before.begin(), before.end(), [&](int a, int b) { return refs[a].key > refs[b].key; });
-        std::sort(after.begin(), after.end(), [&](int a, int b) { return refs[a].key < refs[b].key; });
+        std::vector<int> lt;
+        for (int i = 0; i < (int)refs.size(); i++)
+            if (refs[i].lt) lt.push_back(i);
         std::sort(lt.begin(), lt.end(), [&](int a, int b) { return refs[a].lt_idx < refs[b].lt_idx; });
-        std::vector<int> l0 = before, l1 = after;
-        l0.insert(l0.end(), after.begin(), after.end());
-        l1.insert(l1.end(), before.begin(), before.end());
-        l0.insert(l0.end(), lt.begin(), lt.end());
-        l1.insert(l1.end(), lt.begin(), lt.end());
-        if (l1.size() > 1 && l1 == l0) std::swap(l1[0], l1[1]);
-        const size_t n1 = (size_t)std::max(1, sl.num_ref_l1);
-        l1.resize(n1, -1);
-        size_t at = 0;
-        int pred = sl.frame_num;   // CurrPicNum (frames)
-        for (const RplOp &op : ext.l1) {
-            int pick = -1;
-            if (op.idc == 0 || op.idc == 1) {
-                const int64_t d = (int64_t)op.val + 1;   // (a damaged header may carry any 32-bit value)
-                int64_t nw = op.idc == 0 ? (int64_t)pred - d : (int64_t)pred + d;
-                nw = ((nw % max_fn) + max_fn) % max_fn;
-                const int nowrap = (int)nw;
-                pred = nowrap;
-                const int pn = nowrap > sl.frame_num ? nowrap - max_fn : nowrap;
-                for (int i = 0; i < (int)refs.size(); i++)
-                    if (!refs[i].lt && pic_num(refs[i]) == pn) pick = i;
-            } else if (op.idc == 2) {
-                for (int i = 0; i < (int)refs.size(); i++)
-                    if (refs[i].lt && refs[i].lt_idx == (int)op.val) pick = i;
-            }
-            if (pick < 0 || at >= n1) continue;   // a command that names no reference picture: ignored
-            l1.insert(l1.begin() + (long)at, pick);
-            at++;
-            for (size_t k = at; k < l1.size(); k++)
-                if (l1[k] == pick) { l1.erase(l1.begin() + (long)k); break; }
-            l1.resize(n1, -1);
+        l0.clear();
+        l1.clear();
+        if (sl.slice_type == 1) {
+            std::vector<int> before, after;
+            for (int i = 0; i < (int)refs.size(); i++)
+                if (!refs[i].lt) (refs[i].key < key ? before : after).push_back(i);
+            std::sort(before.begin(), before.end(), [&](int a, int b) { return refs[a].key > refs[b].key; });
+            std::sort(after.begin(), after.end(), [&](int a, int b) { return refs[a].key < refs[b].key; });
+            l0 = before;
+            l1 = after;
+            l0.insert(l0.end(), after.begin(), after.end());
+            l1.insert(l1.end(), before.begin(), before.end());
+            l0.insert(l0.end(), lt.begin(), lt.end());
+            l1.insert(l1.end(), lt.begin(), lt.end());
+            if (l1.size() > 1 && l1 == l0) std::swap(l1[0], l1[1]);
+        } else {
+            for (int i = 0; i < (int)refs.size(); i++)
+                if (!refs[i].lt) l0.push_back(i);
+            std::sort(l0.begin(), l0.end(), [&](int a, int b) { return pic_num(refs[a]) > pic_num(refs[b]); });
+            l0.insert(l0.end(), lt.begin(), lt.end());
         }
+        auto modify = [&](std::vector<int> &l, const std::vector<RplOp> &ops, int n_active) {
+            const size_t n = (size_t)std::max(1, n_active);
+            l.resize(n, -1);
+            size_t at = 0;
+            int pred = sl.frame_num;   // CurrPicNum (frames)
+            for (const RplOp &op : ops) {
+                int pick = -1;
+                if (op.idc == 0 || op.idc == 1) {
+                    const int64_t d = (int64_t)op.val + 1;   // (a damaged header may carry any 32-bit value)
+                    int64_t nw = op.idc == 0 ? (int64_t)pred - d : (int64_t)pred + d;
+                    nw = ((nw % max_fn) + max_fn) % max_fn;
+                    const int nowrap = (int)nw;
+                    pred = nowrap;
+                    const int pn = nowrap > sl.frame_num ? nowrap - max_fn : nowrap;
+                    for (int i = 0; i < (int)refs.size(); i++)
+                        if (!refs[i].lt && pic_num(refs[i]) == pn) pick = i;
+                } else if (op.idc == 2) {
+                    for (int i = 0; i < (int)refs.size(); i++)
+                        if (refs[i].lt && refs[i].lt_idx == (int)op.val) pick = i;
+                }
+                if (pick < 0 || at >= n) continue;   // a command that names no reference picture: ignored
+                l.insert(l.begin() + (long)at, pick);
+                at++;
+                for (size_t k = at; k < l.size(); k++)
+                    if (l[k] == pick) { l.erase(l.begin() + (long)k); break; }
+                l.resize(n, -1);
+            }
+        };
+        modify(l0, ext.l0, sl.num_ref_l0);
+        if (sl.slice_type == 1) modify(l1, ext.l1, sl.num_ref_l1);
+    }
+    // RefPicList1[0] of a B picture.  false: no such picture.
+    bool list1_first(const Sps &sp, const covahip_h264_slice &sl, const SliceExt &ext, int64_t key, int &id, bool &short_term) const {
+        std::vector<int> l0, l1;
+        build_lists(sp, sl, ext, key, l0, l1);
         if (l1.empty() || l1[0] < 0) return false;
         id = refs[(size_t)l1[0]].id;
         short_term = !refs[(size_t)l1[0]].lt;
@@ -268,6 +293,38 @@ struct Dpb {
     }
 };
 
+// One entry of a reference picture list as later pictures need it: which picture (caller's id, -1: none), its picture order
+// count key, long-term or not
+struct RefEntry { int32_t id; int64_t key; bool lt; };
+void list_entries(const Dpb &dpb, const std::vector<int> &l, std::vector<RefEntry> &out) {
+    out.clear();
+    for (int i : l) out.push_back(i < 0 ? RefEntry{-1, 0, false} : RefEntry{dpb.refs[(size_t)i].id, dpb.refs[(size_t)i].key, dpb.refs[(size_t)i].lt});
+}
+// Temporal direct (8.4.1.2.3): for every entry of the co-located picture's lists the lowest index in the current list 0 that
+// names the same picture, and DistScaleFactor of every current list-0 index against RefPicList1[0]
+void temporal_tables(const std::vector<RefEntry> &l0, const std::vector<RefEntry> &l1, int64_t key, const std::vector<RefEntry> &col_l0,
+                     const std::vector<RefEntry> &col_l1, int8_t col_to_l0[64], int16_t dist_scale[32]) {
+    auto clip3 = [](int64_t lo, int64_t hi, int64_t v) { return v < lo ? lo : (v > hi ? hi : v); };
+    for (int list = 0; list < 2; list++) {
+        const std::vector<RefEntry> &cl = list ? col_l1 : col_l0;
+        for (int i = 0; i < 32; i++) {
+            int8_t m = -1;
+            if (i < (int)cl.size() && cl[(size_t)i].id >= 0)
+                for (int j = 0; j < (int)l0.size() && j < 32; j++)
+                    if (l0[(size_t)j].id == cl[(size_t)i].id) { m = (int8_t)j; break; }
+            col_to_l0[list * 32 + i] = m;
+        }
+    }
+    for (int i = 0; i < 32; i++) {
+        dist_scale[i] = h264::DIST_SCALE_NONE;
+        if (i >= (int)l0.size() || l0[(size_t)i].id < 0 || l0[(size_t)i].lt || l1.empty() || l1[0].id < 0) continue;
+        const int64_t tb = clip3(-128, 127, key - l0[(size_t)i].key), td = clip3(-128, 127, l1[0].key - l0[(size_t)i].key);
+        if (td == 0) continue;
+        const int64_t tx = (16384 + (td < 0 ? -td : td) / 2) / td;
+        dist_scale[i] = (int16_t)clip3(-1024, 1023, (tb * tx + 32) >> 6);
+    }
+}
+
 uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 uint64_t be64(const uint8_t *p) { return ((uint64_t)be32(p) << 32) | be32(p + 4); }
 
@@ -283,12 +340,19 @@ struct covahip_h264 {
     std::vector<int64_t> order_key;     // per sample: (IDR period << 32) + picture order count + 2^31; empty when not computable
     std::vector<int32_t> display;       // sample indices in output order
     struct PocState { int64_t prev_msb = 0, prev_lsb = 0, period = -1, fn_off = 0, prev_fn = 0; } poc;   // stream form (covahip_h264_decode_au)
-    // colZeroFlag (8.4.1.2.2): per picture the "does not move" bits of its macroblocks (h264_cabac.h, SliceParams::col_still)
-    typedef std::shared_ptr<std::vector<uint16_t>> Still;
+    // What direct prediction needs of a reference picture (h264_cabac.h): the "does not move" bits of its macroblocks (colZeroFlag,
+    // 8.4.1.2.2), the motion of their corner blocks and the pictures its own lists named (temporal direct, 8.4.1.2.3)
+    struct PicMotion {
+        std::vector<uint16_t> still;
+        std::vector<h264::ColMb> motion;
+        std::vector<RefEntry> l0, l1;
+    };
+    typedef std::shared_ptr<PicMotion> Still;
     // file form: per sample the sample that is its RefPicList1[0] (-1: none / not B) and whether that is a short-term picture
     // (from a pass over the slice headers at open); bits of decoded reference pictures are kept for the B pictures that follow
     std::vector<int32_t> col_sample;
     std::vector<uint8_t> col_short;
+    std::vector<std::vector<RefEntry>> lists0, lists1;   // per sample: its reference picture lists (empty for I pictures)
     mutable std::mutex still_mu;
     mutable std::map<int, Still> still_cache;
     mutable std::vector<int> still_order;   // insertion order, oldest first
@@ -362,7 +426,7 @@ int parse_slice_header(const covahip_h264 *h, const uint8_t *nal, size_t n, cova
                     op = r.ue();
                     if (op == 0 || op == 1 || op == 2) {
                         const uint32_t v = r.ue();
-                        if (ext && list == 1) ext->l1.push_back(RplOp{(int)op, v});
+                        if (ext) (list == 0 ? ext->l0 : ext->l1).push_back(RplOp{(int)op, v});
                     }
                 } while (op != 3 && !r.bad);
             }
@@ -458,6 +522,8 @@ void compute_display_order(covahip_h264 *h) {
     h->order_key.assign(n, 0);
     h->col_sample.assign(n, -1);
     h->col_short.assign(n, 0);
+    h->lists0.assign(n, {});
+    h->lists1.assign(n, {});
     covahip_h264::PocState st;
     Dpb dpb;
     for (size_t i = 0; i < n; i++) {
@@ -469,14 +535,21 @@ void compute_display_order(covahip_h264 *h) {
         if ((rc != COVAHIP_OK && rc != COVAHIP_ERR_OVERFLOW) || cnt < 1 || !poc_step(h->sps, st, sl[0], h->order_key[i])) {
             h->order_key.clear();
             h->col_sample.assign(n, -1);
+            h->lists0.assign(n, {});
+            h->lists1.assign(n, {});
             return;
         }
         // RefPicList1[0] of a B picture (the co-located picture of its direct prediction), then the marking of this picture
         int64_t key = h->order_key[i];
-        if (sl[0].slice_type == 1) {
-            int id = -1;
-            bool st1 = false;
-            if (dpb.list1_first(h->sps, sl[0], ext, key, id, st1)) { h->col_sample[i] = id; h->col_short[i] = st1 ? 1 : 0; }
+        if (sl[0].slice_type == 0 || sl[0].slice_type == 1) {
+            std::vector<int> l0, l1;
+            dpb.build_lists(h->sps, sl[0], ext, key, l0, l1);
+            list_entries(dpb, l0, h->lists0[i]);
+            list_entries(dpb, l1, h->lists1[i]);
+            if (sl[0].slice_type == 1 && !h->lists1[i].empty() && h->lists1[i][0].id >= 0) {
+                h->col_sample[i] = h->lists1[i][0].id;
+                h->col_short[i] = h->lists1[i][0].lt ? 0 : 1;
+            }
         }
         if (sl[0].has_mmco5) key = (st.period << 32) + (1ll << 31);   // tempPicOrderCnt subtracted: the picture's own count becomes 0
         dpb.mark(h->sps, sl[0], ext, (int)i, key);
@@ -540,8 +613,11 @@ int parse_avcc(covahip_h264 *h, const uint8_t *a, size_t n) {
 }
 
 // Entropy-decodes the single whole-picture slice `sl` whose NAL unit starts at nal.
+// col: the motion of RefPicList1[0] (NULL: not known / long-term / not a B slice); l0, l1, key: this picture's lists and count
+// (temporal direct); mine (may be NULL) receives this picture's motion for the pictures after it.
 int decode_slice_records(const covahip_h264 *h, const uint8_t *nal, const covahip_h264_slice &sl, uint8_t *records, size_t cap,
-                         const uint16_t *col_still = nullptr, uint16_t *still_out = nullptr) {
+                         const covahip_h264::PicMotion *col, const std::vector<RefEntry> *l0, const std::vector<RefEntry> *l1, int64_t key,
+                         covahip_h264::PicMotion *mine) {
     const int wmb = h->sps.width_mbs, hmb = h->sps.height_map_units;
     if (records && cap < (size_t)wmb * hmb * 4) return COVAHIP_ERR_OVERFLOW;
     // CAVLC streams, field / MBAFF coding: not built -- refused, never faked
@@ -561,8 +637,23 @@ int decode_slice_records(const covahip_h264 *h, const uint8_t *nal, const covahi
     sp.direct_8x8_inference = h->sps.direct_8x8;
     sp.chroma_format = h->sps.chroma_format;
     sp.direct_spatial = sl.direct_spatial;
-    sp.col_still = sl.slice_type == 1 ? col_still : nullptr;
-    sp.still_out = still_out;
+    int8_t col_to_l0[64];
+    int16_t dist_scale[32];
+    if (sl.slice_type == 1 && col) {
+        sp.col_still = col->still.data();
+        if (!sl.direct_spatial && l0 && l1) {
+            temporal_tables(*l0, *l1, key, col->l0, col->l1, col_to_l0, dist_scale);
+            sp.col_motion = col->motion.data();
+            sp.col_to_l0 = col_to_l0;
+            sp.dist_scale = dist_scale;
+        }
+    }
+    if (mine) {
+        mine->still.assign((size_t)wmb * hmb, 0);
+        mine->motion.assign((size_t)wmb * hmb, h264::ColMb());
+        sp.still_out = mine->still.data();
+        sp.motion_out = mine->motion.data();
+    }
     std::string why;
     const int rc = h264::parse_slice_cabac(rbsp.data(), rbsp.size(), sl.data_bit_offset, sp, records, &why);
     if (rc && getenv("COVAHIP_H264_DEBUG")) fprintf(stderr, "covahip h264: %s\n", why.c_str());
@@ -578,14 +669,19 @@ int decode_sample(const covahip_h264 *h, int sample, uint8_t *records, size_t ca
     const int rc = covahip_h264_sample_slices(h, sample, sl, 2, &n);
     if (rc == COVAHIP_ERR_OVERFLOW || (rc == COVAHIP_OK && n != 1)) return COVAHIP_ERR_UNSUPPORTED;   // several slices per picture
     if (rc) return rc;
+    const bool tables = (size_t)sample < h->col_sample.size() && h->lists0.size() == h->col_sample.size();
     covahip_h264::Still col;
-    if (sl[0].slice_type == 1 && sl[0].direct_spatial && (size_t)sample < h->col_sample.size() && h->col_sample[(size_t)sample] >= 0 &&
-        h->col_short[(size_t)sample] && depth < 8)
+    if (sl[0].slice_type == 1 && tables && h->col_sample[(size_t)sample] >= 0 && h->col_short[(size_t)sample] && depth < 8)
         col = still_of(h, h->col_sample[(size_t)sample], depth + 1);
     covahip_h264::Still mine;
-    if (sl[0].nal_ref_idc != 0) mine = std::make_shared<std::vector<uint16_t>>((size_t)h->sps.width_mbs * h->sps.height_map_units, 0);
-    const int rc2 = decode_slice_records(h, h->data + sl[0].nal_offset, sl[0], records, cap, col ? col->data() : nullptr,
-                                         mine ? mine->data() : nullptr);
+    if (sl[0].nal_ref_idc != 0 && tables) {
+        mine = std::make_shared<covahip_h264::PicMotion>();
+        mine->l0 = h->lists0[(size_t)sample];
+        mine->l1 = h->lists1[(size_t)sample];
+    }
+    const int rc2 = decode_slice_records(h, h->data + sl[0].nal_offset, sl[0], records, cap, col.get(),
+                                         tables ? &h->lists0[(size_t)sample] : nullptr, tables ? &h->lists1[(size_t)sample] : nullptr,
+                                         tables && !h->order_key.empty() ? h->order_key[(size_t)sample] : 0, mine.get());
     if (rc2 == COVAHIP_OK && mine) {
         std::lock_guard<std::mutex> lock(h->still_mu);
         if (!h->still_cache.count(sample)) {
@@ -770,16 +866,23 @@ int covahip_h264_decode_au(covahip_h264 *h, const uint8_t *au, size_t len, uint8
     // access units arrive in decoding order: the reference pictures so far give RefPicList1[0] of a B picture, whose "does
     // not move" bits (kept while the picture is a reference) feed the colZeroFlag test of its direct prediction
     covahip_h264::Still col, mine;
-    if (have_key && sl[0].slice_type == 1 && sl[0].direct_spatial) {
-        int id = -1;
-        bool st1 = false;
-        if (h->dpb.list1_first(h->sps, sl[0], ext, key, id, st1) && st1) {
-            auto it = h->still_live.find(id);
+    std::vector<RefEntry> l0e, l1e;
+    if (have_key && (sl[0].slice_type == 0 || sl[0].slice_type == 1)) {
+        std::vector<int> l0, l1;
+        h->dpb.build_lists(h->sps, sl[0], ext, key, l0, l1);
+        list_entries(h->dpb, l0, l0e);
+        list_entries(h->dpb, l1, l1e);
+        if (sl[0].slice_type == 1 && !l1e.empty() && l1e[0].id >= 0 && !l1e[0].lt) {
+            auto it = h->still_live.find(l1e[0].id);
             if (it != h->still_live.end()) col = it->second;
         }
     }
-    if (have_key && sl[0].nal_ref_idc != 0) mine = std::make_shared<std::vector<uint16_t>>((size_t)h->sps.width_mbs * h->sps.height_map_units, 0);
-    const int rc2 = decode_slice_records(h, au + sl[0].nal_offset, sl[0], records, cap, col ? col->data() : nullptr, mine ? mine->data() : nullptr);
+    if (have_key && sl[0].nal_ref_idc != 0) {
+        mine = std::make_shared<covahip_h264::PicMotion>();
+        mine->l0 = l0e;
+        mine->l1 = l1e;
+    }
+    const int rc2 = decode_slice_records(h, au + sl[0].nal_offset, sl[0], records, cap, col.get(), &l0e, &l1e, key, mine.get());
     if (have_key) {
         const int id = h->au_count++;
         if (sl[0].has_mmco5) key = (h->poc.period << 32) + (1ll << 31);

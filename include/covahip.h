@@ -308,8 +308,8 @@ int covahip_h264_display_order(const covahip_h264 *h, int32_t *samples, int cap,
  * the first width_mbs * height_mbs * 4 bytes of the carrier frame.  Byte 0: macroblock class (0 P_Skip / B_Skip, 1 inter 16x16,
  * 2 inter 16x8 / 8x16, 3 inter 8x8, 4 B_Direct_16x16, 5 intra NxN, 6 intra 16x16, 7 I_PCM); bytes 1 / 2: |mean motion vector| of
  * the macroblock, x / y, in quarter pixels (<= 255) -- the standard's prediction (median, P_Skip, spatial direct with the
- * colZeroFlag test against RefPicList1[0], which is decoded on the way when no earlier call has) plus the coded difference; not
- * done: temporal direct (direct_spatial 0: predicted spatially, without that test); byte 3: 0.  What the reference's patched decoder puts into these bytes is not known here (SURVEY.md row A0:
+ * colZeroFlag test against RefPicList1[0], temporal direct from that picture's motion; the picture is decoded on the way when no
+ * earlier call has) plus the coded difference; byte 3: 0.  What the reference's patched decoder puts into these bytes is not known here (SURVEY.md row A0:
  * unpinned); a BlobNet has to be trained on the front end it runs behind.  COVAHIP_OK only if the slice decoded exactly
  * width_mbs * height_mbs macroblocks, ended there with end_of_slice_flag and left only trailing bits. */
 int covahip_h264_decode_records(const covahip_h264 *h, int sample, uint8_t *records, size_t cap);

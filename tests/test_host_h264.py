@@ -178,6 +178,35 @@ def test_colocated_picture_of_every_b_picture_is_the_nearest_following_reference
     assert lib.covahip_h264_colocated(h, 1802, C.byref(col), C.byref(short)) != 0
 
 
+def test_temporal_direct_pictures_move_half_as_far_as_the_p_picture_behind_them(demo, decoded):
+    """The first GoP of the stream codes its reference B pictures with temporal direct prediction (direct_spatial 0): their
+    vectors are the co-located P picture's, scaled by the ratio of the picture order count distances (8.4.1.2.3).  Such a B
+    picture sits halfway between two P pictures, so its moving macroblocks are about as many as the following P picture's and
+    move half as far -- which only comes out if the co-located picture, the list-0 mapping and DistScaleFactor are right."""
+    lib, h, _ = demo
+    recs, types = decoded
+    order = np.zeros(1802, np.int32)
+    n = C.c_int()
+    assert lib.covahip_h264_display_order(h, order.ctypes.data, 1802, C.byref(n)) == 0
+    sl = np.zeros(4, dtype=L.H264_SLICE_DTYPE)
+    checked = 0
+    for k in range(1, 24):
+        s = int(order[k])
+        assert lib.covahip_h264_sample_slices(h, s, sl.ctypes.data, 4, C.byref(n)) == 0
+        if not (sl[0]["slice_type"] == 1 and sl[0]["direct_spatial"] == 0 and sl[0]["nal_ref_idc"] != 0):
+            continue
+        nxt = next(int(order[j]) for j in range(k + 1, k + 6) if types[int(order[j])] == 0)      # the P picture behind it
+        mv_b, mv_p = recs[s][..., 1:3].astype(int), recs[nxt][..., 1:3].astype(int)
+        mov_b, mov_p = mv_b.max(axis=-1) >= 4, mv_p.max(axis=-1) >= 4
+        if mov_p.sum() < 50 or mov_b.sum() < 30:     # (the stream repeats frames: the B picture right behind the key frame shows the key frame again)
+            continue
+        assert 0.6 < mov_b.sum() / mov_p.sum() < 1.3
+        ratio = mv_b[mov_b].mean(axis=0) / mv_p[mov_p].mean(axis=0)
+        assert (0.35 < ratio).all() and (ratio < 0.75).all(), (k, ratio)
+        checked += 1
+    assert checked >= 4
+
+
 def test_stream_form_in_decode_order_gives_the_records_of_the_file_form(demo, decoded):
     """covahip_h264_decode_au (parameter sets from the avcC box, access units in decode order: what the h264entropydec element
     calls) keeps its own reference marking and co-located motion; covahip_h264_decode_records (random access) finds them
