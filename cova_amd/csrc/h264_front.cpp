@@ -77,7 +77,7 @@ struct Sps {
     int id = 0;
     int profile = 0, level = 0, chroma_format = 1, log2_max_frame_num = 4, poc_type = 0, log2_max_poc_lsb = 4;
     int delta_pic_order_always_zero = 0, num_ref_frames = 0, width_mbs = 0, height_map_units = 0, frame_mbs_only = 1, mbaff = 0;
-    int direct_8x8 = 0;
+    int direct_8x8 = 0, bit_depth = 8;
     bool ok = false;
 };
 struct Pps {
@@ -96,7 +96,8 @@ bool parse_sps(const std::vector<uint8_t> &rbsp, Sps &s) {
         s.profile == 86 || s.profile == 118 || s.profile == 128) {
         s.chroma_format = (int)r.ue();
         if (s.chroma_format == 3) r.u(1);
-        r.ue(); r.ue(); r.u(1);
+        s.bit_depth = 8 + (int)std::max(r.ue(), r.ue());   // luma, chroma: samples of more than 8 bits are refused at open (I_PCM sizes)
+        r.u(1);
         if (r.u(1)) return false;   // seq_scaling_matrix_present_flag: not handled
     }
     s.log2_max_frame_num = (int)r.ue() + 4;
@@ -609,6 +610,7 @@ int parse_avcc(covahip_h264 *h, const uint8_t *a, size_t n) {
     }
     if (!h->sps.ok || !h->pps.ok) return COVAHIP_ERR_BAD_DATA;
     if (h->pps.sps_id != h->sps.id) return COVAHIP_ERR_UNSUPPORTED;   // only the first SPS / PPS are kept
+    if (h->sps.bit_depth != 8) return COVAHIP_ERR_UNSUPPORTED;        // High 10 and up
     return COVAHIP_OK;
 }
 

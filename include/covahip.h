@@ -277,7 +277,7 @@ size_t covahip_assoc_csv(covahip_assoc *a, int which, char *out, size_t cap, int
  * output frame.  Built here, verified on the reference's demo/1m.mp4: ISO-BMFF / NAL / SPS / PPS / slice-header layer, picture
  * order (output order of the access units), the CABAC macroblock layer of frame-coded 4:2:0 streams with one slice per
  * picture and cabac_init_idc 0 (every slice must end on its last macroblock with end_of_slice_flag: 1,802 of 1,802 do) and
- * the record writer.  Anything else (CAVLC, fields / MBAFF, several slices per picture, cabac_init_idc 1 / 2) returns
+ * the record writer.  Anything else (CAVLC, fields / MBAFF, several slices per picture, cabac_init_idc 1 / 2, samples of more than 8 bits) returns
  * COVAHIP_ERR_UNSUPPORTED.  `file` must stay valid while the handle lives. */
 typedef struct covahip_h264 covahip_h264;
 typedef struct covahip_h264_info {
