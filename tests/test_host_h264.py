@@ -338,3 +338,42 @@ def test_corrupted_headers_never_crash(demo):
                 lib.covahip_h264_sample_slices(h, s, sl.ctypes.data, 4, C.byref(n))
             lib.covahip_h264_close(h)
     assert opened > 0
+
+
+# A second, unrelated stream that ships with this image (imageio's test clip: 320x240, High@4.0, picture order count type 2, one
+# reference frame, I and P pictures, another encoder configuration than the demo video's): nothing in the front end is fitted to one file.
+SECOND = "/opt/conda/lib/python3.9/site-packages/imageio/resources/images/realshort.mp4"
+
+
+@pytest.mark.skipif(not os.path.exists(SECOND), reason="imageio's test clip is not in this image")
+def test_a_second_stream_decodes_to_the_last_macroblock_of_every_slice():
+    lib = L.lib()
+    data = np.fromfile(SECOND, dtype=np.uint8)
+    h = C.c_void_p()
+    assert lib.covahip_h264_open_mp4(data.ctypes.data, data.size, C.byref(h)) == 0
+    try:
+        info = np.zeros(1, dtype=L.H264_INFO_DTYPE)
+        assert lib.covahip_h264_get_info(h, info.ctypes.data) == 0
+        n_s, wmb, hmb = int(info[0]["n_samples"]), int(info[0]["width_mbs"]), int(info[0]["height_mbs"])
+        assert (wmb, hmb) == (20, 15) and n_s == 36 and info[0]["entropy_cabac"] == 1 and info[0]["poc_type"] == 2
+        sl = np.zeros(4, dtype=L.H264_SLICE_DTYPE)
+        n = C.c_int()
+        rec = np.zeros((hmb, wmb, 4), np.uint8)
+        types = []
+        moving = 0
+        for s in range(n_s):
+            assert lib.covahip_h264_sample_slices(h, s, sl.ctypes.data, 4, C.byref(n)) == 0 and n.value == 1
+            types.append(int(sl[0]["slice_type"]))
+            assert lib.covahip_h264_decode_records(h, s, rec.ctypes.data, rec.nbytes) == 0, f"access unit {s}"
+            assert rec[..., 0].max() <= 7 and not rec[..., 3].any()
+            if types[-1] == 2:
+                assert set(np.unique(rec[..., 0])) <= {5, 6, 7} and not rec[..., 1:3].any()
+            else:
+                moving += int((rec[..., 1:3].max(axis=-1) > 0).sum())
+        assert types.count(2) == 2 and types.count(0) == 34 and moving > 0
+        # picture order count type 2: output order = decode order
+        order = np.zeros(n_s, np.int32)
+        assert lib.covahip_h264_display_order(h, order.ctypes.data, n_s, C.byref(n)) == 0 and (order == np.arange(n_s)).all()
+    finally:
+        lib.covahip_h264_close(h)
+
