@@ -61,6 +61,7 @@ struct DecPrep {
 struct Prepared {
     EncPrep enc[BN_LEVELS];
     DecPrep dec[BN_LEVELS - 1];
+    size_t enc1w;    // level 1 again, in the fragment order of enc1w_mfma: [2 N tiles][5 K steps][64] x half8
     size_t final_w;  // B fragments of the folded (convT 32->16) x (1x1 16->1) last block: [KSTEPS][64] x half8
     size_t final_epi;  // folded bias (fp32)
     size_t zero;     // 256 zero bytes (LDS-DMA source for halo chunks)
@@ -610,8 +611,22 @@ __device__ unsigned long long g_phase[80];
         ph_[i] += now_ - last_;                                           \
         last_ = now_;                                                     \
     } while (0)
+// per-workgroup life span of the last launch of a kernel: {start, end} in s_memrealtime ticks (10 ns) and the hardware id
+// (which workgroups shared a CU)
+__device__ unsigned long long g_wgspan[6][1024][3];
+#define WGSPAN_BEGIN() const unsigned long long wg_t0_ = __builtin_amdgcn_s_memrealtime()
+#define WGSPAN_END(kid)                                                                          \
+    do {                                                                                         \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) {                                             \
+            g_wgspan[kid][blockIdx.x][0] = wg_t0_;                                               \
+            g_wgspan[kid][blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();                     \
+            g_wgspan[kid][blockIdx.x][2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); \
+        }                                                                                        \
+    } while (0)
 #else
 #define PHASE_MARK(i) do { } while (0)
+#define WGSPAN_BEGIN() do { } while (0)
+#define WGSPAN_END(kid) do { } while (0)
 #endif
 template <int CIN, int COUT, int TPAR, int OCC, int NWV, bool WIDE, bool ALLPOS, bool PRE = false>
 __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
@@ -625,6 +640,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     const int TR = p.TR, TC = p.TC;
     const int tsz = TR * TC * PS;
 
+    WGSPAN_BEGIN();
 #ifdef PHASE_TIMING
     unsigned long long ph_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -954,6 +970,547 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     if (tid == 64 * (PHASE_WAVE < 0 ? NWV + PHASE_WAVE : PHASE_WAVE))
         for (int i = 0; i < 9; i++) atomicAdd(&g_phase[i + (PRE ? 0 : COUT == 64 ? 16 : COUT == 128 ? 32 : 48)], ph_[i]);
 #endif
+    WGSPAN_END(COUT == 32 ? 0 : COUT == 64 ? 1 : 2);
+}
+
+// ------------------------------------------------------------------ enc level 1, sixteen-channel waves (round 4)
+// conv3x3 16 -> 32 on v_mfma_f32_16x16x32_f16: a wave owns 16 output channels (N) and tiles of 4 pool windows x 4
+// positions (M = 16); one K step = TWO taps x 16 input channels, five K steps (the tenth tap carries zero weights).
+// Against enc_mfma<16,32>: 20 weight registers instead of 36, 16 accumulator registers (all four T slices) instead
+// of 32 (two at a time) -> 64 registers per lane, EIGHT waves per SIMD (two workgroups of sixteen waves per CU)
+// instead of four.  What that buys is independent chains per CU: the launch is a chain of short phases per item
+// (request, landing, temporal MLP, barrier, tiles, epilogue), and the phases of a workgroup's item shrink with the
+// number of waves that share them (one 16-byte piece per thread to stage, at most three tiles per wave).
+//   * LDS band: [T][row][pixel][16 ch] with a FIXED row stride of E1_RS bytes == 128 mod 256 -- with the 16x16 lane map
+//     (lane = 16 * (tap-of-the-pair, channel half) + position) every ds_read_b128 lane group then covers all 64 banks
+//     once, without a swizzle.  No swizzle means the address of every fragment of a tile is ONE per-lane base plus a
+//     compile-time constant (tap, T slice): twenty ds_read_b128 with immediate offsets, no address arithmetic between
+//     the products (the swizzled form spends seven vector instructions per tap).
+//   * staging through registers (global_load -> [temporal MLP of the level below] -> ds_write_b128): in the
+//     carrier-frame form (PRE) every piece goes through the vector ALU anyway, the T = 0 result leaves for the skip
+//     tensor straight from the registers, and a kernel without LDS-DMA keeps hipcc from draining the vector-memory
+//     counter in front of LDS reads (it does that in every kernel that has one: an LDS-DMA is a pending LDS write).
+//     The loads of an item are issued BEFORE the barrier that ends the previous item.
+// Reference semantics: encoder.py:58-80 (conv -> ReLU -> BN -> pool -> pad -> PointWiseTN), pointwise.py:16-26.
+constexpr int E1_RS = 2176;              // bytes per band row: 66 pixels x 32 B + 64 B, == 128 mod 256
+constexpr int E1_TR = 8;                 // band rows per T slice (three pool-window rows + halo)
+constexpr int E1_TSZ = E1_RS * E1_TR;    // bytes per T slice
+constexpr int E1_MAXW = 65;              // (W + 2) * 32 + 32 <= E1_RS: the zero-weight tap of the last K step reads one pixel past the row
+struct Enc1wArgs {
+    const __half *in;    // stacked: act[1] [B][T][H][W][16]; PRE: P [F][H][W][16]
+    __half *out;         // [B][T][Ho][Wo][32]
+    const half8 *wfrag;  // [2 N tiles][5 K steps][64 lanes]
+    const float *epi;    // e0[32], e1[32], e2[32] (pool4), w1[16], w2[16]
+    int B, H, W, Hp, Wp, Ho, Wo, oy, ox;
+    int nbands;
+    uint32_t mWp, mRC;   // magic of Wp and of 2 * (W + 2)
+    int scr_off;         // per-wave store scratch (512 B per wave) behind the band
+    ItemPlan plan;
+    const int32_t *pidx; // PRE: frames of the T = 0..3 slices of every stack
+    __half *skip;        // PRE: [B][T][H][W][16], T = 0 written
+    const float *tm_pre; // PRE: w1[16], w2[16] of the level below
+    int stagger;         // developer knob: the second workgroup of every CU starts this many x 1,024 cycles late
+};
+// Per-lane constants live in a small LDS table instead of registers (the register budget is 64 per lane, and hipcc keeps
+// every loop-invariant load in a register for the whole kernel -- and then spills it):
+//   [0, 384)    e0[32], e1[32], e2[32]                      (pool4)
+//   [384, 448)  this level's temporal MLP: rows lane % 4 of W1^T and W2^T as fp16 (TmixW::a1, a2), 16 B per lane % 4
+//   [448, 512)  PRE: the same for the level below
+constexpr int E1_CONST = 512;
+#ifndef E1_ABL
+#define E1_ABL 0   // developer builds (tools/ablate_enc1w.sh): 1 no temporal MLP, 2 no products, 3 no tile epilogue, 4 no tiles, 5 no staging
+#endif
+template <int NWV, bool ALLPOS, bool PRE>
+__global__ __launch_bounds__(NWV * 64, NWV / 2) void enc1w_mfma(Enc1wArgs p) {
+    constexpr int WGS = NWV * 64, MG = NWV / 2;
+    constexpr int AD = 4;   // A fragments in flight ahead of their product
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    WGSPAN_BEGIN();
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: everything derived from it stays scalar
+    const int ntile = wave & 1, mgroup = wave >> 1;
+    // the row pads are read (by the zero-weight half of the last K step) and never written: finite once, finite for good
+    for (int i = tid; i < BN_T * E1_TSZ / 16; i += WGS) *reinterpret_cast<uint4 *>(smem + i * 16) = make_uint4(0, 0, 0, 0);
+    uint8_t *const cst = smem + p.scr_off + NWV * 512;
+    if (tid < 96) reinterpret_cast<float *>(cst)[tid] = p.epi[tid];
+    if (tid >= 128 && tid < 136) {
+        const int i = tid & 3;
+        const float *tmw = (tid & 4) ? p.tm_pre : p.epi + 96;
+        if (PRE || !(tid & 4)) {
+            half4 a1, a2;
+#pragma unroll
+            for (int t = 0; t < BN_T; t++) { a1[t] = (_Float16)tmw[t * BN_T + i]; a2[t] = (_Float16)tmw[16 + t * BN_T + i]; }
+            *reinterpret_cast<half4 *>(cst + 384 + (tid & 4) * 16 + i * 16) = a1;
+            *reinterpret_cast<half4 *>(cst + 384 + (tid & 4) * 16 + i * 16 + 8) = a2;
+        }
+    }
+    const int RCr = 2 * (p.W + 2);                         // 16-byte pieces per band row (without the pad)
+    const uint32_t plane = (uint32_t)p.H * p.W * 32;       // bytes per frame / T slice
+    if (p.stagger > 0 && (int)blockIdx.x >= ((int)gridDim.x >> 1))
+        for (int k = 0; k < p.stagger; k++) __builtin_amdgcn_s_sleep(16);
+
+    ItemIter it;
+    int item_no = (int)blockIdx.x >= ((int)gridDim.x >> 1) ? 1 : 0;
+    for (bool more = it.start(p.plan, p.B, p.nbands); more; more = it.next(p.plan, p.B, p.nbands)) {
+        const int b = it.b, band = it.band;
+        const int y0 = 2 * ((band * p.Hp) / p.nbands);
+        const int rows = 2 * (((band + 1) * p.Hp) / p.nbands) - y0;
+        const int n2 = rows + 2;
+        if (p.stagger == -1) {
+            if (item_no & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            item_no++;
+        } else if (p.stagger == -2) {
+            if (item_no & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+        }
+        // the lane id, recomputed per item (two instructions): nothing derived from it lives across items, where the 64
+        // registers per lane are all taken
+        auto lane_id = []() -> int {   // opaque seed: hipcc would otherwise hoist the (loop-invariant) result and spill it
+            uint32_t zero = 0;
+            asm volatile("" : "+v"(zero));
+            return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+        };
+        const int ll = lane_id();
+        // ---- stage rows y0-1 .. y0+rows of the four T slices: one 16-byte piece (8 channels of a pixel) of all four
+        // slices per thread; the loads are in flight across the barrier
+        int fidx[BN_T] = {0, 1, 2, 3};
+        const uint8_t *fbase = reinterpret_cast<const uint8_t *>(p.in);
+        if constexpr (PRE) {
+            // scalar load (constant address space): the table is uploaded before the launch and never written by a kernel
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            typedef const __attribute__((address_space(4))) i32x4 *const_i32x4_ptr;
+            const i32x4 row = *(const_i32x4_ptr)(uintptr_t)(p.pidx + b * BN_T);
+            fidx[0] = row[0]; fidx[1] = row[1]; fidx[2] = row[2]; fidx[3] = row[3];
+        } else {
+            fbase += (size_t)b * BN_T * plane;
+        }
+        const int ya = y0, yb = (band == p.nbands - 1) ? p.H : y0 + rows;   // rows whose T = 0 slice this item owns (PRE)
+        const int nreal = n2 * RCr;
+        const int i = wave * 64 + ll;    // the host keeps 8 * RCr <= WGS: one piece per thread
+        // (branch-free: every thread loads -- threads without a piece and halo pieces from a clamped address -- and only
+        // the LDS / skip writes are predicated; hipcc's register allocation across the barrier is far better for it)
+        const int ic = min(i, nreal - 1);
+        const int r = fdiv(ic, p.mRC), within = ic - r * RCr;
+        const int c = within >> 1, hf = within & 1;
+        const int y = y0 - 1 + r, x = c - 1;
+        const bool in = y >= 0 && y < p.H && x >= 0 && x < p.W;
+        const int dst = r * E1_RS + c * 32 + hf * 16;
+        const uint32_t eoff = (uint32_t)((min(max(y, 0), p.H - 1) * p.W + min(max(x, 0), p.W - 1)) * 32 + hf * 16);
+        const bool own = i < nreal && in && y >= ya && y < yb;
+        half8 v[BN_T];
+#pragma unroll
+        for (int t = 0; t < BN_T; t++) {
+            // scalar 64-bit base + 32-bit lane offset
+            const uint64_t fo = (uint64_t)(uint32_t)fidx[t] * plane;
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)fo), hi = __builtin_amdgcn_readfirstlane((uint32_t)(fo >> 32));
+            v[t] = *reinterpret_cast<const half8 *>(fbase + (((uint64_t)hi << 32) | lo) + eoff);
+        }
+        lds_barrier();   // every wave has left the previous item's band (first item: the table and the zeros are written)
+        if (!in) {
+#pragma unroll
+            for (int t = 0; t < BN_T; t++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[t][j] = (_Float16)0;
+        }
+        const bool have = (E1_ABL != 5) && wave * 64 + lane_id() < nreal;   // (recomputed: cheaper than a register held across the MLP)
+        if constexpr (PRE && E1_ABL != 1 && E1_ABL != 5) {
+            // temporal MLP of the level below (zero padding stays zero: no bias): four channels = one 8-byte piece per T
+            // slice at a time, so that at most half of the results are held in registers
+            TmixW tmp;
+            {
+                const uint4 w = *reinterpret_cast<const uint4 *>(cst + 448 + (ll & 3) * 16);
+                tmp.a1 = __builtin_bit_cast(half4, make_uint2(w.x, w.y));
+                tmp.a2 = __builtin_bit_cast(half4, make_uint2(w.z, w.w));
+#pragma unroll
+                for (int t = 0; t < BN_T; t++) tmp.id[t] = (_Float16)(t == (ll & 3) ? 1.f : 0.f);
+            }
+            uint8_t *const skp = reinterpret_cast<uint8_t *>(p.skip) + (size_t)b * BN_T * plane + eoff;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                half4 o[BN_T];
+#pragma unroll
+                for (int j0 = 0; j0 < 4; j0 += 2) {
+                    half4 pb[2];
+                    f32x4 rr[2];
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+                        pb[j] = half4{v[0][4 * h + j0 + j], v[1][4 * h + j0 + j], v[2][4 * h + j0 + j], v[3][4 * h + j0 + j]};
+                    tmix4f<2>(tmp, pb, rr);
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+#pragma unroll
+                        for (int t = 0; t < BN_T; t++) o[t][j0 + j] = (_Float16)rr[j][t];
+                }
+                if (have) {
+#pragma unroll
+                    for (int t = 0; t < BN_T; t++) *reinterpret_cast<half4 *>(smem + t * E1_TSZ + dst + 8 * h) = o[t];
+                }
+                if (own) *reinterpret_cast<half4 *>(skp + 8 * h) = o[0];
+            }
+        } else {
+            if (have) {
+#pragma unroll
+                for (int t = 0; t < BN_T; t++) *reinterpret_cast<half8 *>(smem + t * E1_TSZ + dst) = v[t];
+            }
+        }
+        // the wave's weight fragments, (re)loaded per item: held across the staging they would not leave the temporal MLP
+        // its registers
+        half8 bf[5];
+        {
+            const half8 *wp = p.wfrag + ntile * 5 * 64 + ll;
+            asm volatile("" : "+v"(wp));
+#pragma unroll
+            for (int s = 0; s < 5; s++) bf[s] = wp[s * 64];
+        }
+        lds_barrier();   // the band is complete
+        // ---- tiles of 4 pool windows
+        const int m = ll & 15, kg = ll >> 4;
+        const int nwin = (rows / 2) * p.Wp;
+        const int ntiles = (nwin + 3) / 4;
+        const uint32_t tstride = (uint32_t)(p.Ho * p.Wo * 32);
+        __half *const ob = p.out + (size_t)b * BN_T * tstride;
+        uint8_t *const scr = smem + p.scr_off + wave * 512;
+        for (int tile = mgroup; tile < (E1_ABL == 4 ? 0 : ntiles); tile += MG) {
+            const int win = min(tile * 4 + (m >> 2), nwin - 1);
+            const int wy = fdiv(win, p.mWp), wx = win - wy * p.Wp;
+            const int yy0 = 2 * wy + ((m >> 1) & 1), xx0 = 2 * wx + (m & 1);
+            const int base = yy0 * E1_RS + xx0 * 32 + (kg & 1) * 16;
+            // K step s, lane half kg >> 1: taps (0,0)|(0,1), (1,0)|(1,1), (2,0)|(2,1) -> aH + s * RS; (0,2)|(1,2) -> aV + 64;
+            // (2,2)|zero weights -> aH + 2 RS + 64
+            const uint8_t *const aH = smem + base + (kg >> 1) * 32, *const aV = smem + base + (kg >> 1) * E1_RS;
+            // two T slices at a time (8 accumulator registers): order (T pair, K step, T of the pair)
+            auto frag = [&](int idx) -> half8 {
+                const int s = (idx % 10) >> 1, t = 2 * (idx / 10) + (idx & 1);
+                const uint8_t *a = s == 3 ? aV + 64 : s == 4 ? aH + 2 * E1_RS + 64 : aH + s * E1_RS;
+                return *reinterpret_cast<const half8 *>(__builtin_assume_aligned(a + t * E1_TSZ, 16));
+            };
+            half8 ab[AD];
+#pragma unroll
+            for (int k = 0; k < AD; k++) ab[k] = frag(k);
+            // the epilogue's constants, requested ahead of the products
+            const int co = ntile * 16 + m;
+            const float e0 = reinterpret_cast<const float *>(cst)[co], e1 = reinterpret_cast<const float *>(cst)[32 + co];
+            const float e2 = ALLPOS ? 0.f : reinterpret_cast<const float *>(cst)[64 + co];
+            const uint4 tw = *reinterpret_cast<const uint4 *>(cst + 384 + (m & 3) * 16);
+            f32x4 acc[2];
+            f32x4 pooled;
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 20; k++) {
+                const int s = (k % 10) >> 1, tp = k & 1;
+#if E1_ABL == 2
+                asm volatile("" : "+v"(acc[tp]) : "v"(ab[k % AD]), "v"(bf[s]));
+#else
+                acc[tp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ab[k % AD], bf[s], s == 0 ? z4 : acc[tp], 0, 0, 0);
+#endif
+                if (k + AD < 20) ab[k % AD] = frag(k + AD);
+#if E1_ABL == 3
+                if (s == 4) asm volatile("" :: "v"(acc[tp]));
+                if (false) {
+#else
+                if (s == 4) {
+#endif
+                    // D row 4 * kg + r: window kg of the tile, position r; column m: channel co
+                    float pv = pool4<ALLPOS>(acc[tp][0], acc[tp][1], acc[tp][2], acc[tp][3], e0, e1, e2);
+                    asm volatile("" : "+v"(pv));   // one rounding point (fp32, then fp16) whatever the instantiation
+                    pooled[2 * (k / 10) + tp] = pv;
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, AD, 0);
+#pragma unroll
+            for (int k = 0; k < 20; k++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (k + AD < 20) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#if E1_ABL == 3
+            asm volatile("" :: "v"(tw.x), "v"(e0), "v"(e1));
+            continue;
+#endif
+            TmixW tm;
+            tm.a1 = __builtin_bit_cast(half4, make_uint2(tw.x, tw.y));
+            tm.a2 = __builtin_bit_cast(half4, make_uint2(tw.z, tw.w));
+#pragma unroll
+            for (int t = 0; t < BN_T; t++) tm.id[t] = (_Float16)(t == (m & 3) ? 1.f : 0.f);
+            half4 o;
+            tmix4h(tm, __builtin_convertvector(pooled, half4), o);
+            // ---- store through a wave-private transpose: S[t][window][16 channels] (32 contiguous bytes per window and T
+            // slice in the output tensor); lane (window kg, m) then moves the 8 bytes (t = m >> 2, quarter m & 3) of ITS window
+            {
+                _Float16 *sw = reinterpret_cast<_Float16 *>(scr + kg * 32) + m;
+#pragma unroll
+                for (int t = 0; t < BN_T; t++) sw[t * 64] = o[t];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int owin = tile * 4 + kg;
+            const uint2 sv = *reinterpret_cast<const uint2 *>(scr + (m >> 2) * 128 + kg * 32 + (m & 3) * 8);
+            if (owin < nwin) {
+                const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
+                const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
+                const uint32_t eo = (uint32_t)((gy * p.Wo + gx) * 32 + ntile * 16 + 4 * (m & 3));
+                *reinterpret_cast<uint2 *>(ob + (m >> 2) * tstride + eo) = sv;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next tile's values stay behind this read
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    WGSPAN_END(0);
+}
+
+// ------------------------------------------------------------------ enc level 1, 32-channel waves on 16-position tiles
+// Same band layout, staging and addressing as enc1w_mfma, but a wave owns BOTH 16-channel N tiles of a 4-window tile: every
+// A fragment read from LDS feeds two products (half the LDS read traffic of enc1w_mfma, which needs the LDS array's full
+// 256 B/clk to keep the matrix pipe busy), the tile's epilogue handles 32 channels (half the per-tile vector instructions
+// per output) and a pixel's 64 output bytes leave in one piece.  Eight waves per workgroup (40 weight + 16 accumulator +
+// 16 ring registers: 128 per lane), two workgroups per CU.
+template <bool ALLPOS, bool PRE>
+__global__ __launch_bounds__(512, 4) void enc1v_mfma(Enc1wArgs p) {
+    constexpr int NWV = 8, WGS = NWV * 64, MG = NWV;
+    constexpr int AD = 4;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    WGSPAN_BEGIN();
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < BN_T * E1_TSZ / 16; i += WGS) *reinterpret_cast<uint4 *>(smem + i * 16) = make_uint4(0, 0, 0, 0);
+    uint8_t *const cst = smem + p.scr_off + NWV * 1024;
+    if (tid < 96) reinterpret_cast<float *>(cst)[tid] = p.epi[tid];
+    if (tid >= 128 && tid < 136) {
+        const int i = tid & 3;
+        const float *tmw = (tid & 4) ? p.tm_pre : p.epi + 96;
+        if (PRE || !(tid & 4)) {
+            half4 a1, a2;
+#pragma unroll
+            for (int t = 0; t < BN_T; t++) { a1[t] = (_Float16)tmw[t * BN_T + i]; a2[t] = (_Float16)tmw[16 + t * BN_T + i]; }
+            *reinterpret_cast<half4 *>(cst + 384 + (tid & 4) * 16 + i * 16) = a1;
+            *reinterpret_cast<half4 *>(cst + 384 + (tid & 4) * 16 + i * 16 + 8) = a2;
+        }
+    }
+    const int RCr = 2 * (p.W + 2);
+    const uint32_t plane = (uint32_t)p.H * p.W * 32;
+#ifdef PHASE_TIMING
+    unsigned long long ph_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+
+    ItemIter it;
+    for (bool more = it.start(p.plan, p.B, p.nbands); more; more = it.next(p.plan, p.B, p.nbands)) {
+        const int b = it.b, band = it.band;
+        const int y0 = 2 * ((band * p.Hp) / p.nbands);
+        const int rows = 2 * (((band + 1) * p.Hp) / p.nbands) - y0;
+        const int n2 = rows + 2;
+        auto lane_id = []() -> int {
+            uint32_t zero = 0;
+            asm volatile("" : "+v"(zero));
+            return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+        };
+        const int ll = lane_id();
+        int fidx[BN_T] = {0, 1, 2, 3};
+        const uint8_t *fbase = reinterpret_cast<const uint8_t *>(p.in);
+        if constexpr (PRE) {
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            typedef const __attribute__((address_space(4))) i32x4 *const_i32x4_ptr;
+            const i32x4 row = *(const_i32x4_ptr)(uintptr_t)(p.pidx + b * BN_T);
+            fidx[0] = row[0]; fidx[1] = row[1]; fidx[2] = row[2]; fidx[3] = row[3];
+        } else {
+            fbase += (size_t)b * BN_T * plane;
+        }
+        const int ya = y0, yb = (band == p.nbands - 1) ? p.H : y0 + rows;
+        const int nreal = n2 * RCr;
+        // ---- stage: two 16-byte pieces of all four T slices per thread (the host keeps 8 * RCr <= 2 * WGS), loads in flight
+        // across the barrier
+        half8 v[2][BN_T];
+        int dst[2];
+        uint32_t eoff[2];
+        bool inb[2], have[2], own[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = wave * 64 + ll + k * WGS;
+            const int ic = min(i, nreal - 1);
+            const int r = fdiv(ic, p.mRC), within = ic - r * RCr;
+            const int c = within >> 1, hf = within & 1;
+            const int y = y0 - 1 + r, x = c - 1;
+            inb[k] = y >= 0 && y < p.H && x >= 0 && x < p.W;
+            dst[k] = r * E1_RS + c * 32 + hf * 16;
+            eoff[k] = (uint32_t)((min(max(y, 0), p.H - 1) * p.W + min(max(x, 0), p.W - 1)) * 32 + hf * 16);
+            have[k] = (E1_ABL != 5) && i < nreal;
+            own[k] = have[k] && inb[k] && y >= ya && y < yb;
+#pragma unroll
+            for (int t = 0; t < BN_T; t++) {
+                const uint64_t fo = (uint64_t)(uint32_t)fidx[t] * plane;
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)fo), hi = __builtin_amdgcn_readfirstlane((uint32_t)(fo >> 32));
+                v[k][t] = *reinterpret_cast<const half8 *>(fbase + (((uint64_t)hi << 32) | lo) + eoff[k]);
+            }
+        }
+        PHASE_MARK(0);   // item bookkeeping, addresses, loads issued
+        lds_barrier();   // every wave has left the previous item's band
+        PHASE_MARK(1);   // barrier: the other waves finishing the previous item
+#ifdef PHASE_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PHASE_MARK(2);   // loads landing
+#endif
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (!inb[k]) {
+#pragma unroll
+                for (int t = 0; t < BN_T; t++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[k][t][j] = (_Float16)0;
+            }
+            if constexpr (PRE && E1_ABL != 1 && E1_ABL != 5) {
+                TmixW tmp;
+                {
+                    const uint4 w = *reinterpret_cast<const uint4 *>(cst + 448 + (ll & 3) * 16);
+                    tmp.a1 = __builtin_bit_cast(half4, make_uint2(w.x, w.y));
+                    tmp.a2 = __builtin_bit_cast(half4, make_uint2(w.z, w.w));
+#pragma unroll
+                    for (int t = 0; t < BN_T; t++) tmp.id[t] = (_Float16)(t == (ll & 3) ? 1.f : 0.f);
+                }
+                half8 o[BN_T];
+#pragma unroll
+                for (int j0 = 0; j0 < 8; j0 += 4) {
+                    half4 pb[4];
+                    f32x4 rr[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) pb[j] = half4{v[k][0][j0 + j], v[k][1][j0 + j], v[k][2][j0 + j], v[k][3][j0 + j]};
+                    tmix4f<4>(tmp, pb, rr);
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int t = 0; t < BN_T; t++) o[t][j0 + j] = (_Float16)rr[j][t];
+                }
+                if (have[k]) {
+#pragma unroll
+                    for (int t = 0; t < BN_T; t++) *reinterpret_cast<half8 *>(smem + t * E1_TSZ + dst[k]) = o[t];
+                }
+                if (own[k]) *reinterpret_cast<half8 *>(reinterpret_cast<uint8_t *>(p.skip) + (size_t)b * BN_T * plane + eoff[k]) = o[0];
+            } else {
+                if (have[k]) {
+#pragma unroll
+                    for (int t = 0; t < BN_T; t++) *reinterpret_cast<half8 *>(smem + t * E1_TSZ + dst[k]) = v[k][t];
+                }
+            }
+        }
+        PHASE_MARK(3);   // temporal MLP, LDS writes, skip stores
+        // weight fragments of both N tiles, (re)loaded per item (the temporal MLP needs the registers)
+        half8 bf[2][5];
+        {
+            const half8 *wp = p.wfrag + ll;
+            asm volatile("" : "+v"(wp));
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int s = 0; s < 5; s++) bf[nt][s] = wp[(nt * 5 + s) * 64];
+        }
+        lds_barrier();   // the band is complete
+        PHASE_MARK(4);   // barrier: the band complete
+#ifdef PHASE_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PHASE_MARK(5);   // weights landing
+#endif
+        const int m = ll & 15, kg = ll >> 4;
+        const int nwin = (rows / 2) * p.Wp;
+        const int ntiles = (nwin + 3) / 4;
+        const uint32_t tstride = (uint32_t)(p.Ho * p.Wo * 32);
+        __half *const ob = p.out + (size_t)b * BN_T * tstride;
+        uint8_t *const scr = smem + p.scr_off + wave * 1024;
+        for (int tile = wave; tile < (E1_ABL == 4 ? 0 : ntiles); tile += MG) {
+            const int win = min(tile * 4 + (m >> 2), nwin - 1);
+            const int wy = fdiv(win, p.mWp), wx = win - wy * p.Wp;
+            const int yy0 = 2 * wy + ((m >> 1) & 1), xx0 = 2 * wx + (m & 1);
+            const int base = yy0 * E1_RS + xx0 * 32 + (kg & 1) * 16;
+            const uint8_t *const aH = smem + base + (kg >> 1) * 32, *const aV = smem + base + (kg >> 1) * E1_RS;
+            auto frag = [&](int idx) -> half8 {
+                const int s = (idx % 10) >> 1, t = 2 * (idx / 10) + (idx & 1);
+                const uint8_t *a = s == 3 ? aV + 64 : s == 4 ? aH + 2 * E1_RS + 64 : aH + s * E1_RS;
+                return *reinterpret_cast<const half8 *>(__builtin_assume_aligned(a + t * E1_TSZ, 16));
+            };
+            half8 ab[AD];
+#pragma unroll
+            for (int k = 0; k < AD; k++) ab[k] = frag(k);
+            const float *cf = reinterpret_cast<const float *>(cst);
+            float e0[2], e1[2], e2[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) {
+                e0[nt] = cf[nt * 16 + m]; e1[nt] = cf[32 + nt * 16 + m];
+                e2[nt] = ALLPOS ? 0.f : cf[64 + nt * 16 + m];
+            }
+            const uint4 tw = *reinterpret_cast<const uint4 *>(cst + 384 + (m & 3) * 16);
+            f32x4 acc[2][2];
+            f32x4 pooled[2];
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 20; k++) {
+                const int s = (k % 10) >> 1, tp = k & 1;
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++)
+                    acc[nt][tp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ab[k % AD], bf[nt][s], s == 0 ? z4 : acc[nt][tp], 0, 0, 0);
+                if (k + AD < 20) ab[k % AD] = frag(k + AD);
+#if E1_ABL == 3
+                if (s == 4) asm volatile("" :: "v"(acc[0][tp]), "v"(acc[1][tp]));
+                if (false) {
+#else
+                if (s == 4) {
+#endif
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++) {
+                        float pv = pool4<ALLPOS>(acc[nt][tp][0], acc[nt][tp][1], acc[nt][tp][2], acc[nt][tp][3], e0[nt], e1[nt], e2[nt]);
+                        asm volatile("" : "+v"(pv));   // one rounding point (fp32, then fp16) whatever the instantiation
+                        pooled[nt][2 * (k / 10) + tp] = pv;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, AD, 0);
+#pragma unroll
+            for (int k = 0; k < 20; k++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                if (k + AD < 20) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#if E1_ABL == 3
+            asm volatile("" :: "v"(tw.x), "v"(e0[0]), "v"(e1[0]), "v"(e0[1]), "v"(e1[1]));
+            continue;
+#endif
+#ifdef PHASE_TIMING
+            asm volatile("" : "+v"(pooled[0]), "+v"(pooled[1]));
+            PHASE_MARK(6);   // tiles: fragments, products, pooling
+#endif
+            TmixW tm;
+            tm.a1 = __builtin_bit_cast(half4, make_uint2(tw.x, tw.y));
+            tm.a2 = __builtin_bit_cast(half4, make_uint2(tw.z, tw.w));
+#pragma unroll
+            for (int t = 0; t < BN_T; t++) tm.id[t] = (_Float16)(t == (m & 3) ? 1.f : 0.f);
+            half4 pb2[2], o2[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) pb2[nt] = __builtin_convertvector(pooled[nt], half4);
+            tmix4h<2>(tm, pb2, o2);
+            // ---- store through a wave-private transpose: S[window][t][32 channels] (64 contiguous bytes per window and T slice
+            // in the output tensor); lane (window kg, m) then moves the 16 bytes (t = m >> 2, quarter m & 3) of ITS window
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) {
+                _Float16 *sw = reinterpret_cast<_Float16 *>(scr + kg * 256) + nt * 16 + m;
+#pragma unroll
+                for (int t = 0; t < BN_T; t++) sw[t * 32] = o2[nt][t];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int owin = tile * 4 + kg;
+            const uint4 sv = *reinterpret_cast<const uint4 *>(scr + ll * 16);   // = kg * 256 + (m >> 2) * 64 + (m & 3) * 16
+            if (owin < nwin) {
+                const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
+                const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
+                const uint32_t eo = (uint32_t)((gy * p.Wo + gx) * 32 + 8 * (m & 3));
+                *reinterpret_cast<uint4 *>(ob + (m >> 2) * tstride + eo) = sv;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            PHASE_MARK(7);   // tiles: epilogue
+        }
+    }
+#ifdef PHASE_TIMING
+    if (tid == 64 * (PHASE_WAVE < 0 ? NWV + PHASE_WAVE : PHASE_WAVE))
+        for (int i = 0; i < 9; i++) atomicAdd(&g_phase[i], ph_[i]);
+#endif
+    WGSPAN_END(0);
 }
 
 // ------------------------------------------------------------------ decoder blocks 0..3
@@ -1575,6 +2132,23 @@ void prep_enc(bool allpos, int cin, int cout, const float *k, const float *bias,
     std::memcpy(epi + 3 * cout + 16, w2, 16 * sizeof(float));
 }
 
+// level 1 for enc1w_mfma: 16x16x32 B fragment, lane l: n = l & 15, k = 8 * (l >> 4) + j; one K step = two taps x 16
+// channels: k < 16 -> first tap of the pair, k >= 16 -> second.  Pairs (ky,kx): (0,0)|(0,1), (1,0)|(1,1), (2,0)|(2,1),
+// (0,2)|(1,2), (2,2)|none.
+void prep_enc1w(bool allpos, const float *k, const float *bias, const float *gamma, const float *beta, const float *mean,
+                const float *var, _Float16 *wfrag) {
+    static const int pairs[5][2] = {{0, 1}, {3, 4}, {6, 7}, {2, 5}, {8, -1}};
+    std::vector<float> ws, epi(3 * 32);
+    enc_epilogue(32, allpos, bias, gamma, beta, mean, var, ws, epi.data());
+    for (int nt = 0; nt < 2; nt++)
+        for (int s = 0; s < 5; s++)
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 8; j++) {
+                    const int kg = l >> 4, tap = pairs[s][kg >> 1], c = 8 * (kg & 1) + j, n = nt * 16 + (l & 15);
+                    wfrag[(((size_t)nt * 5 + s) * 64 + l) * 8 + j] = f2h(tap < 0 ? 0.f : k[((size_t)tap * 16 + c) * 32 + n] * ws[n]);
+                }
+}
+
 void prep_dec(int cin, int cout, const float *k, const float *bias, const float *gamma, const float *beta,
               const float *mean, const float *var, _Float16 *wfrag, float *epi) {
     const int NTT = 4 * cout / 32, KC = cin / 16, KSTEPS = 4 * KC;
@@ -1802,6 +2376,7 @@ int blobnet_prepare_mfma(covahip_ctx *ctx, covahip_blobnet *m, const float *w) {
         pr->dec[j].wfrag = off; off = align256(off + nfrag * 16);
         pr->dec[j].epi = off; off = align256(off + 3 * co * sizeof(float));
     }
+    pr->enc1w = off; off = align256(off + (size_t)2 * 5 * 64 * 16);
     pr->final_w = off; off = align256(off + (size_t)(4 * m->dec_ci[3] / 16) * 64 * 16);
     pr->final_epi = off; off = align256(off + 16 * sizeof(float));
     pr->zero = off; off = align256(off + 256);
@@ -1818,6 +2393,9 @@ int blobnet_prepare_mfma(covahip_ctx *ctx, covahip_blobnet *m, const float *w) {
         prep_enc(pr->allpos[i], m->enc_c[i], m->enc_c[i + 1], he[i].k, he[i].b, he[i].gamma, he[i].beta, he[i].mean, he[i].var,
                  he[i].w1, he[i].w2, (_Float16 *)(host.data() + pr->enc[i].wfrag),
                  (float *)(host.data() + pr->enc[i].epi));
+    if (m->enc_c[1] == 16 && m->enc_c[2] == 32)
+        prep_enc1w(pr->allpos[1], he[1].k, he[1].b, he[1].gamma, he[1].beta, he[1].mean, he[1].var,
+                   (_Float16 *)(host.data() + pr->enc1w));
     for (int j = 0; j < BN_LEVELS - 1; j++)
         prep_dec(m->dec_ci[j], m->dec_co[j], hd[j].k, hd[j].b, hd[j].gamma, hd[j].beta, hd[j].mean, hd[j].var,
                  (_Float16 *)(host.data() + pr->dec[j].wfrag), (float *)(host.data() + pr->dec[j].epi));
@@ -1890,6 +2468,55 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
     for (int i = first_level; i < BN_LEVELS; i++) {
         const int H = m->lv[i].H, W = m->lv[i].W, Hp = H / 2, Wp = W / 2;
         const int cin = m->enc_c[i];
+        if (i == 1 && m->enc1_wide16 && cin == 16 && m->enc_c[2] == 32 && W <= E1_MAXW && !ctx->enc_plan[1].nbands) {
+            // sixteen-channel waves (enc1w_mfma): bands of at most three pool-window rows (E1_TR rows per T slice), two
+            // sixteen-wave workgroups per CU; same planner as below: rounds x (rows + 1)
+            static const bool wide8 = !(std::getenv("COVAHIP_E1_VARIANT") && std::getenv("COVAHIP_E1_VARIANT")[0] == 'w');
+            const int NWV = wide8 ? 8 : 16;
+            const long long slots = 2LL * num_cu;
+            long long best = -1;
+            int nbands = 0;
+            for (int nb = 1; nb <= Hp; nb++) {
+                const int rb = (Hp + nb - 1) / nb;
+                if (2 * rb + 2 > E1_TR) continue;
+                const long long rounds = ((long long)batch * nb + slots - 1) / slots;
+                const long long cost = rounds * (rb + 1);
+                if (best < 0 || cost < best) { best = cost; nbands = nb; }
+            }
+            if (nbands && E1_TR * 2 * (W + 2) <= 1024) {
+                Enc1wArgs a;
+                a.in = by_frames ? ws.pbuf : act[1]; a.out = act[2];
+                a.wfrag = (const half8 *)(prep + pr->enc1w); a.epi = (const float *)(prep + pr->enc[1].epi);
+                a.B = batch; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.Ho = m->lv[2].H; a.Wo = m->lv[2].W;
+                a.oy = H & 1; a.ox = W & 1; a.nbands = nbands;
+                a.mWp = magic(Wp); a.mRC = magic(2 * (W + 2));
+                a.scr_off = BN_T * E1_TSZ;
+                static const int stagger = std::getenv("COVAHIP_E1_STAGGER") ? std::atoi(std::getenv("COVAHIP_E1_STAGGER")) : 0;
+                const int grid = std::min(batch * nbands, (stagger == -3 ? 1 : 2) * num_cu);
+                a.plan = make_plan(grid, num_cu, 2, batch, nbands, Hp);
+                a.pidx = inp.index; a.skip = act[1]; a.tm_pre = (const float *)(prep + pr->enc[0].epi) + 48;
+                a.stagger = stagger;
+                const size_t lds = (size_t)BN_T * E1_TSZ + (wide8 ? 8 * 1024 : 16 * 512) + E1_CONST;
+                int rc;
+                ProfScope ps(ctx, by_frames ? "enc1t_mfma" : "enc1_mfma");
+#define E1_LAUNCH(KERNEL)                                                                  \
+    do {                                                                                   \
+        rc = set_lds(ctx, KERNEL, lds);                                                    \
+        if (rc) return rc;                                                                 \
+        LAUNCH((KERNEL), dim3(grid), dim3(NWV * 64), lds, ctx->stream, a);                 \
+    } while (0)
+                if (wide8) {
+                    if (by_frames) { if (pr->allpos[1]) E1_LAUNCH((enc1v_mfma<true, true>)); else E1_LAUNCH((enc1v_mfma<false, true>)); }
+                    else { if (pr->allpos[1]) E1_LAUNCH((enc1v_mfma<true, false>)); else E1_LAUNCH((enc1v_mfma<false, false>)); }
+                } else {
+                    if (by_frames) { if (pr->allpos[1]) E1_LAUNCH((enc1w_mfma<16, true, true>)); else E1_LAUNCH((enc1w_mfma<16, false, true>)); }
+                    else { if (pr->allpos[1]) E1_LAUNCH((enc1w_mfma<16, true, false>)); else E1_LAUNCH((enc1w_mfma<16, false, false>)); }
+                }
+#undef E1_LAUNCH
+                COVAHIP_CHECK_HIP(ctx, hipGetLastError());
+                continue;
+            }
+        }
         const size_t px_bytes = (i == 0) ? 8 : (size_t)cin * 2;
         // enc0: two zero columns left (16-byte aligned 4-pixel groups) and two right (halo + the 4th,
         // zero-weight pixel its K layout reads per tap row)
@@ -2134,6 +2761,9 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
 }
 
 #ifdef PHASE_TIMING
+extern "C" int covahip_dev_wgspan_read(unsigned long long *out, int kid) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgspan), sizeof(unsigned long long) * 1024 * 3, sizeof(unsigned long long) * 1024 * 3 * kid) != hipSuccess;
+}
 extern "C" int covahip_dev_phase_read(unsigned long long *out64, int reset) {
     if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase), sizeof(g_phase)) != hipSuccess) return 1;
     if (reset) {

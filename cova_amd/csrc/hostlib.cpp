@@ -674,6 +674,18 @@ int covahip_sort_tracker_info(const covahip_sort *s, size_t i, uint64_t *id, int
     return COVAHIP_OK;
 }
 
+int covahip_sort_tracker_predict(covahip_sort *s, size_t i, uint64_t ts, covahip_bbox *last) {
+    if (!s || i >= s->s.trackers.size()) return COVAHIP_ERR_INVALID_ARG;
+    const covahip_bbox &b = s->s.trackers[i].predict(ts);
+    if (last) *last = b;
+    return COVAHIP_OK;
+}
+
+int covahip_sort_tracker_update(covahip_sort *s, size_t i, const covahip_bbox *det) {
+    if (!s || i >= s->s.trackers.size()) return COVAHIP_ERR_INVALID_ARG;
+    return s->s.trackers[i].update(det) ? COVAHIP_OK : COVAHIP_ERR_BAD_DATA;
+}
+
 size_t covahip_linear_assignment(const float *cost_colmajor, size_t n_rows, size_t n_cols, uint32_t *pairs,
                                  size_t cap_pairs) {
     if (!cost_colmajor) return 0;

@@ -53,7 +53,7 @@ struct covahip_ctx {
     hipStream_t primary = nullptr;   // the ctx's own stream
     hipStream_t stream = nullptr;    // where launches go NOW: `primary`, or the current lane's stream inside a LaneScope
     CtxLane lanes[COVAHIP_MAX_LANES];
-    int n_lanes = 2, next_lane = 0, cur_lane = 0;
+    int n_lanes = 1, next_lane = 0, cur_lane = 0;   // one lane unless the caller opts in (covahip_ctx_set_lanes)
     bool in_lane = false;
     uint64_t primary_seq = 1;        // bumped by every operation enqueued on the primary stream
     hipEvent_t ev_fork = nullptr;

@@ -52,7 +52,7 @@ class Context:
         L.check(self._lib.covahip_ctx_sync(self.handle), "covahip_ctx_sync", self.handle)
 
     def set_lanes(self, n: int):
-        """Batches in flight (covahip_ctx_set_lanes): 1 = strictly in call order, 2 (default) = consecutive device-pointer
+        """Batches in flight (covahip_ctx_set_lanes): 1 (default) = strictly in call order, 2 = consecutive device-pointer
         filter calls overlap."""
         L.check(self._lib.covahip_ctx_set_lanes(self.handle, n), "covahip_ctx_set_lanes", self.handle)
 
@@ -177,8 +177,9 @@ class BlobNetInfer:
         L.check(self._lib.covahip_blobnet_set_enc_plan(self.ctx.handle, level, nbands, nbuf), "covahip_blobnet_set_enc_plan")
 
     def set_impl(self, impl: str):
-        """Developer switch (include/covahip_dev.h): decoder blocks 0..2 as one launch ("mfma", default) or three ("dec_separate")."""
-        L.check(self._lib.covahip_blobnet_set_impl(self.ctx.handle, {"mfma": 1, "dec_separate": 4}[impl]), "set_impl")
+        """Developer switch (include/covahip_dev.h): decoder blocks 0..2 as one launch ("mfma", default) or three
+        ("dec_separate"); "enc1_legacy": encoder level 1 on the 32x32x16 kernel instead of the sixteen-channel-wave one."""
+        L.check(self._lib.covahip_blobnet_set_impl(self.ctx.handle, {"mfma": 1, "dec_separate": 4, "enc1_legacy": 5}[impl]), "set_impl")
 
     @property
     def macs_per_frame(self) -> int:

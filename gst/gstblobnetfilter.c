@@ -132,7 +132,9 @@ static gboolean bf_ensure_model(GstBlobNetFilter *s) {   /* lock held */
         GST_ELEMENT_ERROR(s, RESOURCE, OPEN_READ, ("no HIP device %u", s->gpu_id), (NULL));
         return FALSE;
     }
-    rc = covahip_blobnet_load(s->ctx, blob, len, s->h_mb, s->w_mb, BF_TIMESTEP, (int)s->batch_size);
+    /* two batches in flight: every pipe slot owns its output buffers (the ctx default is one lane, include/covahip.h) */
+    rc = covahip_ctx_set_lanes(s->ctx, 2);
+    if (rc == COVAHIP_OK) rc = covahip_blobnet_load(s->ctx, blob, len, s->h_mb, s->w_mb, BF_TIMESTEP, (int)s->batch_size);
     g_free(blob);
     if (rc == COVAHIP_OK) rc = covahip_pipe_create(s->ctx, (int)s->batch_size, BF_TIMESTEP * (int)s->batch_size, (int)s->max_boxes, BF_SLOTS, 0, &s->pipe);
     if (rc == COVAHIP_OK) rc = covahip_pipe_acquire(s->pipe, &s->slot, &s->pf, &s->pi);

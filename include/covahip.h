@@ -69,8 +69,10 @@ int covahip_ctx_sync(covahip_ctx *ctx);
  *     calls) waits for / is ordered behind all lanes;
  *   - two device-pointer filter calls with nothing in between may run concurrently: give them separate output buffers
  *     (inputs may be shared) or call covahip_ctx_sync between them.
- * n_lanes in [1, 4]; default 2; 1 = strictly in call order on one stream.  Workspace per lane at 68x120, max_batch 256:
- * about 150 MB.  Drains the ctx first. */
+ * n_lanes in [1, 4]; DEFAULT 1 = strictly in call order on one stream, no hidden concurrency (the boundary the reference's
+ * own FFI has, cova-rs/nvdsbbox/nvdsbbox.h:7-14).  A caller that owns one set of output buffers per batch in flight opts in
+ * with covahip_ctx_set_lanes(ctx, 2): the blobnetfilter element, tools/pipe_bench and bench.py do (covahip_pipe_* slots own
+ * their buffers).  Workspace per lane at 68x120, max_batch 256: about 150 MB.  Drains the ctx first. */
 int covahip_ctx_set_lanes(covahip_ctx *ctx, int n_lanes);
 int covahip_ctx_get_lanes(covahip_ctx *ctx, int *n_lanes);
 /* Text of the last failing HIP call on this ctx ("" if none). */
@@ -366,6 +368,11 @@ int covahip_sort_num_trackers(const covahip_sort *s, size_t *n);
 /* Introspection for tests: tracker i's id / active flag / hit_streaks / state box. */
 int covahip_sort_tracker_info(const covahip_sort *s, size_t i, uint64_t *id, int *active,
                               uint64_t *hit_streaks, uint64_t *time_since_update, covahip_bbox *state);
+/* Introspection for tests (the reference's own unit tests drive the tracker this way, sort/src/lib.rs:250-274,
+ * tracker/mod.rs:154-165): KalmanBoxTracker::predict(ts) on tracker i (tracker/mod.rs:104-121; *last = history.last()),
+ * KalmanBoxTracker::update(Some(det) / None) (tracker/mod.rs:71-102; det == NULL is None). */
+int covahip_sort_tracker_predict(covahip_sort *s, size_t i, uint64_t ts, covahip_bbox *last);
+int covahip_sort_tracker_update(covahip_sort *s, size_t i, const covahip_bbox *det);
 /* linear_assignment() of lib.rs:25-56 on a column-major n_rows x n_cols f32 cost
  * matrix; writes (row, col) pairs; returns their number. */
 size_t covahip_linear_assignment(const float *cost_colmajor, size_t n_rows, size_t n_cols, uint32_t *pairs,

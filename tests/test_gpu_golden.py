@@ -112,7 +112,7 @@ def test_lanes_give_the_bits_of_one_step_after_the_other(ctx, weights_flat, lane
     """Six device-pointer calls with DIFFERENT inputs enqueued back to back on a ctx with 2 / 3 lanes (they overlap on the GPU,
     each lane with its own workspace, stack table and output buffers) against the same six calls with one lane."""
     h, w, b = 45, 80, 24
-    assert ctx.lanes() == 2          # the default
+    assert ctx.lanes() == 1          # the default: no hidden concurrency
     net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=b)
     inputs = [synth.carrier_batch(b, h, w, seed=100 + k, streams=1 + k % 3) for k in range(6)]
     d_in = []
@@ -149,7 +149,7 @@ def test_lanes_give_the_bits_of_one_step_after_the_other(ctx, weights_flat, lane
         assert (np.abs(ref_logits[want[5][2] != (ref_logits > 0)]) <= atol).all()
         _same_boxes(want[5][0], want[5][1], *ref.regionprops_batch(want[5][2], 1, 512))
     finally:
-        ctx.set_lanes(2)
+        ctx.set_lanes(1)
         for p in d_in:
             ctx.free(p)
         for o in outs:
@@ -166,6 +166,7 @@ def test_lanes_order_behind_and_before_primary_stream_work(ctx, weights_flat):
     fr_b, _ = synth.carrier_batch(b, h, w, seed=8, streams=2)
     d_in = ctx.malloc(fr_a.nbytes)
     out = (ctx.malloc(b * 512 * 20), ctx.malloc(b * 4), ctx.malloc(b * h * w))
+    ctx.set_lanes(2)
     try:
         res = []
         for fr in (fr_a, fr_b, fr_a):
@@ -186,9 +187,46 @@ def test_lanes_order_behind_and_before_primary_stream_work(ctx, weights_flat):
         np.testing.assert_array_equal(c2, res[0][1])
         ctx.free(d_b2); ctx.free(d_c2)
     finally:
+        ctx.set_lanes(1)
         ctx.free(d_in)
         for p in out:
             ctx.free(p)
+
+
+def test_default_ctx_runs_calls_in_order_on_shared_output_buffers(weights_flat):
+    """The drop-in contract (include/covahip.h; boundary precedent cova-rs/nvdsbbox/nvdsbbox.h:7-14: no hidden concurrency): on a
+    ctx nobody has touched, device-pointer filter calls enqueued back to back WITHOUT a sync and sharing ONE set of output
+    buffers leave the last call's results there -- every call is ordered behind the one before it."""
+    from cova_amd.elements import Context
+    c = Context(0)
+    try:
+        assert c.lanes() == 1
+        h, w, b = 45, 80, 24
+        net = BlobNetInfer(c, weights_flat, h, w, max_batch=b)
+        inputs = [synth.carrier_batch(b, h, w, seed=300 + k, streams=2) for k in range(4)]
+        d_in = []
+        for fr, _ in inputs:
+            p = c.malloc(fr.nbytes)
+            c.h2d(p, fr)
+            d_in.append(p)
+        out = (c.malloc(b * 512 * 20), c.malloc(b * 4), c.malloc(b * h * w))
+        want = []
+        for k in range(4):
+            _device_run(c, net, d_in[k], inputs[k][0].shape[0], inputs[k][1], b, out)
+            c.sync()
+            want.append(_fetch(c, b, h, w, out))
+        assert want[2][2].tobytes() != want[3][2].tobytes()
+        for rep in range(5):
+            for k in range(4):          # four calls in flight on the same outputs, no sync in between
+                _device_run(c, net, d_in[k], inputs[k][0].shape[0], inputs[k][1], b, out)
+            boxes, counts, mask = _fetch(c, b, h, w, out)
+            np.testing.assert_array_equal(mask, want[3][2])
+            np.testing.assert_array_equal(counts, want[3][1])
+            for i in range(b):
+                n = min(int(counts[i]), 512)
+                assert boxes[i, :n].tobytes() == want[3][0][i, :n].tobytes()
+    finally:
+        c.close()
 
 
 def test_real_video_records_through_the_hot_path(ctx):

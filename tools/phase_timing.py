@@ -14,6 +14,8 @@ from cova_amd import _lib as L  # noqa: E402
 B, H, Wd = 256, 68, 120
 ctx = Context(0)
 net = BlobNetInfer(ctx, W.random_init(1234), H, Wd, max_batch=B)
+if os.environ.get('QB_IMPL'):
+    net.set_impl(os.environ['QB_IMPL'])
 for spec in filter(None, os.environ.get("QB_PLAN", "").split(",")):      # level:nbands:nbuf
     net.set_enc_plan(*[int(x) for x in spec.split(":")])
 NWG = {0: int(os.environ.get("NWG1", 512)), 16: 512, 32: 256, 48: 256, 64: 256}
@@ -27,6 +29,7 @@ d_boxes, d_counts, d_mask = ctx.malloc(B * 256 * 20), ctx.malloc(B * 4), ctx.mal
 lib = ctypes.CDLL(L.LIB_PATH)
 out = (ctypes.c_ulonglong * 80)()
 names = ["bookkeeping", "barrier (previous item)", "DMA issue", "band landing", "temporal MLP in place", "skip slice out", "tiles: matrix part", "tiles: epilogue", "weights into registers (kernel start)"]
+E1V_NAMES = ["bookkeeping, addresses, loads issued", "barrier (previous item)", "loads landing", "temporal MLP, LDS writes, skip stores", "barrier (band complete)", "weights landing", "tiles: matrix part", "tiles: epilogue", "-"]
 steps = 20
 for _ in range(3):
     net.filter_frames_device(d_frames, frames.shape[0], index, B, 1, d_boxes, d_counts, 256, d_mask)
@@ -40,5 +43,5 @@ v = np.array(list(out), dtype=np.float64)
 for base, label in ((0, "enc1t (PRE)"), (16, "enc2"), (32, "enc3"), (48, "dec012"), (64, "dec3cc")):
     tot = v[base:base + 9].sum()
     print(f"{label}: {tot / steps / 100:.0f} us of workgroup time per launch (all workgroups)")
-    for i, n in enumerate(DEC_NAMES if base == 48 else TAIL_NAMES if base == 64 else names):
+    for i, n in enumerate(DEC_NAMES if base == 48 else TAIL_NAMES if base == 64 else E1V_NAMES if base == 0 and not os.environ.get('QB_IMPL') else names):
         print(f"   {n:40s} {100 * v[base + i] / tot:5.1f} %   {v[base + i] / steps / 100 / NWG[base]:7.2f} us per workgroup ({NWG[base]} of them)")

@@ -21,7 +21,7 @@ int main(int argc, char **argv) {
     if (fread(blob, 1, n, f) != (size_t)n) return 2;
     fclose(f);
     covahip_ctx *ctx; covahip_pipe *pipe;
-    if (covahip_ctx_create(0, &ctx) || covahip_blobnet_load(ctx, blob, n, H, W, 4, B)) return 3;
+    if (covahip_ctx_create(0, &ctx) || covahip_ctx_set_lanes(ctx, 2) || covahip_blobnet_load(ctx, blob, n, H, W, 4, B)) return 3;
     if (covahip_pipe_create(ctx, B, NF, 2048, 3, 0, &pipe)) return 4;
     const size_t fb = (size_t)H * W * 4;
     uint8_t *src = malloc(NF * fb);
