@@ -145,6 +145,8 @@ PROTOTYPES = {
     "covahip_sort_num_trackers": (C.c_int, [_P, C.POINTER(_SZ)]),
     "covahip_sort_tracker_info": (C.c_int, [_P, _SZ, C.POINTER(C.c_uint64), C.POINTER(C.c_int),
                                             C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _P]),
+    "covahip_sort_tracker_predict": (C.c_int, [_P, _SZ, C.c_uint64, _P]),
+    "covahip_sort_tracker_update": (C.c_int, [_P, _SZ, _P]),
     "covahip_linear_assignment": (_SZ, [_P, _SZ, _SZ, _P, _SZ]),
     "covahip_gopfilter_default_cfg": (None, [C.POINTER(GopFilterCfg)]),
     "covahip_gopfilter_new": (C.c_int, [C.POINTER(GopFilterCfg), C.POINTER(_P)]),

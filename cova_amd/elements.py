@@ -505,6 +505,20 @@ class _SortHandle:
         return {"id": tid.value, "active": bool(act.value), "hit_streaks": hs.value,
                 "time_since_update": tsu.value, "state": st[0]}
 
+    def tracker_predict(self, i: int, ts: int):
+        """KalmanBoxTracker::predict(ts) on tracker i (tracker/mod.rs:104-121); returns history.last()."""
+        st = np.zeros(1, dtype=L.BBOX_DTYPE)
+        L.check(self._lib.covahip_sort_tracker_predict(self.h, i, ts, _ptr(st)), "sort_tracker_predict")
+        return st[0]
+
+    def tracker_update(self, i: int, det=None):
+        """KalmanBoxTracker::update(Some(det) / None) on tracker i (tracker/mod.rs:71-102)."""
+        if det is None:
+            L.check(self._lib.covahip_sort_tracker_update(self.h, i, None), "sort_tracker_update")
+        else:
+            d = np.ascontiguousarray(det, dtype=L.BBOX_DTYPE).reshape(1)
+            L.check(self._lib.covahip_sort_tracker_update(self.h, i, _ptr(d)), "sort_tracker_update")
+
 
 class SortTracker:
     """`sorttracker` (BaseTransform, NeverInPlace): `iou-threshold` 0.1, `maxage` 30, `minhits` 30."""

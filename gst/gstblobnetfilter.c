@@ -183,8 +183,10 @@ static void bf_push_share(GstBlobNetFilter *s, BfFlight *fl, guint group, covahi
         GST_BUFFER_DURATION(b) = mt->duration;
         const GstFlowReturn r = gst_pad_push(p->src, b);
         if (r != GST_FLOW_OK && r != GST_FLOW_NOT_LINKED) {
-            /* EOS / FLUSHING concern this stream only (its own chain function returns them); errors stop the element */
-            g_atomic_int_set(&p->src_ret, (gint)r);
+            /* EOS / FLUSHING concern this stream only (its own chain function returns them); errors stop the element.
+             * A FLUSHING that comes from the element's own shutdown (pads already deactivated while the queued batches
+             * drain, PAUSED -> READY) is not a state of the stream and is not remembered. */
+            if (!(r == GST_FLOW_FLUSHING && s->stop)) g_atomic_int_set(&p->src_ret, (gint)r);
             if (r != GST_FLOW_EOS && r != GST_FLOW_FLUSHING && ret == GST_FLOW_OK) ret = r;
         } else if (g_atomic_int_get(&p->src_ret) == GST_FLOW_FLUSHING) {
             g_atomic_int_set(&p->src_ret, GST_FLOW_OK);   /* the flush is over */
@@ -543,7 +545,14 @@ static gboolean bf_sink_event(GstPad *pad, GstObject *parent, GstEvent *ev) {
             for (guint i = 0; i < s->pads->len; i++) gst_pad_push_event(((BfPad *)g_ptr_array_index(s->pads, i))->src, gst_event_new_eos());
         return TRUE;
     }
+    case GST_EVENT_FLUSH_STOP:
     case GST_EVENT_STREAM_START:
+        /* a new stream / the end of a flushing seek: whatever the last push on this pad returned is history */
+        g_atomic_int_set(&p->src_ret, GST_FLOW_OK);
+        g_mutex_lock(&s->lock);
+        p->eos = FALSE;
+        g_mutex_unlock(&s->lock);
+        return gst_pad_push_event(p->src, ev);
     case GST_EVENT_SEGMENT:
         return gst_pad_push_event(p->src, ev);
     default:
@@ -583,6 +592,11 @@ static GstStateChangeReturn bf_change_state(GstElement *e, GstStateChange t) {
         g_mutex_lock(&s->lock);
         s->stop = FALSE;
         s->push_ret = GST_FLOW_OK;
+        for (guint i = 0; i < s->pads->len; i++) {   /* a restart begins with clean per-pad flow returns */
+            BfPad *bp = g_ptr_array_index(s->pads, i);
+            g_atomic_int_set(&bp->src_ret, GST_FLOW_OK);
+            bp->eos = FALSE;
+        }
         for (guint g = 0; g < BF_PUSHERS; g++)
             if (!s->pusher[g].th) {
                 s->pusher[g].s = s;

@@ -59,6 +59,39 @@ def test_new_sort_kat():
             assert st[k] == dets[i][k]
 
 
+def test_observation_model_kat():
+    """cova-rs/sort/src/lib.rs:250-274: two fresh trackers, predict(0) on each: history.last() (ids and timestamps cleared)
+    equals the detection exactly -- through the C-ABI (covahip_sort_tracker_predict)."""
+    d, k = KATS["sort_default"], KATS["observation_model"]
+    s = E._SortHandle(d["max_age"], d["min_hits"], d["iou_threshold"])
+    dets = _bb(k["dets"])
+    s.update(dets, 0)
+    assert s.num_trackers() == k["expect_trackers"]
+    for i in range(s.num_trackers()):
+        last = s.tracker_predict(i, k["predict_ts"])
+        assert last["has_track_id"] == 1 and last["has_timestamp"] == 1 and last["timestamp"] == k["predict_ts"]
+        for f in ("left", "top", "width", "height", "area"):
+            assert last[f] == dets[i][f]                       # exact equality, as the reference asserts
+        assert last["has_class_id"] == 0 and last["has_confidence"] == 0
+    assert s.num_trackers() == k["expect_trackers"]
+
+
+def test_create_tracker_kat():
+    """cova-rs/sort/src/tracker/mod.rs:154-165: new -> predict(0) -> update(Some(next)) (the reference's smoke test)."""
+    k = KATS["create_tracker"]
+    s = E._SortHandle(3, 3, 0.2)
+    s.update(_bb([k["bbox"]]), 0)                              # KalmanBoxTracker::new(0, &bbox, 0) (Sort creates it)
+    assert s.num_trackers() == 1 and s.tracker_info(0)["id"] == 0
+    prior = s.tracker_predict(0, 0)
+    for f, v in zip(("left", "top", "width", "height"), k["bbox"]):
+        assert prior[f] == v
+    s.tracker_update(0, _bb([k["next_bbox"]])[0])
+    info = s.tracker_info(0)
+    assert info["hit_streaks"] == 1 and np.isfinite([info["state"][f] for f in ("left", "top", "width", "height")]).all()
+    s.tracker_update(0, None)                                  # update(None): the streak ends
+    assert s.tracker_info(0)["hit_streaks"] == 0
+
+
 def test_match_dets_kat():
     """lib.rs:384-407: after the second frame only tracker 1 is matched (to detection 0), so
     tracker 0 has hit_streaks 0, tracker 1 has 1, and two new trackers are born."""
