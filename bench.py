@@ -91,7 +91,7 @@ def kernel_bytes_per_frame():
     return out
 
 
-PMC_KERNEL_KEYS = {"enc0_mfma": "enc0_mfma", "enc0p_mfma": "enc0p_mfma", "enc1t_mfma": "enc_mfma<16, 32", "enc1_mfma": "enc_mfma<16, 32", "enc2_mfma": "enc_mfma<32, 64",
+PMC_KERNEL_KEYS = {"enc0p_mfma": "enc0p_mfma", "enc1_mfma": "enc1_mfma<", "enc2_mfma": "enc_mfma<32, 64",
                    "enc3_mfma": "enc_mfma<64, 128", "dec0_mfma": "dec_mfma<0, 128", "dec1_mfma": "dec_mfma<64, 64",
                    "dec2_mfma": "dec_mfma<32, 32", "dec012_mfma": "dec012_mfma", "dec3_final_mfma": "dec_mfma<16, 16", "dec3_bboxcc_fused": "dec3cc_mfma",
                    "bboxcc_kernel": "bboxcc_kernel"}
@@ -609,11 +609,11 @@ def main():
         kbytes = kernel_bytes_per_frame()
         hs, ws = level_dims()
         # carrier path: level 0 up to the pool once per carrier frame; level 1 + level 0's temporal MLP + the gather per stack
-        nfr = frames.shape[0]
+        nfr = frames.shape[0] if args.entry == "frames" else T * B     # (the stacked tensor is T * B carrier frames)
         macs["enc0p_mfma"] = hs[0] * ws[0] * 9 * 3 * 16 * nfr / B
         kbytes["enc0p_mfma"] = (hs[0] * ws[0] * 4 + hs[1] * ws[1] * 16 * 2) * nfr / B
-        macs["enc1t_mfma"] = macs["enc1_mfma"] + hs[1] * ws[1] * 16 * 32
-        kbytes["enc1t_mfma"] = kbytes["enc1_mfma"] + hs[1] * ws[1] * 16 * 2
+        macs["enc1_mfma"] += hs[1] * ws[1] * 16 * 32            # + level 0's temporal MLP (applied while staging)
+        kbytes["enc1_mfma"] += hs[1] * ws[1] * 16 * 2           # + the T = 0 skip slice
         dom_s = dom_ms / dom_n * 1e-3
         cc_s = cc_ms * 1e-3
         cc_gbs = B * H_MB * W_MB / cc_s / 1e9

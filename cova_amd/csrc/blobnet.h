@@ -46,7 +46,7 @@ struct covahip_blobnet {
     struct Prepared *prep = nullptr;
     int fuse_tail = 1;  // MFMA path, with bboxcc requested: last decoder block + bboxcc in one launch
     int fuse_dec = 1;  // MFMA path: decoder blocks 0..2 as one launch (a frame's three input tiles side by side in LDS) when they fit
-    int enc1_wide16 = 1;  // MFMA path: level 1 on sixteen-channel waves (enc1w_mfma) where the row fits its fixed LDS stride
+    int enc1_tile16 = 1;  // MFMA path: level 1 on 16-position tiles (enc1_mfma) where the row fits its fixed LDS stride
     int64_t macs_per_frame = 0;
 };
 

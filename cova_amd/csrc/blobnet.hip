@@ -51,12 +51,17 @@ int covahip_blobnet_geometry(covahip_ctx *ctx, int *h, int *w) {
 }
 
 // BlobNet forward (+ optionally bboxcc) on device pointers, asynchronous on the ctx stream.
+static int ensure_pbuf(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, int n_frames);
 static int filter_dev(covahip_ctx *ctx, const BnInput &in, int batch, float *d_logits, uint8_t *d_mask,
                       bool with_cc, int area_thresh, covahip_box *d_boxes, int32_t *d_counts, int max_boxes) {
     covahip_blobnet *m = ctx->blobnet;
     if (!m) return COVAHIP_ERR_NOT_LOADED;
     if (batch > m->max_batch) return COVAHIP_ERR_INVALID_ARG;
     if (batch == 0) return COVAHIP_OK;
+    if (in.stack) {   // the stacked tensor is batch * T carrier frames (blobnet_mfma.hip)
+        const int rc = ensure_pbuf(ctx, m, m->ws[ctx->cur_lane], batch * BN_T);
+        if (rc) return rc;
+    }
     BnCcTail tail{area_thresh, max_boxes, d_boxes, d_counts};
     bool cc_done = false;
     int rc = blobnet_forward_mfma(ctx, m, m->ws[ctx->cur_lane], in, batch, d_logits, d_mask, with_cc ? &tail : nullptr, &cc_done);
@@ -109,7 +114,11 @@ static int prepare_frames(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws,
     in.frames = d_frames;
     in.n_frames = n_frames;
     in.index = ws.d_index;
-    // the tensor P of pooled level-0 values, one slice per carrier frame
+    return ensure_pbuf(ctx, m, ws, n_frames);
+}
+
+// The tensor P of pooled level-0 values, one slice per carrier frame (the stacked entry has batch * T of them).
+static int ensure_pbuf(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, int n_frames) {
     if (ws.pbuf_frames < (size_t)n_frames) {
         // grown in whole steps; the pad row / column of P (odd grids) is zeroed here and never written
         const size_t want = std::min((size_t)BN_T * m->max_batch, std::max((size_t)n_frames, 2 * ws.pbuf_frames));
@@ -259,7 +268,7 @@ int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl) {
     if (!ctx || !ctx->blobnet) return COVAHIP_ERR_NOT_LOADED;
     if (impl != 1 && impl != 4 && impl != 5) return COVAHIP_ERR_INVALID_ARG;
     ctx->blobnet->fuse_dec = impl != 4;
-    ctx->blobnet->enc1_wide16 = impl != 5;
+    ctx->blobnet->enc1_tile16 = impl != 5;
     return COVAHIP_OK;
 }
 

@@ -61,7 +61,7 @@ struct DecPrep {
 struct Prepared {
     EncPrep enc[BN_LEVELS];
     DecPrep dec[BN_LEVELS - 1];
-    size_t enc1w;    // level 1 again, in the fragment order of enc1w_mfma: [2 N tiles][5 K steps][64] x half8
+    size_t enc1w;    // level 1 again, in the fragment order of enc1_mfma: [2 N tiles][5 K steps][64] x half8
     size_t final_w;  // B fragments of the folded (convT 32->16) x (1x1 16->1) last block: [KSTEPS][64] x half8
     size_t final_epi;  // folded bias (fp32)
     size_t zero;     // 256 zero bytes (LDS-DMA source for halo chunks)
@@ -256,18 +256,6 @@ struct ItemIter {
 };
 
 // ------------------------------------------------------------------ geometry structs
-struct Enc0Args {
-    const uint8_t *in;  // [B][T][H][W][4]
-    __half *out;        // [B][T][Ho][Wo][16]
-    const half8 *wfrag;
-    const float *epi;
-    int B, H, W, Hp, Wp, Ho, Wo, oy, ox;
-    int RB, nbands, TR, TC;
-    uint32_t mWp, mNb, mW4;
-    int scr_off;   // byte offset of the per-wave output transpose scratch (1 KB per wave) in LDS
-    ItemPlan plan;
-};
-
 struct EncArgs {
     const __half *in;  // [B][T][H][W][CIN]
     __half *out;       // [B][To][Ho][Wo][COUT]
@@ -307,179 +295,30 @@ struct DecArgs {
 };
 
 // ------------------------------------------------------------------ enc level 0
-// u8 RGBA stack -> conv3x3 (3->16) on v_mfma_f32_16x16x32_f16.
+// u8 RGBA carrier frame -> conv3x3 (3->16) on v_mfma_f32_16x16x32_f16.
 // K layout: one K-step = 2 kernel rows x (4 pixels x 4 channels); pixel 3 and channel 3
 // carry zero weights, the 1/6 of clip(x,0,6)/6 is folded into the weights, so the LDS tile
 // holds min(x,6) as exact small integers in fp16, 8 bytes per macroblock.
 // Tile: row r <-> input row y0-1+r, col c <-> input col c-2 (cols 0,1 and W+2,W+3 are zero),
 // TC = W+4 so rows are 16-byte multiples and 4-pixel groups land 16-byte aligned.
+// One tile = 8 pool windows.  The 16 rows of an MFMA are the 8 windows x 2 conv rows (dy) of ONE column parity: conv
+// pixels with even x and with odd x go to two MFMAs with two weight sets, so that the 4-pixel K group every lane reads
+// starts at an even tile column, i.e. is one 16-byte aligned ds_read_b128:
+//   even x: tile cols [x, x+3]   = inputs x-2..x+1 -> weights [0, k0, k1, k2]
+//   odd  x: tile cols [x+1, x+4] = inputs x-1..x+2 -> weights [k0, k1, k2, 0]
+// (tile col = input col + 2).  D rows 4*(lane>>4)+r -> window 2*(lane>>4) + (r>>1), dy = r&1, so both windows of a lane
+// pool in-register over {even, odd} x {dy}.
+// u8 -> fp16 without integer->float conversions: v_perm builds the fp16 bit pattern 0x6400 | n (= 1024 + n, exact for
+// n < 1024) for two channels at a time, then a packed min with 1030 (the clip at 6) and a packed subtract of 1024.  The
+// alpha byte lands in channel 3, whose weights are zero.
 constexpr int WG0 = 512;  // 8 waves: the per-tile dependency chain is latency bound, so run 4 waves per SIMD
-template <bool ALLPOS>
-__global__ __launch_bounds__(WG0, 4) void enc0_mfma(Enc0Args p) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int TR = p.TR, TC = p.TC;
-    const int tsz = TR * TC * 8;  // bytes per T slice
-
-    const half8 be0 = p.wfrag[lane], be1 = p.wfrag[64 + lane];          // even-x weight set
-    const half8 bo0 = p.wfrag[128 + lane], bo1 = p.wfrag[192 + lane];   // odd-x weight set
-    const int co = lane & 15;
-    const float e0 = p.epi[co], e1 = p.epi[16 + co], e2 = p.epi[32 + co];   // see pool4
-    const TmixW tm = load_tmix(p.epi + 48, lane);
-
-    ItemIter it;
-    for (bool more = it.start(p.plan, p.B, p.nbands); more; more = it.next(p.plan, p.B, p.nbands)) {
-        const int b = it.b, band = it.band;
-        // balanced bands of whole pool-window rows
-        const int y0 = 2 * ((band * p.Hp) / p.nbands);
-        const int rows = 2 * (((band + 1) * p.Hp) / p.nbands) - y0;
-        const int n2 = rows + 2;
-        lds_barrier();
-        // ---- stage: a thread owns (row, 4-pixel group) chunks and fetches them for all four T slices
-        // (one address computation, all global loads issued before the first conversion).
-        // u8 -> fp16 without integer->float conversions: v_perm builds the fp16 bit pattern 0x6400 | n
-        // (= 1024 + n, exact for n < 1024) for two channels at a time, then a packed min with 1030
-        // (the clip at 6) and a packed subtract of 1024.  The alpha byte lands in channel 3, whose
-        // weights are zero.
-        {
-            const int W4 = p.W >> 2;                  // 16-byte chunks (4 macroblocks) per image row
-            const int per_t = n2 * W4;
-            constexpr int KQ = 2;                     // chunk positions per thread this kernel is sized for (host checks)
-            const size_t tplane = (size_t)p.H * p.W * 4;
-            const uint8_t *fb = p.in + (size_t)b * BN_T * tplane;
-            uint4 v[KQ][BN_T];
-            int dsto[KQ];
-#pragma unroll
-            for (int k = 0; k < KQ; k++) {
-                const int i = tid + k * WG0;
-                dsto[k] = -1;
-                if (i < per_t) {
-                    const int r = fdiv(i, p.mW4), c4 = i - r * W4;
-                    const int y = y0 - 1 + r;
-                    dsto[k] = r * TC * 8 + 16 + c4 * 32;
-                    const bool in = y >= 0 && y < p.H;
-                    const uint8_t *src = fb + ((size_t)y * p.W + c4 * 4) * 4;
-#pragma unroll
-                    for (int t = 0; t < BN_T; t++)
-                        v[k][t] = in ? *reinterpret_cast<const uint4 *>(src + t * tplane) : make_uint4(0, 0, 0, 0);
-                }
-            }
-            const half2v clip = {(_Float16)1030.f, (_Float16)1030.f}, off = {(_Float16)1024.f, (_Float16)1024.f};
-#pragma unroll
-            for (int k = 0; k < KQ; k++) {
-                if (dsto[k] >= 0) {
-#pragma unroll
-                    for (int t = 0; t < BN_T; t++) {
-                        const uint32_t px[4] = {v[k][t].x, v[k][t].y, v[k][t].z, v[k][t].w};
-                        uint32_t o[8];
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const uint32_t c01 = __builtin_amdgcn_perm(0x64646464u, px[q], 0x05010500u);
-                            const uint32_t c23 = __builtin_amdgcn_perm(0x64646464u, px[q], 0x05030502u);
-                            const half2v h01 = __builtin_elementwise_min(__builtin_bit_cast(half2v, c01), clip) - off;
-                            const half2v h23 = __builtin_elementwise_min(__builtin_bit_cast(half2v, c23), clip) - off;
-                            o[2 * q] = __builtin_bit_cast(uint32_t, h01);
-                            o[2 * q + 1] = __builtin_bit_cast(uint32_t, h23);
-                        }
-                        uint8_t *d = smem + t * tsz + dsto[k];
-                        *reinterpret_cast<uint4 *>(d) = make_uint4(o[0], o[1], o[2], o[3]);        // tile cols 4c+2, 4c+3
-                        *reinterpret_cast<uint4 *>(d + 16) = make_uint4(o[4], o[5], o[6], o[7]);   // tile cols 4c+4, 4c+5
-                    }
-                }
-            }
-            // zero halo columns 0,1 and W+2,W+3 of every (t, row)
-            for (int i = tid; i < BN_T * n2 * 2; i += WG0) {
-                const int rr = i >> 1;
-                const int t = (rr >= n2) + (rr >= 2 * n2) + (rr >= 3 * n2);
-                const int r = rr - t * n2;
-                *reinterpret_cast<uint4 *>(smem + t * tsz + r * TC * 8 + ((i & 1) ? (p.W + 2) * 8 : 0)) =
-                    make_uint4(0, 0, 0, 0);
-            }
-        }
-        lds_barrier();
-        // ---- compute.  One tile = 8 pool windows.  The 16 rows of an MFMA are the 8 windows x 2
-        // conv rows (dy) of ONE column parity: conv pixels with even x and with odd x go to two MFMAs
-        // with two weight sets, so that the 4-pixel K group every lane reads starts at an even tile
-        // column, i.e. is one 16-byte aligned ds_read_b128:
-        //   even x: tile cols [x, x+3]   = inputs x-2..x+1 -> weights [0, k0, k1, k2]
-        //   odd  x: tile cols [x+1, x+4] = inputs x-1..x+2 -> weights [k0, k1, k2, 0]
-        // (tile col = input col + 2).  D rows 4*(lane>>4)+r -> window 2*(lane>>4) + (r>>1), dy = r&1,
-        // so both windows of a lane pool in-register over {even, odd} x {dy}.
-        const int nwin = (rows / 2) * p.Wp;
-        const int ntiles = (nwin + 7) / 8;
-        const int m = lane & 15, g = lane >> 4;
-        for (int tile = wave; tile < ntiles; tile += WG0 / 64) {
-            const int win = min(tile * 8 + (m >> 1), nwin - 1);
-            const int wy = fdiv(win, p.mWp), wx = win - wy * p.Wp;
-            const int yy = 2 * wy + (m & 1), xe = 2 * wx;
-            // K-step 0: kernel rows 0/1 (g>>1), pixel pair g&1; K-step 1: kernel row 2 (zero weights for g>>1 == 1)
-            const int offe0 = ((yy + (g >> 1)) * TC + xe + 2 * (g & 1)) * 8;
-            const int offe1 = ((yy + 2) * TC + xe + 2 * (g & 1)) * 8;
-            float pooled[2][BN_T];
-#pragma unroll
-            for (int t = 0; t < BN_T; t++) {
-                const uint8_t *base = smem + t * tsz;
-                const half8 ae0 = *reinterpret_cast<const half8 *>(base + offe0);
-                const half8 ae1 = *reinterpret_cast<const half8 *>(base + offe1);
-                const half8 ao0 = *reinterpret_cast<const half8 *>(base + offe0 + 16);
-                const half8 ao1 = *reinterpret_cast<const half8 *>(base + offe1 + 16);
-                f32x4 ce = {0.f, 0.f, 0.f, 0.f}, co_ = {0.f, 0.f, 0.f, 0.f};
-                ce = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae0, be0, ce, 0, 0, 0);
-                co_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao0, bo0, co_, 0, 0, 0);
-                ce = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae1, be1, ce, 0, 0, 0);
-                co_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao1, bo1, co_, 0, 0, 0);
-                pooled[0][t] = pool4<ALLPOS>(ce[0], ce[1], co_[0], co_[1], e0, e1, e2);
-                pooled[1][t] = pool4<ALLPOS>(ce[2], ce[3], co_[2], co_[3], e0, e1, e2);
-            }
-            // ---- store through a wave-private LDS transpose: the lanes drop their 2-byte values into
-            // S[t][window][channel] (the global layout of the tile: 32 contiguous bytes per window and T
-            // slice) and every lane then moves one 16-byte piece, so a tile leaves the wave as ONE
-            // global_store_dwordx4 instead of eight 2-byte stores.  LDS operations of one wave execute
-            // in order, so no workgroup barrier is involved.
-            const uint32_t tstride = (uint32_t)(p.Ho * p.Wo * 16);
-            __half *const ob = p.out + (size_t)b * BN_T * tstride;   // wave-uniform; lanes add a 32-bit offset
-            uint8_t *const scr = smem + p.scr_off + wave * 1024;
-            half4 pb2[2], o2[2];
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                // opaque fp32 values: the BN multiply-add must round to fp32 and THEN to fp16, as enc0p_mfma does (hipcc
-                // would otherwise fuse both into one v_fma_mixlo_f16 and the two entry points would differ in the last bit)
-#pragma unroll
-                for (int t = 0; t < BN_T; t++) asm volatile("" : "+v"(pooled[q][t]));
-                pb2[q] = __builtin_convertvector((f32x4){pooled[q][0], pooled[q][1], pooled[q][2], pooled[q][3]}, half4);
-            }
-            tmix4h<2>(tm, pb2, o2);
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const half4 o = o2[q];
-                _Float16 *sw = reinterpret_cast<_Float16 *>(scr + (2 * g + q) * 32) + co;
-#pragma unroll
-                for (int t = 0; t < BN_T; t++) sw[t * 128] = o[t];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            {
-                const int owin = tile * 8 + ((lane >> 1) & 7);
-                if (owin < nwin) {
-                    const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
-                    const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
-                    const uint32_t eo = (uint32_t)((gy * p.Wo + gx) * 16 + 8 * (lane & 1));
-                    const uint4 v = *reinterpret_cast<const uint4 *>(scr + lane * 16);
-                    *reinterpret_cast<uint4 *>(ob + (lane >> 4) * tstride + eo) = v;
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------ enc level 0, one carrier frame at a time
-// Carrier-frame entry point (covahip_filter_forward_frames): conv + ReLU + BN + pool of level 0 work on single T
-// slices (kernel depth 1, encoder.py:35-52), and with gamma = 1 a carrier frame is a slice of four consecutive
-// stacks.  This kernel runs that part ONCE per carrier frame and leaves the pooled values -- the input of the
-// level's temporal MLP -- as an fp16 tensor P [F][Ho][Wo][16]; the MLP itself moves into the staging of level 1
-// (enc_mfma<.., PRE>), which gathers the four frames of a stack by index.  Same tiles, same MFMA operands and the
-// same rounding point (tmix4h) as enc0_mfma, so both entry points compute identical bits.
+// ------------------------------------------------------------------ enc level 0, one carrier frame (= one T slice) at a time
+// conv + ReLU + BN + pool of level 0 work on single T slices (kernel depth 1, encoder.py:35-52), and with gamma = 1 a
+// carrier frame is a slice of four consecutive stacks.  This kernel runs that part ONCE per carrier frame and leaves the
+// pooled values -- the input of the level's temporal MLP -- as an fp16 tensor P [F][Ho][Wo][16]; the MLP itself moves
+// into the staging of level 1 (enc1_mfma / enc_mfma<.., PRE>), which gathers the four frames of a stack by index.
+// BOTH entry points run it (round 4): the stacked tensor [B][T*H][W][4] of covahip_filter_forward is B*T carrier frames
+// whose stack b takes its T = 0..3 slices from frames 4b .. 4b+3 -- one kernel chain, identical bits by construction.
 struct Enc0pArgs {
     const uint8_t *in;  // [F][H][W][4]
     __half *out;        // [F][Ho][Wo][16]
@@ -697,8 +536,12 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
             // below could not be issued before those have drained
             typedef int i32x4 __attribute__((ext_vector_type(4)));
             typedef const __attribute__((address_space(4))) i32x4 *const_i32x4_ptr;
-            const i32x4 row = *(const_i32x4_ptr)(uintptr_t)(p.pidx + sb * BN_T);
-            fidx[0] = row[0]; fidx[1] = row[1]; fidx[2] = row[2]; fidx[3] = row[3];
+            if (p.pidx) {
+                const i32x4 row = *(const_i32x4_ptr)(uintptr_t)(p.pidx + sb * BN_T);
+                fidx[0] = row[0]; fidx[1] = row[1]; fidx[2] = row[2]; fidx[3] = row[3];
+            } else {   // stacked entry: stack sb = frames 4 sb .. 4 sb + 3
+                fidx[0] = BN_T * sb; fidx[1] = BN_T * sb + 1; fidx[2] = BN_T * sb + 2; fidx[3] = BN_T * sb + 3;
+            }
         }
         const int RC = TC * CPP;  // chunks per tile row
         const int nchunk = sn2 * RC;
@@ -973,298 +816,57 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     WGSPAN_END(COUT == 32 ? 0 : COUT == 64 ? 1 : 2);
 }
 
-// ------------------------------------------------------------------ enc level 1, sixteen-channel waves (round 4)
-// conv3x3 16 -> 32 on v_mfma_f32_16x16x32_f16: a wave owns 16 output channels (N) and tiles of 4 pool windows x 4
-// positions (M = 16); one K step = TWO taps x 16 input channels, five K steps (the tenth tap carries zero weights).
-// Against enc_mfma<16,32>: 20 weight registers instead of 36, 16 accumulator registers (all four T slices) instead
-// of 32 (two at a time) -> 64 registers per lane, EIGHT waves per SIMD (two workgroups of sixteen waves per CU)
-// instead of four.  What that buys is independent chains per CU: the launch is a chain of short phases per item
-// (request, landing, temporal MLP, barrier, tiles, epilogue), and the phases of a workgroup's item shrink with the
-// number of waves that share them (one 16-byte piece per thread to stage, at most three tiles per wave).
+// ------------------------------------------------------------------ enc level 1 on 16-position tiles (round 4)
+// conv3x3 16 -> 32 on v_mfma_f32_16x16x32_f16: tiles of 4 pool windows x 4 positions (M = 16), a wave owns both
+// 16-channel N tiles of its tile; one K step = TWO taps x 16 input channels, five K steps (the tenth tap carries zero
+// weights).  Eight waves per workgroup (40 weight + 16 accumulator + 16 ring registers: 128 per lane), two workgroups
+// per CU.  Against enc_mfma<16,32> (32x32x16 products, swizzled band, LDS-DMA; kept for grids wider than this kernel's
+// fixed LDS row and as the A/B partner, covahip_blobnet_set_impl(ctx, 5)):
 //   * LDS band: [T][row][pixel][16 ch] with a FIXED row stride of E1_RS bytes == 128 mod 256 -- with the 16x16 lane map
 //     (lane = 16 * (tap-of-the-pair, channel half) + position) every ds_read_b128 lane group then covers all 64 banks
 //     once, without a swizzle.  No swizzle means the address of every fragment of a tile is ONE per-lane base plus a
 //     compile-time constant (tap, T slice): twenty ds_read_b128 with immediate offsets, no address arithmetic between
-//     the products (the swizzled form spends seven vector instructions per tap).
-//   * staging through registers (global_load -> [temporal MLP of the level below] -> ds_write_b128): in the
-//     carrier-frame form (PRE) every piece goes through the vector ALU anyway, the T = 0 result leaves for the skip
-//     tensor straight from the registers, and a kernel without LDS-DMA keeps hipcc from draining the vector-memory
-//     counter in front of LDS reads (it does that in every kernel that has one: an LDS-DMA is a pending LDS write).
-//     The loads of an item are issued BEFORE the barrier that ends the previous item.
+//     the products (the swizzled form spends seven vector instructions per tap), and every fragment feeds two products;
+//   * staging through registers (global_load -> temporal MLP of the level below -> ds_write_b128): every piece goes
+//     through the vector ALU anyway, the T = 0 result leaves for the skip tensor straight from the registers, and a
+//     kernel without LDS-DMA keeps hipcc from draining the vector-memory counter in front of LDS reads (it does that in
+//     every kernel that has one: an LDS-DMA is a pending LDS write).  The loads of an item are issued BEFORE the barrier
+//     that ends the previous item;
+//   * tiles of 16 positions: 23 per three-row band over 8 waves (3 + 3 + ... + 2) where 32-position tiles gave 12 over 8.
+// Measured on one box (HIP events, b = 256, 68x120): 32.0 us against 36.1 for enc_mfma<16,32,PRE>; a form with sixteen
+// waves of 16 channels each (64 registers, eight waves per SIMD -- the candidate round 3 named) 34.6: it reads every
+// fragment for ONE product and needs the LDS array's full 256 B/clk to keep the matrix pipe busy.
 // Reference semantics: encoder.py:58-80 (conv -> ReLU -> BN -> pool -> pad -> PointWiseTN), pointwise.py:16-26.
 constexpr int E1_RS = 2176;              // bytes per band row: 66 pixels x 32 B + 64 B, == 128 mod 256
 constexpr int E1_TR = 8;                 // band rows per T slice (three pool-window rows + halo)
 constexpr int E1_TSZ = E1_RS * E1_TR;    // bytes per T slice
-constexpr int E1_MAXW = 65;              // (W + 2) * 32 + 32 <= E1_RS: the zero-weight tap of the last K step reads one pixel past the row
-struct Enc1wArgs {
-    const __half *in;    // stacked: act[1] [B][T][H][W][16]; PRE: P [F][H][W][16]
+constexpr int E1_MAXW = 62;              // 8 rows x 2 (W + 2) pieces <= 2 pieces per thread; (W + 2) * 32 + 32 <= E1_RS (the
+                                         // zero-weight tap of the last K step reads one pixel past the row)
+struct Enc1Args {
+    const __half *in;    // P [F][H][W][16]: pooled level-0 values per carrier frame (enc0p_mfma)
     __half *out;         // [B][T][Ho][Wo][32]
     const half8 *wfrag;  // [2 N tiles][5 K steps][64 lanes]
     const float *epi;    // e0[32], e1[32], e2[32] (pool4), w1[16], w2[16]
     int B, H, W, Hp, Wp, Ho, Wo, oy, ox;
     int nbands;
     uint32_t mWp, mRC;   // magic of Wp and of 2 * (W + 2)
-    int scr_off;         // per-wave store scratch (512 B per wave) behind the band
+    int scr_off;         // per-wave store scratch (1 KB per wave) behind the band
     ItemPlan plan;
-    const int32_t *pidx; // PRE: frames of the T = 0..3 slices of every stack
-    __half *skip;        // PRE: [B][T][H][W][16], T = 0 written
-    const float *tm_pre; // PRE: w1[16], w2[16] of the level below
-    int stagger;         // developer knob: the second workgroup of every CU starts this many x 1,024 cycles late
+    const int32_t *pidx; // frames of the T = 0..3 slices of every stack; null: stack b = frames 4b .. 4b+3 (stacked entry)
+    __half *skip;        // [B][T][H][W][16], T = 0 written (the decoder's skip input)
+    const float *tm_pre; // w1[16], w2[16] of the level below
 };
-// Per-lane constants live in a small LDS table instead of registers (the register budget is 64 per lane, and hipcc keeps
-// every loop-invariant load in a register for the whole kernel -- and then spills it):
+// Per-lane constants live in a small LDS table behind the scratch instead of registers (hipcc keeps every loop-invariant
+// load in a register for the whole kernel):
 //   [0, 384)    e0[32], e1[32], e2[32]                      (pool4)
 //   [384, 448)  this level's temporal MLP: rows lane % 4 of W1^T and W2^T as fp16 (TmixW::a1, a2), 16 B per lane % 4
-//   [448, 512)  PRE: the same for the level below
+//   [448, 512)  the same for the level below
 constexpr int E1_CONST = 512;
 #ifndef E1_ABL
-#define E1_ABL 0   // developer builds (tools/ablate_enc1w.sh): 1 no temporal MLP, 2 no products, 3 no tile epilogue, 4 no tiles, 5 no staging
+#define E1_ABL 0   // developer builds (tools/ablate_enc1.sh): 1 no temporal MLP, 3 no tile epilogue, 4 no tiles, 5 no staging
 #endif
-template <int NWV, bool ALLPOS, bool PRE>
-__global__ __launch_bounds__(NWV * 64, NWV / 2) void enc1w_mfma(Enc1wArgs p) {
-    constexpr int WGS = NWV * 64, MG = NWV / 2;
-    constexpr int AD = 4;   // A fragments in flight ahead of their product
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    WGSPAN_BEGIN();
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: everything derived from it stays scalar
-    const int ntile = wave & 1, mgroup = wave >> 1;
-    // the row pads are read (by the zero-weight half of the last K step) and never written: finite once, finite for good
-    for (int i = tid; i < BN_T * E1_TSZ / 16; i += WGS) *reinterpret_cast<uint4 *>(smem + i * 16) = make_uint4(0, 0, 0, 0);
-    uint8_t *const cst = smem + p.scr_off + NWV * 512;
-    if (tid < 96) reinterpret_cast<float *>(cst)[tid] = p.epi[tid];
-    if (tid >= 128 && tid < 136) {
-        const int i = tid & 3;
-        const float *tmw = (tid & 4) ? p.tm_pre : p.epi + 96;
-        if (PRE || !(tid & 4)) {
-            half4 a1, a2;
-#pragma unroll
-            for (int t = 0; t < BN_T; t++) { a1[t] = (_Float16)tmw[t * BN_T + i]; a2[t] = (_Float16)tmw[16 + t * BN_T + i]; }
-            *reinterpret_cast<half4 *>(cst + 384 + (tid & 4) * 16 + i * 16) = a1;
-            *reinterpret_cast<half4 *>(cst + 384 + (tid & 4) * 16 + i * 16 + 8) = a2;
-        }
-    }
-    const int RCr = 2 * (p.W + 2);                         // 16-byte pieces per band row (without the pad)
-    const uint32_t plane = (uint32_t)p.H * p.W * 32;       // bytes per frame / T slice
-    if (p.stagger > 0 && (int)blockIdx.x >= ((int)gridDim.x >> 1))
-        for (int k = 0; k < p.stagger; k++) __builtin_amdgcn_s_sleep(16);
-
-    ItemIter it;
-    int item_no = (int)blockIdx.x >= ((int)gridDim.x >> 1) ? 1 : 0;
-    for (bool more = it.start(p.plan, p.B, p.nbands); more; more = it.next(p.plan, p.B, p.nbands)) {
-        const int b = it.b, band = it.band;
-        const int y0 = 2 * ((band * p.Hp) / p.nbands);
-        const int rows = 2 * (((band + 1) * p.Hp) / p.nbands) - y0;
-        const int n2 = rows + 2;
-        if (p.stagger == -1) {
-            if (item_no & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-            item_no++;
-        } else if (p.stagger == -2) {
-            if (item_no & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
-        }
-        // the lane id, recomputed per item (two instructions): nothing derived from it lives across items, where the 64
-        // registers per lane are all taken
-        auto lane_id = []() -> int {   // opaque seed: hipcc would otherwise hoist the (loop-invariant) result and spill it
-            uint32_t zero = 0;
-            asm volatile("" : "+v"(zero));
-            return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
-        };
-        const int ll = lane_id();
-        // ---- stage rows y0-1 .. y0+rows of the four T slices: one 16-byte piece (8 channels of a pixel) of all four
-        // slices per thread; the loads are in flight across the barrier
-        int fidx[BN_T] = {0, 1, 2, 3};
-        const uint8_t *fbase = reinterpret_cast<const uint8_t *>(p.in);
-        if constexpr (PRE) {
-            // scalar load (constant address space): the table is uploaded before the launch and never written by a kernel
-            typedef int i32x4 __attribute__((ext_vector_type(4)));
-            typedef const __attribute__((address_space(4))) i32x4 *const_i32x4_ptr;
-            const i32x4 row = *(const_i32x4_ptr)(uintptr_t)(p.pidx + b * BN_T);
-            fidx[0] = row[0]; fidx[1] = row[1]; fidx[2] = row[2]; fidx[3] = row[3];
-        } else {
-            fbase += (size_t)b * BN_T * plane;
-        }
-        const int ya = y0, yb = (band == p.nbands - 1) ? p.H : y0 + rows;   // rows whose T = 0 slice this item owns (PRE)
-        const int nreal = n2 * RCr;
-        const int i = wave * 64 + ll;    // the host keeps 8 * RCr <= WGS: one piece per thread
-        // (branch-free: every thread loads -- threads without a piece and halo pieces from a clamped address -- and only
-        // the LDS / skip writes are predicated; hipcc's register allocation across the barrier is far better for it)
-        const int ic = min(i, nreal - 1);
-        const int r = fdiv(ic, p.mRC), within = ic - r * RCr;
-        const int c = within >> 1, hf = within & 1;
-        const int y = y0 - 1 + r, x = c - 1;
-        const bool in = y >= 0 && y < p.H && x >= 0 && x < p.W;
-        const int dst = r * E1_RS + c * 32 + hf * 16;
-        const uint32_t eoff = (uint32_t)((min(max(y, 0), p.H - 1) * p.W + min(max(x, 0), p.W - 1)) * 32 + hf * 16);
-        const bool own = i < nreal && in && y >= ya && y < yb;
-        half8 v[BN_T];
-#pragma unroll
-        for (int t = 0; t < BN_T; t++) {
-            // scalar 64-bit base + 32-bit lane offset
-            const uint64_t fo = (uint64_t)(uint32_t)fidx[t] * plane;
-            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)fo), hi = __builtin_amdgcn_readfirstlane((uint32_t)(fo >> 32));
-            v[t] = *reinterpret_cast<const half8 *>(fbase + (((uint64_t)hi << 32) | lo) + eoff);
-        }
-        lds_barrier();   // every wave has left the previous item's band (first item: the table and the zeros are written)
-        if (!in) {
-#pragma unroll
-            for (int t = 0; t < BN_T; t++)
-#pragma unroll
-                for (int j = 0; j < 8; j++) v[t][j] = (_Float16)0;
-        }
-        const bool have = (E1_ABL != 5) && wave * 64 + lane_id() < nreal;   // (recomputed: cheaper than a register held across the MLP)
-        if constexpr (PRE && E1_ABL != 1 && E1_ABL != 5) {
-            // temporal MLP of the level below (zero padding stays zero: no bias): four channels = one 8-byte piece per T
-            // slice at a time, so that at most half of the results are held in registers
-            TmixW tmp;
-            {
-                const uint4 w = *reinterpret_cast<const uint4 *>(cst + 448 + (ll & 3) * 16);
-                tmp.a1 = __builtin_bit_cast(half4, make_uint2(w.x, w.y));
-                tmp.a2 = __builtin_bit_cast(half4, make_uint2(w.z, w.w));
-#pragma unroll
-                for (int t = 0; t < BN_T; t++) tmp.id[t] = (_Float16)(t == (ll & 3) ? 1.f : 0.f);
-            }
-            uint8_t *const skp = reinterpret_cast<uint8_t *>(p.skip) + (size_t)b * BN_T * plane + eoff;
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                half4 o[BN_T];
-#pragma unroll
-                for (int j0 = 0; j0 < 4; j0 += 2) {
-                    half4 pb[2];
-                    f32x4 rr[2];
-#pragma unroll
-                    for (int j = 0; j < 2; j++)
-                        pb[j] = half4{v[0][4 * h + j0 + j], v[1][4 * h + j0 + j], v[2][4 * h + j0 + j], v[3][4 * h + j0 + j]};
-                    tmix4f<2>(tmp, pb, rr);
-#pragma unroll
-                    for (int j = 0; j < 2; j++)
-#pragma unroll
-                        for (int t = 0; t < BN_T; t++) o[t][j0 + j] = (_Float16)rr[j][t];
-                }
-                if (have) {
-#pragma unroll
-                    for (int t = 0; t < BN_T; t++) *reinterpret_cast<half4 *>(smem + t * E1_TSZ + dst + 8 * h) = o[t];
-                }
-                if (own) *reinterpret_cast<half4 *>(skp + 8 * h) = o[0];
-            }
-        } else {
-            if (have) {
-#pragma unroll
-                for (int t = 0; t < BN_T; t++) *reinterpret_cast<half8 *>(smem + t * E1_TSZ + dst) = v[t];
-            }
-        }
-        // the wave's weight fragments, (re)loaded per item: held across the staging they would not leave the temporal MLP
-        // its registers
-        half8 bf[5];
-        {
-            const half8 *wp = p.wfrag + ntile * 5 * 64 + ll;
-            asm volatile("" : "+v"(wp));
-#pragma unroll
-            for (int s = 0; s < 5; s++) bf[s] = wp[s * 64];
-        }
-        lds_barrier();   // the band is complete
-        // ---- tiles of 4 pool windows
-        const int m = ll & 15, kg = ll >> 4;
-        const int nwin = (rows / 2) * p.Wp;
-        const int ntiles = (nwin + 3) / 4;
-        const uint32_t tstride = (uint32_t)(p.Ho * p.Wo * 32);
-        __half *const ob = p.out + (size_t)b * BN_T * tstride;
-        uint8_t *const scr = smem + p.scr_off + wave * 512;
-        for (int tile = mgroup; tile < (E1_ABL == 4 ? 0 : ntiles); tile += MG) {
-            const int win = min(tile * 4 + (m >> 2), nwin - 1);
-            const int wy = fdiv(win, p.mWp), wx = win - wy * p.Wp;
-            const int yy0 = 2 * wy + ((m >> 1) & 1), xx0 = 2 * wx + (m & 1);
-            const int base = yy0 * E1_RS + xx0 * 32 + (kg & 1) * 16;
-            // K step s, lane half kg >> 1: taps (0,0)|(0,1), (1,0)|(1,1), (2,0)|(2,1) -> aH + s * RS; (0,2)|(1,2) -> aV + 64;
-            // (2,2)|zero weights -> aH + 2 RS + 64
-            const uint8_t *const aH = smem + base + (kg >> 1) * 32, *const aV = smem + base + (kg >> 1) * E1_RS;
-            // two T slices at a time (8 accumulator registers): order (T pair, K step, T of the pair)
-            auto frag = [&](int idx) -> half8 {
-                const int s = (idx % 10) >> 1, t = 2 * (idx / 10) + (idx & 1);
-                const uint8_t *a = s == 3 ? aV + 64 : s == 4 ? aH + 2 * E1_RS + 64 : aH + s * E1_RS;
-                return *reinterpret_cast<const half8 *>(__builtin_assume_aligned(a + t * E1_TSZ, 16));
-            };
-            half8 ab[AD];
-#pragma unroll
-            for (int k = 0; k < AD; k++) ab[k] = frag(k);
-            // the epilogue's constants, requested ahead of the products
-            const int co = ntile * 16 + m;
-            const float e0 = reinterpret_cast<const float *>(cst)[co], e1 = reinterpret_cast<const float *>(cst)[32 + co];
-            const float e2 = ALLPOS ? 0.f : reinterpret_cast<const float *>(cst)[64 + co];
-            const uint4 tw = *reinterpret_cast<const uint4 *>(cst + 384 + (m & 3) * 16);
-            f32x4 acc[2];
-            f32x4 pooled;
-            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < 20; k++) {
-                const int s = (k % 10) >> 1, tp = k & 1;
-#if E1_ABL == 2
-                asm volatile("" : "+v"(acc[tp]) : "v"(ab[k % AD]), "v"(bf[s]));
-#else
-                acc[tp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ab[k % AD], bf[s], s == 0 ? z4 : acc[tp], 0, 0, 0);
-#endif
-                if (k + AD < 20) ab[k % AD] = frag(k + AD);
-#if E1_ABL == 3
-                if (s == 4) asm volatile("" :: "v"(acc[tp]));
-                if (false) {
-#else
-                if (s == 4) {
-#endif
-                    // D row 4 * kg + r: window kg of the tile, position r; column m: channel co
-                    float pv = pool4<ALLPOS>(acc[tp][0], acc[tp][1], acc[tp][2], acc[tp][3], e0, e1, e2);
-                    asm volatile("" : "+v"(pv));   // one rounding point (fp32, then fp16) whatever the instantiation
-                    pooled[2 * (k / 10) + tp] = pv;
-                }
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, AD, 0);
-#pragma unroll
-            for (int k = 0; k < 20; k++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (k + AD < 20) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-#if E1_ABL == 3
-            asm volatile("" :: "v"(tw.x), "v"(e0), "v"(e1));
-            continue;
-#endif
-            TmixW tm;
-            tm.a1 = __builtin_bit_cast(half4, make_uint2(tw.x, tw.y));
-            tm.a2 = __builtin_bit_cast(half4, make_uint2(tw.z, tw.w));
-#pragma unroll
-            for (int t = 0; t < BN_T; t++) tm.id[t] = (_Float16)(t == (m & 3) ? 1.f : 0.f);
-            half4 o;
-            tmix4h(tm, __builtin_convertvector(pooled, half4), o);
-            // ---- store through a wave-private transpose: S[t][window][16 channels] (32 contiguous bytes per window and T
-            // slice in the output tensor); lane (window kg, m) then moves the 8 bytes (t = m >> 2, quarter m & 3) of ITS window
-            {
-                _Float16 *sw = reinterpret_cast<_Float16 *>(scr + kg * 32) + m;
-#pragma unroll
-                for (int t = 0; t < BN_T; t++) sw[t * 64] = o[t];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int owin = tile * 4 + kg;
-            const uint2 sv = *reinterpret_cast<const uint2 *>(scr + (m >> 2) * 128 + kg * 32 + (m & 3) * 8);
-            if (owin < nwin) {
-                const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
-                const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
-                const uint32_t eo = (uint32_t)((gy * p.Wo + gx) * 32 + ntile * 16 + 4 * (m & 3));
-                *reinterpret_cast<uint2 *>(ob + (m >> 2) * tstride + eo) = sv;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next tile's values stay behind this read
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    WGSPAN_END(0);
-}
-
-// ------------------------------------------------------------------ enc level 1, 32-channel waves on 16-position tiles
-// Same band layout, staging and addressing as enc1w_mfma, but a wave owns BOTH 16-channel N tiles of a 4-window tile: every
-// A fragment read from LDS feeds two products (half the LDS read traffic of enc1w_mfma, which needs the LDS array's full
-// 256 B/clk to keep the matrix pipe busy), the tile's epilogue handles 32 channels (half the per-tile vector instructions
-// per output) and a pixel's 64 output bytes leave in one piece.  Eight waves per workgroup (40 weight + 16 accumulator +
-// 16 ring registers: 128 per lane), two workgroups per CU.
-template <bool ALLPOS, bool PRE>
-__global__ __launch_bounds__(512, 4) void enc1v_mfma(Enc1wArgs p) {
+template <bool ALLPOS>
+__global__ __launch_bounds__(512, 4) void enc1_mfma(Enc1Args p) {
     constexpr int NWV = 8, WGS = NWV * 64, MG = NWV;
     constexpr int AD = 4;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1277,7 +879,7 @@ __global__ __launch_bounds__(512, 4) void enc1v_mfma(Enc1wArgs p) {
     if (tid >= 128 && tid < 136) {
         const int i = tid & 3;
         const float *tmw = (tid & 4) ? p.tm_pre : p.epi + 96;
-        if (PRE || !(tid & 4)) {
+        {
             half4 a1, a2;
 #pragma unroll
             for (int t = 0; t < BN_T; t++) { a1[t] = (_Float16)tmw[t * BN_T + i]; a2[t] = (_Float16)tmw[16 + t * BN_T + i]; }
@@ -1304,15 +906,15 @@ __global__ __launch_bounds__(512, 4) void enc1v_mfma(Enc1wArgs p) {
             return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
         };
         const int ll = lane_id();
-        int fidx[BN_T] = {0, 1, 2, 3};
-        const uint8_t *fbase = reinterpret_cast<const uint8_t *>(p.in);
-        if constexpr (PRE) {
+        // frames of the stack's T = 0..3 slices: a SCALAR load (constant address space; the table is uploaded before the
+        // launch and never written by a kernel); the stacked entry's frames are 4b .. 4b+3
+        int fidx[BN_T] = {BN_T * b, BN_T * b + 1, BN_T * b + 2, BN_T * b + 3};
+        const uint8_t *const fbase = reinterpret_cast<const uint8_t *>(p.in);
+        if (p.pidx) {
             typedef int i32x4 __attribute__((ext_vector_type(4)));
             typedef const __attribute__((address_space(4))) i32x4 *const_i32x4_ptr;
             const i32x4 row = *(const_i32x4_ptr)(uintptr_t)(p.pidx + b * BN_T);
             fidx[0] = row[0]; fidx[1] = row[1]; fidx[2] = row[2]; fidx[3] = row[3];
-        } else {
-            fbase += (size_t)b * BN_T * plane;
         }
         const int ya = y0, yb = (band == p.nbands - 1) ? p.H : y0 + rows;
         const int nreal = n2 * RCr;
@@ -1356,7 +958,7 @@ __global__ __launch_bounds__(512, 4) void enc1v_mfma(Enc1wArgs p) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) v[k][t][j] = (_Float16)0;
             }
-            if constexpr (PRE && E1_ABL != 1 && E1_ABL != 5) {
+            if constexpr (E1_ABL != 1 && E1_ABL != 5) {
                 TmixW tmp;
                 {
                     const uint4 w = *reinterpret_cast<const uint4 *>(cst + 448 + (ll & 3) * 16);
@@ -2132,7 +1734,7 @@ void prep_enc(bool allpos, int cin, int cout, const float *k, const float *bias,
     std::memcpy(epi + 3 * cout + 16, w2, 16 * sizeof(float));
 }
 
-// level 1 for enc1w_mfma: 16x16x32 B fragment, lane l: n = l & 15, k = 8 * (l >> 4) + j; one K step = two taps x 16
+// level 1 for enc1_mfma: 16x16x32 B fragment, lane l: n = l & 15, k = 8 * (l >> 4) + j; one K step = two taps x 16
 // channels: k < 16 -> first tap of the pair, k >= 16 -> second.  Pairs (ky,kx): (0,0)|(0,1), (1,0)|(1,1), (2,0)|(2,1),
 // (0,2)|(1,2), (2,2)|none.
 void prep_enc1w(bool allpos, const float *k, const float *bias, const float *gamma, const float *beta, const float *mean,
@@ -2419,7 +2021,6 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
                          uint8_t *d_mask, const BnCcTail *cc, bool *cc_done) {
     if (cc_done) *cc_done = false;
     const bool dry = inp.dry;              // planning only: every check below runs, no kernel is launched
-    const uint8_t *d_stack = inp.stack;
     const bool by_frames = inp.frames != nullptr || (dry && inp.n_frames > 0);
     __half *const *act = ws.act;
     __half *const *dact = ws.dact;
@@ -2428,10 +2029,14 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
     const int num_cu = ctx->props.multiProcessorCount;
 
     // ---------------- encoder
-    int first_level = 0;
-    if (by_frames) {
-        // carrier-frame path: level 0 up to the pool ONCE per carrier frame (enc0p_mfma -> P); level 1 gathers the
-        // four frames of a stack, applies level 0's temporal MLP in LDS and writes the decoder's skip slice
+    // Level 0 up to the pool runs ONCE per carrier frame (enc0p_mfma -> P); level 1 gathers the four frames of a stack,
+    // applies level 0's temporal MLP while staging and writes the decoder's skip slice.  The stacked tensor of the other
+    // entry point is B * T carrier frames with an implicit table (stack b = frames 4b .. 4b+3).
+    const uint8_t *const d_frames = by_frames ? inp.frames : inp.stack;
+    const int n_frames = by_frames ? inp.n_frames : batch * BN_T;
+    const int32_t *const d_index = by_frames ? inp.index : nullptr;
+    if ((size_t)n_frames > ws.pbuf_frames && !dry) return COVAHIP_ERR_INVALID_ARG;   // (the caller sizes P: blobnet.hip)
+    {
         const int H = m->lv[0].H, W = m->lv[0].W, Hp = H / 2, Wp = W / 2;
         const int TC = ((W + 4 - 16 + 31) / 32) * 32 + 16;
         if (W % 4) return COVAHIP_ERR_UNSUPPORTED;
@@ -2440,7 +2045,7 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
         for (int nb = 1; nb <= Hp; nb++) {
             const int rb = (Hp + nb - 1) / nb, n2 = 2 * rb + 2;
             if (n2 * (W / 4) > 2 * WG0 || (size_t)n2 * TC * 8 > 30 * 1024) continue;
-            if ((long long)inp.n_frames * nb < 2LL * num_cu && nb < Hp) continue;   // keep every CU busy
+            if ((long long)n_frames * nb < 2LL * num_cu && nb < Hp) continue;   // keep every CU busy
             nbands = nb;
             break;
         }
@@ -2448,15 +2053,15 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
         const int rbmax = (Hp + nbands - 1) / nbands;
         const size_t tile_bytes = (((size_t)(2 * rbmax + 2) * TC * 8) + 15) & ~(size_t)15;
         Enc0pArgs a;
-        a.in = inp.frames; a.out = ws.pbuf;
+        a.in = d_frames; a.out = ws.pbuf;
         a.wfrag = (const half8 *)(prep + pr->enc[0].wfrag); a.epi = (const float *)(prep + pr->enc[0].epi);
-        a.F = inp.n_frames; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.Ho = m->lv[1].H; a.Wo = m->lv[1].W;
+        a.F = n_frames; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.Ho = m->lv[1].H; a.Wo = m->lv[1].W;
         a.oy = H & 1; a.ox = W & 1; a.nbands = nbands; a.TC = TC;
         a.mWp = magic(Wp); a.mNb = magic(nbands); a.mW4 = magic(W / 4); a.scr_off = (int)tile_bytes;
         const size_t lds = tile_bytes + (size_t)(WG0 / 64) * 1024;
         // three persistent workgroups per CU: measured 13.9 - 14.6 us at 280 frames against 15.0 with four (the kernel sits
         // on its latency floor: band count 3 .. 7 and 2 .. 4 workgroups per CU all land within 1.5 us)
-        const int grid = std::min(inp.n_frames * nbands, 3 * num_cu);
+        const int grid = std::min(n_frames * nbands, 3 * num_cu);
         {
             ProfScope ps(ctx, "enc0p_mfma");
             if (pr->allpos[0]) LAUNCH(enc0p_mfma<true>, dim3(grid), dim3(WG0), lds, ctx->stream, a);
@@ -2464,15 +2069,12 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
         }
         COVAHIP_CHECK_HIP(ctx, hipGetLastError());
     }
-    if (by_frames && first_level == 0) first_level = 1;
-    for (int i = first_level; i < BN_LEVELS; i++) {
+    for (int i = 1; i < BN_LEVELS; i++) {
         const int H = m->lv[i].H, W = m->lv[i].W, Hp = H / 2, Wp = W / 2;
         const int cin = m->enc_c[i];
-        if (i == 1 && m->enc1_wide16 && cin == 16 && m->enc_c[2] == 32 && W <= E1_MAXW && !ctx->enc_plan[1].nbands) {
-            // sixteen-channel waves (enc1w_mfma): bands of at most three pool-window rows (E1_TR rows per T slice), two
-            // sixteen-wave workgroups per CU; same planner as below: rounds x (rows + 1)
-            static const bool wide8 = !(std::getenv("COVAHIP_E1_VARIANT") && std::getenv("COVAHIP_E1_VARIANT")[0] == 'w');
-            const int NWV = wide8 ? 8 : 16;
+        if (i == 1 && m->enc1_tile16 && cin == 16 && m->enc_c[2] == 32 && W <= E1_MAXW && !ctx->enc_plan[1].nbands) {
+            // enc1_mfma: bands of at most three pool-window rows (E1_TR rows per T slice), two eight-wave workgroups per CU;
+            // same planner as below: rounds x (rows + 1)
             const long long slots = 2LL * num_cu;
             long long best = -1;
             int nbands = 0;
@@ -2483,61 +2085,41 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
                 const long long cost = rounds * (rb + 1);
                 if (best < 0 || cost < best) { best = cost; nbands = nb; }
             }
-            if (nbands && E1_TR * 2 * (W + 2) <= 1024) {
-                Enc1wArgs a;
-                a.in = by_frames ? ws.pbuf : act[1]; a.out = act[2];
+            if (nbands) {
+                Enc1Args a;
+                a.in = ws.pbuf; a.out = act[2];
                 a.wfrag = (const half8 *)(prep + pr->enc1w); a.epi = (const float *)(prep + pr->enc[1].epi);
                 a.B = batch; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.Ho = m->lv[2].H; a.Wo = m->lv[2].W;
                 a.oy = H & 1; a.ox = W & 1; a.nbands = nbands;
                 a.mWp = magic(Wp); a.mRC = magic(2 * (W + 2));
                 a.scr_off = BN_T * E1_TSZ;
-                static const int stagger = std::getenv("COVAHIP_E1_STAGGER") ? std::atoi(std::getenv("COVAHIP_E1_STAGGER")) : 0;
-                const int grid = std::min(batch * nbands, (stagger == -3 ? 1 : 2) * num_cu);
+                const int grid = std::min(batch * nbands, 2 * num_cu);
                 a.plan = make_plan(grid, num_cu, 2, batch, nbands, Hp);
-                a.pidx = inp.index; a.skip = act[1]; a.tm_pre = (const float *)(prep + pr->enc[0].epi) + 48;
-                a.stagger = stagger;
-                const size_t lds = (size_t)BN_T * E1_TSZ + (wide8 ? 8 * 1024 : 16 * 512) + E1_CONST;
-                int rc;
-                ProfScope ps(ctx, by_frames ? "enc1t_mfma" : "enc1_mfma");
-#define E1_LAUNCH(KERNEL)                                                                  \
-    do {                                                                                   \
-        rc = set_lds(ctx, KERNEL, lds);                                                    \
-        if (rc) return rc;                                                                 \
-        LAUNCH((KERNEL), dim3(grid), dim3(NWV * 64), lds, ctx->stream, a);                 \
-    } while (0)
-                if (wide8) {
-                    if (by_frames) { if (pr->allpos[1]) E1_LAUNCH((enc1v_mfma<true, true>)); else E1_LAUNCH((enc1v_mfma<false, true>)); }
-                    else { if (pr->allpos[1]) E1_LAUNCH((enc1v_mfma<true, false>)); else E1_LAUNCH((enc1v_mfma<false, false>)); }
-                } else {
-                    if (by_frames) { if (pr->allpos[1]) E1_LAUNCH((enc1w_mfma<16, true, true>)); else E1_LAUNCH((enc1w_mfma<16, false, true>)); }
-                    else { if (pr->allpos[1]) E1_LAUNCH((enc1w_mfma<16, true, false>)); else E1_LAUNCH((enc1w_mfma<16, false, false>)); }
-                }
-#undef E1_LAUNCH
+                a.pidx = d_index; a.skip = act[1]; a.tm_pre = (const float *)(prep + pr->enc[0].epi) + 48;
+                const size_t lds = (size_t)BN_T * E1_TSZ + 8 * 1024 + E1_CONST;
+                int rc = pr->allpos[1] ? set_lds(ctx, enc1_mfma<true>, lds) : set_lds(ctx, enc1_mfma<false>, lds);
+                if (rc) return rc;
+                ProfScope ps(ctx, "enc1_mfma");
+                if (pr->allpos[1]) LAUNCH(enc1_mfma<true>, dim3(grid), dim3(512), lds, ctx->stream, a);
+                else LAUNCH(enc1_mfma<false>, dim3(grid), dim3(512), lds, ctx->stream, a);
                 COVAHIP_CHECK_HIP(ctx, hipGetLastError());
                 continue;
             }
         }
-        const size_t px_bytes = (i == 0) ? 8 : (size_t)cin * 2;
-        // enc0: two zero columns left (16-byte aligned 4-pixel groups) and two right (halo + the 4th,
-        // zero-weight pixel its K layout reads per tap row)
-        // (enc0 rows are padded to a stride of 128 mod 256 bytes so the two tile rows a wave reads
-        //  in one ds_read_b64 never share LDS banks)
-        const int TC = (i == 0) ? ((W + 4 - 16 + 31) / 32) * 32 + 16 : W + 2;
+        const size_t px_bytes = (size_t)cin * 2;
+        const int TC = W + 2;
         // band height: largest even RB whose tile (RB+2 rows, all T) fits in ~78 KB of LDS
         // (two workgroups per CU; the 64->128 level keeps 144 weight VGPRs per wave and runs one
         //  workgroup per CU with up to 150 KB)
-        // output transpose scratch behind the tile: 1 KB per wave at level 0, 2 KB per wave at levels 1 and 3
-        // (level 2 keeps 2-byte stores: its 80 KB tile leaves no room beside a second workgroup)
-        static const int enc_waves[BN_LEVELS] = {WG0 / 64, 8, 4, 8};
-        static const bool enc_wide[BN_LEVELS] = {true, true, true, true};
+        // output transpose scratch behind the tile: 2 KB per wave
+        static const int enc_waves[BN_LEVELS] = {0, 8, 4, 8};
         int waves = enc_waves[i], nbuf = 1, wgs_per_cu = (i == BN_LEVELS - 1) ? 1 : 2;
         int nbands = 0, RB = 0;
-        size_t scr_bytes = (i == 0) ? (size_t)waves * 1024 : (enc_wide[i] ? (size_t)waves * 2048 : 0);
-        if (i >= 1 && ctx->enc_plan[i].nbands) {
+        size_t scr_bytes = (size_t)waves * 2048;
+        if (ctx->enc_plan[i].nbands) {
             // developer override (covahip_blobnet_set_enc_plan)
             nbands = std::min(ctx->enc_plan[i].nbands, Hp);
             nbuf = ctx->enc_plan[i].nbuf;
-            scr_bytes = (size_t)waves * 2048;
             RB = 2 * ((Hp + nbands - 1) / nbands);
             const size_t need = (size_t)nbuf * BN_T * (RB + 2) * TC * px_bytes + scr_bytes;
             if (need > 160 * 1024 - 256) return COVAHIP_ERR_UNSUPPORTED;
@@ -2564,59 +2146,37 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
         if (lds > 160 * 1024 - 256) return COVAHIP_ERR_UNSUPPORTED;
         const int items = batch * nbands;
         const int grid = std::min(items, wgs_per_cu * num_cu);
-        if (i == 0) {
-            Enc0Args a;
-            a.in = d_stack; a.out = act[1];
-            a.wfrag = (const half8 *)(prep + pr->enc[0].wfrag); a.epi = (const float *)(prep + pr->enc[0].epi);
-            a.B = batch; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.Ho = m->lv[1].H; a.Wo = m->lv[1].W;
-            a.oy = H & 1; a.ox = W & 1; a.RB = RB; a.nbands = nbands; a.TR = RB + 2; a.TC = TC;
-            a.mWp = magic(Wp); a.mNb = magic(nbands); a.mW4 = magic(W / 4); a.scr_off = (int)tile_bytes;
-            a.plan = make_plan(grid, num_cu, wgs_per_cu, batch, nbands, Hp);
-            if (W % 4 || (RB + 2) * (W / 4) > 2 * WG0) return COVAHIP_ERR_UNSUPPORTED;
-            int rc = pr->allpos[0] ? set_lds(ctx, enc0_mfma<true>, lds) : set_lds(ctx, enc0_mfma<false>, lds);
+        EncArgs a;
+        a.in = i == 1 ? ws.pbuf : act[i]; a.out = act[i + 1];
+        a.wfrag = (const half8 *)(prep + pr->enc[i].wfrag); a.epi = (const float *)(prep + pr->enc[i].epi);
+        a.B = batch; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.Ho = m->lv[i + 1].H; a.Wo = m->lv[i + 1].W;
+        a.oy = H & 1; a.ox = W & 1; a.To = (i == BN_LEVELS - 1) ? 1 : BN_T;
+        a.RB = RB; a.nbands = nbands; a.TR = RB + 2; a.TC = TC;
+        a.mWp = magic(Wp); a.mNb = magic(nbands); a.mRC = magic(TC * (cin / 8)); a.zero = prep + pr->zero;
+        a.nbuf = nbuf; a.buf_stride = (int)tile_bytes; a.scr_off = (int)(nbuf * tile_bytes);
+        a.plan = make_plan(grid, num_cu, wgs_per_cu, batch, nbands, Hp);
+        a.swz = choose_swz(true, cin, W, Wp, RB / 2);
+        a.pidx = d_index; a.skip = act[1]; a.tm_pre = (const float *)(prep + pr->enc[0].epi) + 48;
+        int rc = COVAHIP_OK;
+        if (i == 1) {
+            // the round-1..3 level-1 kernel: grids wider than enc1_mfma's LDS row, developer band plans, set_impl(5)
+            rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true, true, true>, lds) : set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true, false, true>, lds);
             if (rc) return rc;
-            ProfScope ps(ctx, "enc0_mfma");
-            if (pr->allpos[0]) LAUNCH(enc0_mfma<true>, dim3(grid), dim3(WG0), lds, ctx->stream, a);
-            else LAUNCH(enc0_mfma<false>, dim3(grid), dim3(WG0), lds, ctx->stream, a);
+            ProfScope ps(ctx, "enc1_mfma");
+            if (pr->allpos[i]) LAUNCH((enc_mfma<16, 32, 2, 4, 8, true, true, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
+            else LAUNCH((enc_mfma<16, 32, 2, 4, 8, true, false, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
+        } else if (i == 2) {
+            rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<32, 64, 4, 2, 4, true, true>, lds) : set_lds(ctx, enc_mfma<32, 64, 4, 2, 4, true, false>, lds);
+            if (rc) return rc;
+            ProfScope ps(ctx, "enc2_mfma");
+            if (pr->allpos[i]) LAUNCH((enc_mfma<32, 64, 4, 2, 4, true, true>), dim3(grid), dim3(WG), lds, ctx->stream, a);
+            else LAUNCH((enc_mfma<32, 64, 4, 2, 4, true, false>), dim3(grid), dim3(WG), lds, ctx->stream, a);
         } else {
-            EncArgs a;
-            a.in = act[i]; a.out = act[i + 1];
-            a.wfrag = (const half8 *)(prep + pr->enc[i].wfrag); a.epi = (const float *)(prep + pr->enc[i].epi);
-            a.B = batch; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.Ho = m->lv[i + 1].H; a.Wo = m->lv[i + 1].W;
-            a.oy = H & 1; a.ox = W & 1; a.To = (i == BN_LEVELS - 1) ? 1 : BN_T;
-            a.RB = RB; a.nbands = nbands; a.TR = RB + 2; a.TC = TC;
-            a.mWp = magic(Wp); a.mNb = magic(nbands); a.mRC = magic(TC * (cin / 8)); a.zero = prep + pr->zero;
-            a.nbuf = nbuf; a.buf_stride = (int)tile_bytes; a.scr_off = (int)(nbuf * tile_bytes);
-            a.plan = make_plan(grid, num_cu, wgs_per_cu, batch, nbands, Hp);
-            a.swz = choose_swz(true, cin, W, Wp, RB / 2);
-            a.pidx = inp.index; a.skip = act[1]; a.tm_pre = (const float *)(prep + pr->enc[0].epi) + 48;
-            int rc = COVAHIP_OK;
-            if (i == 1 && by_frames) {
-                a.in = ws.pbuf;
-                rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true, true, true>, lds) : set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true, false, true>, lds);
-                if (rc) return rc;
-                ProfScope ps(ctx, "enc1t_mfma");
-                if (pr->allpos[i]) LAUNCH((enc_mfma<16, 32, 2, 4, 8, true, true, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
-                else LAUNCH((enc_mfma<16, 32, 2, 4, 8, true, false, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
-            } else if (i == 1) {
-                rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true, true>, lds) : set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true, false>, lds);
-                if (rc) return rc;
-                ProfScope ps(ctx, "enc1_mfma");
-                if (pr->allpos[i]) LAUNCH((enc_mfma<16, 32, 2, 4, 8, true, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
-                else LAUNCH((enc_mfma<16, 32, 2, 4, 8, true, false>), dim3(grid), dim3(512), lds, ctx->stream, a);
-            } else if (i == 2) {
-                rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<32, 64, 4, 2, 4, true, true>, lds) : set_lds(ctx, enc_mfma<32, 64, 4, 2, 4, true, false>, lds);
-                if (rc) return rc;
-                ProfScope ps(ctx, "enc2_mfma");
-                if (pr->allpos[i]) LAUNCH((enc_mfma<32, 64, 4, 2, 4, true, true>), dim3(grid), dim3(WG), lds, ctx->stream, a);
-                else LAUNCH((enc_mfma<32, 64, 4, 2, 4, true, false>), dim3(grid), dim3(WG), lds, ctx->stream, a);
-            } else {
-                rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<64, 128, 2, 2, 8, true, true>, lds) : set_lds(ctx, enc_mfma<64, 128, 2, 2, 8, true, false>, lds);
-                if (rc) return rc;
-                ProfScope ps(ctx, "enc3_mfma");
-                if (pr->allpos[i]) LAUNCH((enc_mfma<64, 128, 2, 2, 8, true, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
-                else LAUNCH((enc_mfma<64, 128, 2, 2, 8, true, false>), dim3(grid), dim3(512), lds, ctx->stream, a);
-            }
+            rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<64, 128, 2, 2, 8, true, true>, lds) : set_lds(ctx, enc_mfma<64, 128, 2, 2, 8, true, false>, lds);
+            if (rc) return rc;
+            ProfScope ps(ctx, "enc3_mfma");
+            if (pr->allpos[i]) LAUNCH((enc_mfma<64, 128, 2, 2, 8, true, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
+            else LAUNCH((enc_mfma<64, 128, 2, 2, 8, true, false>), dim3(grid), dim3(512), lds, ctx->stream, a);
         }
         COVAHIP_CHECK_HIP(ctx, hipGetLastError());
     }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Developer helper (here): builds ab_tmp/abl<N>.so = the library with -DE1_ABL=N (enc1w_mfma with one part removed; results
+# Developer helper (here): builds ab_tmp/abl<N>.so = the library with -DE1_ABL=N (enc1_mfma with one part removed; results
 # are wrong, the timing says what the part costs).  Run on the GPU box with tools/ab.sh ab_tmp/abl0.so ab_tmp/abl1.so ...
 cd "$(dirname "$0")/../cova_amd/csrc" || exit 1
 mkdir -p ../../ab_tmp /tmp/isa
