@@ -294,6 +294,34 @@ struct DecArgs {
     int mask_off;        // last block: byte offset of the band's mask rows in LDS
 };
 
+#ifdef PHASE_TIMING
+// developer build only (tools/phase_timing.sh): wall-clock ticks (s_memrealtime, 100 MHz) per phase of the item loop,
+// summed over the workgroups' wave 0
+__device__ unsigned long long g_phase[80];
+#define PHASE_MARK(i)                                                     \
+    do {                                                                  \
+        const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+        ph_[i] += now_ - last_;                                           \
+        last_ = now_;                                                     \
+    } while (0)
+// per-workgroup life span of the last launch of a kernel: {start, end} in s_memrealtime ticks (10 ns) and the hardware id
+// (which workgroups shared a CU)
+__device__ unsigned long long g_wgspan[6][1024][4];
+#define WGSPAN_BEGIN() const unsigned long long wg_t0_ = __builtin_amdgcn_s_memrealtime(), wg_c0_ = __builtin_amdgcn_s_memtime()
+#define WGSPAN_END(kid)                                                                          \
+    do {                                                                                         \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) {                                             \
+            g_wgspan[kid][blockIdx.x][0] = wg_t0_;                                               \
+            g_wgspan[kid][blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();                     \
+            g_wgspan[kid][blockIdx.x][2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); \
+            g_wgspan[kid][blockIdx.x][3] = __builtin_amdgcn_s_memtime() - wg_c0_;                \
+        }                                                                                        \
+    } while (0)
+#else
+#define PHASE_MARK(i) do { } while (0)
+#define WGSPAN_BEGIN() do { } while (0)
+#define WGSPAN_END(kid) do { } while (0)
+#endif
 // ------------------------------------------------------------------ enc level 0
 // u8 RGBA carrier frame -> conv3x3 (3->16) on v_mfma_f32_16x16x32_f16.
 // K layout: one K-step = 2 kernel rows x (4 pixels x 4 channels); pixel 3 and channel 3
@@ -332,6 +360,7 @@ struct Enc0pArgs {
 template <bool ALLPOS>
 __global__ __launch_bounds__(WG0, 4) void enc0p_mfma(Enc0pArgs p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    WGSPAN_BEGIN();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int TC = p.TC;
     const half8 be0 = p.wfrag[lane], be1 = p.wfrag[64 + lane];
@@ -435,38 +464,12 @@ __global__ __launch_bounds__(WG0, 4) void enc0p_mfma(Enc0pArgs p) {
             __builtin_amdgcn_wave_barrier();
         }
     }
+    WGSPAN_END(5);
 }
 
 // ------------------------------------------------------------------ enc levels 1..3
 // conv3x3 CIN -> COUT on v_mfma_f32_32x32x16_f16.  Wave roles: N-tile = wave % NT,
 // M-group = wave / NT.  One K-step = one tap x 16 input channels.
-#ifdef PHASE_TIMING
-// developer build only (tools/phase_timing.sh): wall-clock ticks (s_memrealtime, 100 MHz) per phase of the item loop,
-// summed over the workgroups' wave 0
-__device__ unsigned long long g_phase[80];
-#define PHASE_MARK(i)                                                     \
-    do {                                                                  \
-        const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
-        ph_[i] += now_ - last_;                                           \
-        last_ = now_;                                                     \
-    } while (0)
-// per-workgroup life span of the last launch of a kernel: {start, end} in s_memrealtime ticks (10 ns) and the hardware id
-// (which workgroups shared a CU)
-__device__ unsigned long long g_wgspan[6][1024][3];
-#define WGSPAN_BEGIN() const unsigned long long wg_t0_ = __builtin_amdgcn_s_memrealtime()
-#define WGSPAN_END(kid)                                                                          \
-    do {                                                                                         \
-        if (threadIdx.x == 0 && blockIdx.x < 1024) {                                             \
-            g_wgspan[kid][blockIdx.x][0] = wg_t0_;                                               \
-            g_wgspan[kid][blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();                     \
-            g_wgspan[kid][blockIdx.x][2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); \
-        }                                                                                        \
-    } while (0)
-#else
-#define PHASE_MARK(i) do { } while (0)
-#define WGSPAN_BEGIN() do { } while (0)
-#define WGSPAN_END(kid) do { } while (0)
-#endif
 template <int CIN, int COUT, int TPAR, int OCC, int NWV, bool WIDE, bool ALLPOS, bool PRE = false>
 __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     constexpr int WGS = NWV * 64;
@@ -1478,6 +1481,7 @@ __global__ __launch_bounds__(512, 2) void dec012_mfma(Dec012Args p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t *const t0 = smem + p.lv[0].tile_off, *const t1 = smem + p.lv[1].tile_off, *const t2 = smem + p.lv[2].tile_off;
+    WGSPAN_BEGIN();
 #ifdef PHASE_TIMING
     unsigned long long ph_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1530,6 +1534,7 @@ __global__ __launch_bounds__(512, 2) void dec012_mfma(Dec012Args p) {
     if (tid == 0)
         for (int i = 0; i < 9; i++) atomicAdd(&g_phase[48 + i], ph_[i]);
 #endif
+    WGSPAN_END(3);
 }
 
 // ------------------------------------------------------------------ last decoder block + bboxcc fused
@@ -1564,6 +1569,7 @@ __global__ __launch_bounds__(ccbody::CC_THREADS) void dec3cc_mfma(Dec3ccArgs q) 
     const int kh = lane >> 5;
     const float fbias = p.epi[0];
     uint8_t *const mfull = smem + q.mfull_off;
+    WGSPAN_BEGIN();
 #ifdef PHASE_TIMING
     unsigned long long ph_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1669,6 +1675,7 @@ __global__ __launch_bounds__(ccbody::CC_THREADS) void dec3cc_mfma(Dec3ccArgs q) 
     if (tid == 0)
         for (int i = 0; i < 9; i++) atomicAdd(&g_phase[64 + i], ph_[i]);
 #endif
+    WGSPAN_END(4);
 }
 
 // ------------------------------------------------------------------ host-side weight preparation
@@ -2322,7 +2329,7 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
 
 #ifdef PHASE_TIMING
 extern "C" int covahip_dev_wgspan_read(unsigned long long *out, int kid) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgspan), sizeof(unsigned long long) * 1024 * 3, sizeof(unsigned long long) * 1024 * 3 * kid) != hipSuccess;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgspan), sizeof(unsigned long long) * 1024 * 4, sizeof(unsigned long long) * 1024 * 4 * kid) != hipSuccess;
 }
 extern "C" int covahip_dev_phase_read(unsigned long long *out64, int reset) {
     if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase), sizeof(g_phase)) != hipSuccess) return 1;

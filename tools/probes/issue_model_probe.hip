@@ -86,6 +86,69 @@ __global__ __launch_bounds__(1024) void probe(unsigned long long *out, unsigned 
             }
             asm volatile("s_waitcnt lgkmcnt(0)");
         }
+        if (KIND >= 11 && KIND <= 16) {                                  // 8 MFMA 16x16x32 + NV v_max3 (NV = 8, 24, 32, 48, 64, 96)
+            constexpr int NV = KIND == 11 ? 1 : KIND == 12 ? 3 : KIND == 13 ? 4 : KIND == 14 ? 6 : KIND == 15 ? 8 : 12;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                acc[k & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, acc[k & 3], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < NV; q++) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[(k + q) & 7]) : "v"(b), "v"(c));
+            }
+        }
+        if (KIND >= 17 && KIND <= 20) {                                  // 4 MFMA 32x32x16 + NV v_max3 per MFMA (2, 6, 8, 12)
+            constexpr int NV = KIND == 17 ? 2 : KIND == 18 ? 6 : KIND == 19 ? 8 : 12;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                big[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, big[k & 1], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < NV; q++) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[(k + q) & 7]) : "v"(b), "v"(c));
+            }
+        }
+        if (KIND == 21) {                                                // 16 MFMA 4x4x4
+            typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+            half4 a4 = {ha[0], ha[1], ha[2], ha[3]}, b4 = {hb[0], hb[1], hb[2], hb[3]};
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc[k & 3] = __builtin_amdgcn_mfma_f32_4x4x4f16(a4, b4, acc[k & 3], 0, 0, 0);
+        }
+        if (KIND == 22) {                                                // 16 MFMA 4x4x4 + 32 v_max3
+            typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+            half4 a4 = {ha[0], ha[1], ha[2], ha[3]}, b4 = {hb[0], hb[1], hb[2], hb[3]};
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                acc[k & 3] = __builtin_amdgcn_mfma_f32_4x4x4f16(a4, b4, acc[k & 3], 0, 0, 0);
+                asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[k & 7]) : "v"(b), "v"(c));
+                asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[(k + 4) & 7]) : "v"(b), "v"(c));
+            }
+        }
+        if (KIND == 23) {                                                // 16 v_cndmask (VOP2, vcc)
+#pragma unroll
+            for (int k = 0; k < 16; k++) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[k & 7]) : "v"(b) : "vcc");
+        }
+        if (KIND == 24) {                                                // 16 v_pk_max_f16
+#pragma unroll
+            for (int k = 0; k < 16; k++) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(a[k & 7]) : "v"(b));
+        }
+        if (KIND == 25) {                                                // 16 v_perm_b32
+#pragma unroll
+            for (int k = 0; k < 16; k++) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[k & 7]) : "v"(b), "v"(c));
+        }
+        if (KIND == 26) {                                                // 16 v_fma_f32 (VOP3, 3 operands) 
+#pragma unroll
+            for (int k = 0; k < 16; k++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k & 7]) : "v"(b), "v"(c));
+        }
+        if (KIND == 27) {                                                // 16 v_max_f32 (VOP2)
+#pragma unroll
+            for (int k = 0; k < 16; k++) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[k & 7]) : "v"(b));
+        }
+        if (KIND == 28) {                                                // 16 v_mov_b32
+#pragma unroll
+            for (int k = 0; k < 16; k++) asm volatile("v_mov_b32 %0, %1" : "=v"(a[k & 7]) : "v"(b));
+        }
+        if (KIND == 29) {                                                // 16 ds_write_b16
+#pragma unroll
+            for (int k = 0; k < 16; k++) asm volatile("ds_write_b16 %0, %1 offset:%2" :: "v"(lds_a), "v"(a[k & 7]), "n"(k * 128));
+            asm volatile("s_waitcnt lgkmcnt(0)");
+        }
     }
     __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -109,7 +172,7 @@ void run(const char *name, int per_trip, unsigned long long *d) {
         hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
         double mx = 0;
         for (int w = 0; w < wps * 4; w++) mx = h[2 * w] > mx ? h[2 * w] : mx;
-        printf("  %d w/SIMD: %7.1f cyc/trip = %5.2f cyc per instr per SIMD", wps, mx / trips, mx / trips / (per_trip * wps));
+        printf("  %dw: %7.1f/trip (%5.2f/instr/SIMD)", wps, mx / trips, mx / trips / (per_trip * wps));
     }
     printf("\n");
 }
@@ -128,5 +191,24 @@ int main() {
     run<5>("8 ds_read_b128 + 8 mfma16", 16, d);
     run<6>("8 ds_read_b128 + 16 v_max3", 24, d);
     run<10>("8 ds_read + 8 mfma16 + 16 v_max3", 32, d);
+    run<11>("8 mfma16 + 8 v_max3", 16, d);
+    run<12>("8 mfma16 + 24 v_max3", 32, d);
+    run<13>("8 mfma16 + 32 v_max3", 40, d);
+    run<14>("8 mfma16 + 48 v_max3", 56, d);
+    run<15>("8 mfma16 + 64 v_max3", 72, d);
+    run<16>("8 mfma16 + 96 v_max3", 104, d);
+    run<17>("4 mfma32 + 8 v_max3", 12, d);
+    run<18>("4 mfma32 + 24 v_max3", 28, d);
+    run<19>("4 mfma32 + 32 v_max3", 36, d);
+    run<20>("4 mfma32 + 48 v_max3", 52, d);
+    run<21>("16 mfma 4x4x4", 16, d);
+    run<22>("16 mfma 4x4x4 + 32 v_max3", 48, d);
+    run<23>("16 v_cndmask_b32 (vcc)", 16, d);
+    run<24>("16 v_pk_max_f16", 16, d);
+    run<25>("16 v_perm_b32", 16, d);
+    run<26>("16 v_fma_f32", 16, d);
+    run<27>("16 v_max_f32 (VOP2)", 16, d);
+    run<28>("16 v_mov_b32", 16, d);
+    run<29>("16 ds_write_b16", 16, d);
     return 0;
 }

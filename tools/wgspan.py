@@ -25,14 +25,20 @@ lib = ctypes.CDLL(L.LIB_PATH)
 for _ in range(20):
     net.filter_frames_device(d_frames, frames.shape[0], index, B, 1, d_boxes, d_counts, 256, d_mask)
 ctx.sync()
-for kid, name, nwg in ((0, "level 1", 512), (1, "level 2", 512), (2, "level 3", 256)):
-    out = (ctypes.c_ulonglong * (1024 * 3))()
+for kid, name, nwg in ((5, "level 0 (enc0p)", 768), (0, "level 1", 512), (1, "level 2", 512), (2, "level 3", 256), (3, "dec012", 256), (4, "dec3cc", 256)):
+    out = (ctypes.c_ulonglong * (1024 * 4))()
     assert lib.covahip_dev_wgspan_read(out, kid) == 0
-    v = np.array(list(out), dtype=np.int64).reshape(1024, 3)[:nwg]
+    v = np.array(list(out), dtype=np.int64).reshape(1024, 4)[:nwg]
+    v = v[v[:, 0] > 0]
+    nwg = len(v)
+    if nwg == 0:
+        continue
     t0 = v[:, 0].min()
     st, en = (v[:, 0] - t0) / 100.0, (v[:, 1] - t0) / 100.0      # us
     print(f"{name}: {nwg} workgroups; starts {st.min():.2f} .. {st.max():.2f} us (median {np.median(st):.2f}); ends {en.min():.2f} .. {en.max():.2f} us "
           f"(median {np.median(en):.2f}, 10 % {np.percentile(en, 10):.2f}, 90 % {np.percentile(en, 90):.2f}); life {np.median(en - st):.2f} us median")
+    clk = v[:, 3] / np.maximum(v[:, 1] - v[:, 0], 1) * 100.0     # MHz: shader cycles per 10 ns tick
+    print(f"   shader clock over the workgroups' lives: median {np.median(clk):.0f} MHz, 10 % {np.percentile(clk, 10):.0f}, 90 % {np.percentile(clk, 90):.0f}")
     # by CU: hardware id bits (wave, simd, pipe, cu, sh, se, ...): group by the id without the wave / simd fields
     cu = v[:, 2] >> 8
     first, second = [], []
