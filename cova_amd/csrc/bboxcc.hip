@@ -45,8 +45,14 @@ __global__ __launch_bounds__(CC_THREADS) void bboxcc_kernel(const uint8_t *__res
                                                              int area_thresh, covahip_box *__restrict__ boxes,
                                                              int32_t *__restrict__ counts, int max_boxes,
                                                              const int32_t *__restrict__ list,
-                                                             const int32_t *__restrict__ n_list) {
+                                                             const int32_t *__restrict__ n_list,
+                                                             const int32_t *__restrict__ stat_src, int32_t *__restrict__ stat_dst,
+                                                             int stat_batch, int stat_cap) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // last launch of a large-batch call: the call's overflow counters (final: the launches before this one are complete) go to
+    // pinned host words that the NEXT call's plan reads -- no copy, no event, no host synchronisation
+    if (stat_dst && blockIdx.x == 0 && threadIdx.x < 8)
+        stat_dst[threadIdx.x] = threadIdx.x < 5 ? stat_src[threadIdx.x] : threadIdx.x == 5 ? stat_batch : threadIdx.x == 6 ? stat_cap : 0;
     auto one = [&](int frame) {
         const uint8_t *m = masks + (size_t)frame * g.H * g.W;
         if (wg.cap > 0)
@@ -84,34 +90,43 @@ __global__ __launch_bounds__(CC_THREADS) void bboxcc_big_kernel(const uint8_t *_
 // (the second-chance pass over the frames that had more runs than the first pass's capacity).  A frame with more than
 // g.cap runs goes to ovf_list.
 constexpr int WV_WAVES = 4;
-__global__ __launch_bounds__(WV_WAVES * 64) void bboxcc_wave_kernel(const uint8_t *__restrict__ masks, ccwave::WvGeom g, int batch,
+// Two instantiations on purpose: the first pass (LIST = false: frame = global wave index, nothing else in the kernel) must
+// stay within 64 registers per lane -- eight waves per SIMD are what hides its HBM latency; with the persistent list loop in
+// the same kernel hipcc allocated 92 (five waves per SIMD) and the sparse case lost 20 % (round 3's regression).
+template <bool LIST>
+__global__ __launch_bounds__(WV_WAVES * 64, LIST ? 1 : 8) void bboxcc_wave_kernel(const uint8_t *__restrict__ masks, ccwave::WvGeom g, int batch,
                                                                     int area_thresh, covahip_box *__restrict__ boxes,
                                                                     int32_t *__restrict__ counts, int max_boxes,
                                                                     const int32_t *__restrict__ list, const int32_t *__restrict__ n_list,
                                                                     int32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_n,
-                                                                    int base_cap, int32_t *__restrict__ n_big) {
+                                                                    int base_cap, int32_t *__restrict__ n_big,
+                                                                    int32_t *__restrict__ zero_next) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint8_t *const sm = smem + (size_t)wave * g.wave_bytes;
-    auto one = [&](int frame) {
+    if constexpr (!LIST) {
+        // the counters of the NEXT call on this lane (the other set of the pair): zeroed here instead of by a memset per call
+        if (zero_next && blockIdx.x == 0 && threadIdx.x < 8) zero_next[threadIdx.x] = 0;
+        const int frame = blockIdx.x * WV_WAVES + wave;
+        if (frame >= batch) return;
         const int n = ccwave::frame_wave(masks + (size_t)frame * g.H * g.W, sm, g, area_thresh, boxes + (size_t)frame * max_boxes,
                                          counts + frame, max_boxes, lane);
         if (lane == 0) {
             if (n > g.cap) ovf_list[atomicAdd(ovf_n, 1)] = frame;   // more runs than the LDS region holds
-            // statistics for the next call's plan (pass 1 only), SAMPLED: one frame in sixteen -- an atomic per frame on one
-            // address cost more than the rest of the kernel when most frames had many runs (52 k same-address atomics = 0.5 ms)
-            if (n_big && (frame & 15) == 0 && n > base_cap) atomicAdd(n_big + (n > 2 * base_cap ? 1 : 0), 1);   // [0]: 128 < n <= 256, [1]: n > 256
+            // statistics for the next call's plan, SAMPLED: one frame in sixteen -- an atomic per frame on one address cost more
+            // than the rest of the kernel when most frames had many runs (52 k same-address atomics = 0.5 ms)
+            if (n_big && (frame & 15) == 0 && n > base_cap)   // [0]: 128 < n <= 192, [1]: 192 < n <= 256, [2]: n > 256
+                atomicAdd(n_big + (n > 2 * base_cap ? 2 : 2 * n > 3 * base_cap ? 1 : 0), 1);
         }
-    };
-    if (!list) {
-        const int frame = blockIdx.x * WV_WAVES + wave;
-        if (frame < batch) one(frame);
-        return;
-    }
-    const int n = *n_list;
-    for (int k = blockIdx.x * WV_WAVES + wave; k < n; k += gridDim.x * WV_WAVES) {
-        one(list[k]);
-        ccwave::wave_fence();   // the next frame reuses this wave's LDS region
+    } else {
+        const int nl = *n_list;
+        for (int k = blockIdx.x * WV_WAVES + wave; k < nl; k += gridDim.x * WV_WAVES) {
+            const int frame = list[k];
+            const int n = ccwave::frame_wave(masks + (size_t)frame * g.H * g.W, sm, g, area_thresh, boxes + (size_t)frame * max_boxes,
+                                             counts + frame, max_boxes, lane);
+            if (lane == 0 && n > g.cap) ovf_list[atomicAdd(ovf_n, 1)] = frame;
+            ccwave::wave_fence();   // the next frame reuses this wave's LDS region
+        }
     }
 }
 
@@ -136,10 +151,15 @@ int open_lds(covahip_ctx *ctx, K kernel, size_t lds) {
 //   * large batches: pass 1 = one wave per frame with a run capacity of WAVE_CAP (4.2 KB of LDS per wave, about thirty
 //     frames in flight per CU); frames with more runs -- many objects, noise -- are collected in an overflow list and get a
 //     SECOND CHANCE on the wave kernel at four times the capacity (persistent launch over the list); what overflows that too
-//     goes to a persistent launch of the workgroup-per-frame kernel.  Passes 2 and 3 exit at once when their list is empty.
-//     The first pass's capacity adapts: the kernel counts (on one frame in sixteen) the frames with more than 128 / more than
-//     256 runs; when a quarter of the previous call's frames (same lane) had that many, the next call starts at 256 / 512 and
-//     skips the wasted first read of those frames (256 runs: 7.2 KB of LDS per wave, twenty frames in flight per CU).
+//     goes to a persistent launch of the workgroup-per-frame kernel, which exits at once when its list is empty.
+//     The first pass's capacity adapts: the kernel counts (on one frame in sixteen) the frames with more than 128 / 192 / 256
+//     runs; when a quarter of the last completed call's frames (same lane) had that many, the next call starts at 192 / 256 /
+//     512 and skips the wasted first read of those frames (192 runs: 5.7 KB of LDS per wave, 256: 7.2 KB).
+//     What a call costs besides pass 1 (round 4; round 3 had added a memset, two persistent launches, a device-to-host copy
+//     and an event per call, and a first-pass kernel of 92 registers -- 0.53 -> 0.44 of the HBM peak on sparse masks): ONE
+//     more launch.  The counters live in two sets that calls use alternately (pass 1 zeroes the other set), the last kernel of a
+//     call stores them to pinned host words (no copy, no event), and the second-chance pass is launched only when the last
+//     completed call had frames that overflowed.
 // Everything else runs the workgroup-per-frame kernel.
 constexpr int WAVE_CAP = 128;
 int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, int h, int w, int area_thresh,
@@ -159,9 +179,9 @@ int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, in
         if (batch > 3 * num_cu) {
             // the previous call's statistics, when they have arrived (pinned host words behind an event): frames with more
             // than WAVE_CAP runs; until then the last decision stands
-            if (ln.cc_stat && ln.cc_stat_batch > 0 && hipEventQuery(ln.cc_stat_ev) == hipSuccess) {   // (one frame in sixteen is counted; [2]: more than WAVE_CAP runs but at most twice that, [3]: more)
-                const int64_t mid = 16 * (int64_t)ln.cc_stat[2], big = 16 * (int64_t)ln.cc_stat[3];
-                ln.cc_first_cap = 4 * big > ln.cc_stat_batch ? 4 * WAVE_CAP : (4 * (mid + big) > ln.cc_stat_batch ? 2 * WAVE_CAP : WAVE_CAP);
+            if (ln.cc_stat && ln.cc_stat[5] > 0) {   // (one frame in sixteen is counted; [2]: 128 < runs <= 192, [3]: <= 256, [4]: more; [5]: that call's batch)
+                const int64_t c1 = 16 * (int64_t)ln.cc_stat[2], c2 = 16 * (int64_t)ln.cc_stat[3], c3 = 16 * (int64_t)ln.cc_stat[4], sb = ln.cc_stat[5];
+                ln.cc_first_cap = 4 * c3 > sb ? 4 * WAVE_CAP : 4 * (c2 + c3) > sb ? 2 * WAVE_CAP : 4 * (c1 + c2 + c3) > sb ? 3 * WAVE_CAP / 2 : WAVE_CAP;
             }
             cap = ln.cc_first_cap ? ln.cc_first_cap : WAVE_CAP;
         }
@@ -184,58 +204,72 @@ int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, in
         const bool second = can_overflow && cap2 > cap && ccwave::wv_plan(h, w, cap2, wg2) &&
                             (size_t)WV_WAVES * wg2.wave_bytes <= 160 * 1024 - 64;
         const bool third = can_overflow && (!second || cap2 < nb);
-        int32_t *ovf = nullptr;            // [n1][n2][n_big][-][list1: batch][list2: batch]
+        // [set 0: n1 n2 c1 c2 c3 - - -][set 1: ...][list1: batch][list2: batch]; calls alternate between the two counter sets
+        // and pass 1 zeroes the other one, so a call costs no memset (the buffer is zeroed when it is (re)allocated)
+        int32_t *ovf = nullptr;
         if (can_overflow) {
-            int rc = covahip_ensure_buffer(ctx, &ln.cc_ovf, &ln.cc_ovf_bytes, (2 * (size_t)batch + 4) * sizeof(int32_t));
+            const size_t need = (2 * (size_t)batch + 16) * sizeof(int32_t);
+            const bool fresh = need > ln.cc_ovf_bytes;
+            int rc = covahip_ensure_buffer(ctx, &ln.cc_ovf, &ln.cc_ovf_bytes, need);
             if (rc) return rc;
+            if (fresh) {
+                COVAHIP_CHECK_HIP(ctx, hipMemsetAsync(ln.cc_ovf, 0, 16 * sizeof(int32_t), ctx->stream));
+                ln.cc_stat_turn = 0;
+            }
             ovf = (int32_t *)ln.cc_ovf;
-            COVAHIP_CHECK_HIP(ctx, hipMemsetAsync(ovf, 0, 4 * sizeof(int32_t), ctx->stream));
+            if (!ln.cc_stat_ring) {   // pinned, device-visible words the last kernel of a call writes: {n1, n2, c1, c2, c3, batch, cap, -}
+                COVAHIP_CHECK_HIP(ctx, hipHostMalloc((void **)&ln.cc_stat_ring, 8 * sizeof(int32_t), hipHostMallocMapped));
+                for (int k = 0; k < 8; k++) ln.cc_stat_ring[k] = 0;
+                ln.cc_stat = ln.cc_stat_ring;
+            }
         }
-        int32_t *n1 = ovf, *n2 = ovf ? ovf + 1 : nullptr, *n_big = ovf ? ovf + 2 : nullptr;
-        int32_t *list1 = ovf ? ovf + 4 : nullptr, *list2 = ovf ? ovf + 4 + batch : nullptr;
+        const unsigned set = can_overflow ? (ln.cc_stat_turn++ & 1) : 0;
+        int32_t *cnt = ovf ? ovf + 8 * set : nullptr, *cnt_next = ovf ? ovf + 8 * (set ^ 1) : nullptr;
+        int32_t *n1 = cnt, *n2 = cnt ? cnt + 1 : nullptr, *n_big = cnt ? cnt + 2 : nullptr;
+        int32_t *list1 = ovf ? ovf + 16 : nullptr, *list2 = ovf ? ovf + 16 + batch : nullptr;
+        // the second-chance pass is worth a launch only when frames DO overflow: the last completed call on this lane says so
+        // (nothing known yet: it runs); whatever overflows is picked up by the workgroup kernel below either way
+        const bool second_now = second && !(ln.cc_stat && ln.cc_stat[5] > 0 && ln.cc_stat[0] == 0);
         const size_t wlds = (size_t)WV_WAVES * wg.wave_bytes;
-        int rc = open_lds(ctx, bboxcc_wave_kernel, std::max(wlds, second ? (size_t)WV_WAVES * wg2.wave_bytes : 0));
+        int rc = open_lds(ctx, bboxcc_wave_kernel<false>, wlds);
+        if (rc) return rc;
+        if (second) rc = open_lds(ctx, bboxcc_wave_kernel<true>, (size_t)WV_WAVES * wg2.wave_bytes);
         if (rc) return rc;
         {
             ProfScope ps(ctx, "bboxcc_wave_kernel");
-            hipLaunchKernelGGL(bboxcc_wave_kernel, dim3((batch + WV_WAVES - 1) / WV_WAVES), dim3(WV_WAVES * 64), wlds, ctx->stream,
+            hipLaunchKernelGGL(bboxcc_wave_kernel<false>, dim3((batch + WV_WAVES - 1) / WV_WAVES), dim3(WV_WAVES * 64), wlds, ctx->stream,
                                d_mask, wg, batch, area_thresh, d_boxes, d_counts, max_boxes, (const int32_t *)nullptr,
-                               (const int32_t *)nullptr, list1, n1, WAVE_CAP, n_big);
+                               (const int32_t *)nullptr, list1, n1, WAVE_CAP, n_big, cnt_next);
             COVAHIP_CHECK_HIP(ctx, hipGetLastError());
         }
-        if (second) {
+        if (second_now) {
             const size_t wlds2 = (size_t)WV_WAVES * wg2.wave_bytes;
             const int per_cu = std::max(1, (int)((160 * 1024 - 256) / wlds2));
             const int grid = std::min((batch + WV_WAVES - 1) / WV_WAVES, per_cu * num_cu);
             ProfScope ps(ctx, "bboxcc_wave_kernel_2");
-            hipLaunchKernelGGL(bboxcc_wave_kernel, dim3(grid), dim3(WV_WAVES * 64), wlds2, ctx->stream, d_mask, wg2, batch, area_thresh,
-                               d_boxes, d_counts, max_boxes, (const int32_t *)list1, (const int32_t *)n1, list2, n2, 0, (int32_t *)nullptr);
-            COVAHIP_CHECK_HIP(ctx, hipGetLastError());
-        }
-        if (third) {
-            rc = open_lds(ctx, bboxcc_kernel, lds_wg);
-            if (rc) return rc;
-            ProfScope ps(ctx, "bboxcc_kernel");
-            hipLaunchKernelGGL(bboxcc_kernel, dim3(std::min(batch, 2 * num_cu)), dim3(CC_THREADS), lds_wg, ctx->stream, d_mask, g, wfull,
-                               area_thresh, d_boxes, d_counts, max_boxes, (const int32_t *)(second ? list2 : list1),
-                               (const int32_t *)(second ? n2 : n1));
+            hipLaunchKernelGGL(bboxcc_wave_kernel<true>, dim3(grid), dim3(WV_WAVES * 64), wlds2, ctx->stream, d_mask, wg2, batch, area_thresh,
+                               d_boxes, d_counts, max_boxes, (const int32_t *)list1, (const int32_t *)n1, list2, n2, 0, (int32_t *)nullptr,
+                               (int32_t *)nullptr);
             COVAHIP_CHECK_HIP(ctx, hipGetLastError());
         }
         if (can_overflow) {
-            // overflow counts of this call -> pinned host words (read by the next call's plan and by covahip_dev_bboxcc_overflow)
-            if (!ln.cc_stat_ring) {
-                COVAHIP_CHECK_HIP(ctx, hipHostMalloc((void **)&ln.cc_stat_ring, 16 * sizeof(int32_t), hipHostMallocDefault));
-                for (hipEvent_t &e : ln.cc_stat_evs) COVAHIP_CHECK_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            }
-            const unsigned slot = ln.cc_stat_turn++ & 3;
-            int32_t *st = ln.cc_stat_ring + 4 * slot;   // {overflowed pass 1, overflowed pass 2, frames with more than WAVE_CAP runs, -}
-            COVAHIP_CHECK_HIP(ctx, hipEventSynchronize(ln.cc_stat_evs[slot]));   // the copy of four calls ago (never recorded: returns at once)
-            COVAHIP_CHECK_HIP(ctx, hipMemcpyAsync(st, ovf, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-            COVAHIP_CHECK_HIP(ctx, hipEventRecord(ln.cc_stat_evs[slot], ctx->stream));
-            ln.cc_stat = st;
-            ln.cc_stat_ev = ln.cc_stat_evs[slot];
+            // the workgroup kernel over what is left (exits at once when the list is empty); it also exports the call's counters
+            rc = open_lds(ctx, bboxcc_kernel, lds_wg);
+            if (rc) return rc;
+            int32_t *stat_dev = nullptr;
+            COVAHIP_CHECK_HIP(ctx, hipHostGetDevicePointer((void **)&stat_dev, ln.cc_stat_ring, 0));
+            const bool have_list = third || !second_now;   // (second chance at full capacity and run: nothing can be left)
+            // a list that was empty in the last completed call is expected to be empty again: a small grid (any grid is correct,
+            // the launch is persistent over the list) costs less to start and to drain
+            const bool quiet = ln.cc_stat && ln.cc_stat[5] > 0 && ln.cc_stat[0] == 0;
+            ProfScope ps(ctx, "bboxcc_kernel");
+            hipLaunchKernelGGL(bboxcc_kernel, dim3(!have_list ? 1 : quiet ? 32 : std::min(batch, 2 * num_cu)), dim3(CC_THREADS), lds_wg, ctx->stream, d_mask, g, wfull,
+                               area_thresh, d_boxes, d_counts, max_boxes, (const int32_t *)(second_now ? list2 : list1),
+                               (const int32_t *)(second_now ? n2 : n1), (const int32_t *)cnt, stat_dev, batch, cap);
+            COVAHIP_CHECK_HIP(ctx, hipGetLastError());
             ln.cc_stat_batch = batch;
             ln.cc_stat_cap = cap;
+            ln.cc_second_skipped = second && !second_now;
         } else {
             ln.cc_stat_batch = 0;
         }
@@ -259,7 +293,8 @@ int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, in
     if (rc) return rc;
     ProfScope ps(ctx, "bboxcc_kernel");
     hipLaunchKernelGGL(bboxcc_kernel, dim3(batch), dim3(CC_THREADS), lds_wg, ctx->stream, d_mask, g, wfull, area_thresh,
-                       d_boxes, d_counts, max_boxes, (const int32_t *)nullptr, (const int32_t *)nullptr);
+                       d_boxes, d_counts, max_boxes, (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr,
+                       (int32_t *)nullptr, 0, 0);
     COVAHIP_CHECK_HIP(ctx, hipGetLastError());
     return COVAHIP_OK;
 }
@@ -271,9 +306,11 @@ extern "C" int covahip_dev_bboxcc_overflow(covahip_ctx *ctx, int32_t *out4) {
     int rc = covahip_sync_all(ctx);
     if (rc) return rc;
     const CtxLane &ln = ctx->lanes[0];
+    // (everything has drained: the words are those of the last large-batch call; a frame that overflowed pass 1 while the
+    // second-chance pass was skipped counts as having overflowed both)
     out4[0] = ln.cc_stat_batch;
     out4[1] = ln.cc_stat && ln.cc_stat_batch ? ln.cc_stat[0] : 0;
-    out4[2] = ln.cc_stat && ln.cc_stat_batch ? ln.cc_stat[1] : 0;
+    out4[2] = ln.cc_stat && ln.cc_stat_batch ? ln.cc_stat[ln.cc_second_skipped ? 0 : 1] : 0;
     out4[3] = ln.cc_stat_cap;
     return COVAHIP_OK;
 }

@@ -90,8 +90,6 @@ void covahip_ctx_destroy(covahip_ctx *ctx) {
         if (l.cc_ovf) hipFree(l.cc_ovf);
         if (l.cc_slab) hipFree(l.cc_slab);
         if (l.cc_stat_ring) hipHostFree(l.cc_stat_ring);
-        for (hipEvent_t e : l.cc_stat_evs)
-            if (e) hipEventDestroy(e);
         if (l.done) hipEventDestroy(l.done);
         if (l.stream) hipStreamDestroy(l.stream);
     }

@@ -36,14 +36,13 @@ struct CtxLane {
     size_t cc_ovf_bytes = 0;
     void *cc_slab = nullptr;
     size_t cc_slab_bytes = 0;
-    // overflow counts of the last large-batch bboxcc call on this lane: pinned host words {overflowed pass 1, overflowed pass 2, frames with more runs than the base capacity}, valid once
-    // cc_stat_ev has completed (bboxcc.hip adapts the next call's first-pass capacity to them)
-    // (a ring of four such records with an event each, so that recording a call's counts never waits for the GPU)
-    int32_t *cc_stat = nullptr;          // the pair of the most recent call (points into cc_stat_ring)
+    // overflow counters of the last completed large-batch bboxcc call on this lane: pinned, device-visible words
+    // {overflowed pass 1, overflowed pass 2, sampled frames with 128 < runs <= 192 / <= 256 / more, batch, capacity of pass 1}
+    // written by the call's last kernel (no copy, no event); bboxcc.hip adapts the next call's plan to them
+    int32_t *cc_stat = nullptr;
     int32_t *cc_stat_ring = nullptr;
-    hipEvent_t cc_stat_evs[4] = {};
-    hipEvent_t cc_stat_ev = nullptr;     // the most recent call's event
-    unsigned cc_stat_turn = 0;
+    unsigned cc_stat_turn = 0;           // which of the two device counter sets the next call uses
+    bool cc_second_skipped = false;      // the last call ran without the second-chance pass
     int cc_stat_batch = 0, cc_stat_cap = 0;
     int cc_first_cap = 0;                // first-pass capacity the statistics last decided on (0: none yet)
 };
