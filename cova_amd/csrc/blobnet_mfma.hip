@@ -79,31 +79,25 @@ inline _Float16 f2h(float v) { return (_Float16)v; }
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, uint32_t mul) { return mul ? __umulhi(n, mul) : n; }
 inline uint32_t magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) / d) + 1); }
 
-// relu -> BN affine -> 2x2 max-pool of the four conv outputs of one window.  BN runs between
-// ReLU and the pool (encoder.py:61-66) and gamma may be negative, so the pool picks the max
-// for scale >= 0 and the min otherwise: max_q(relu(a_q)*s + b) = relu(sel_q a_q)*s + b.
-// The conv bias commutes with max/min and is added after the selection.
-// ALLPOS: every BN scale s of the level is >= 0 (checked on the host).  Then s is folded into the
-// weights and the bias on the host (relu(x)*s = relu(x*s)) and, with b' = bias*s,
-//   relu(mx + b') + shift = max(mx, -b') + (b' + shift)
-// so one window costs two v_max3 and one add: e0 = -b', e1 = b' + shift.
-// Otherwise e0 = bias, e1 = scale, e2 = shift with unfolded weights.
+// relu -> BN affine -> 2x2 max-pool of the four conv outputs of one window.  BN runs between ReLU and the pool
+// (encoder.py:61-66) and gamma may be negative.  The BN scale s of a channel is folded into its weights and bias on the host
+// WHATEVER ITS SIGN (a' = s * conv, b' = s * bias), which turns the per-pixel expression relu(conv + bias) * s + shift into
+//   s >= 0:  max(a' + b', 0) + shift        s < 0:  min(a' + b', 0) + shift
+// and both commute with the window's max (s < 0: the folded weights have flipped the order, the window's max of
+// relu(.) * s is at the max of a'):
+//   s >= 0:  max(mx, -b') + (b' + shift)    s < 0:  min(mx, -b') + (b' + shift),      mx = max of the four a'
+// ALLPOS (every scale of the level >= 0, checked on the host): two v_max3 and one add, e0 = -b', e1 = b' + shift.
+// Otherwise ONE form for both signs (round 4): r = med3(mx, lo, hi) + e1 with (lo, hi) = (-b', +big) or (-big, -b') per
+// channel (e0 = lo, e2 = hi): v_max3, v_max, v_med3, v_add -- four instructions per window instead of the ~10 of the
+// select-max-or-min form of rounds 1-3, so one negative gamma no longer costs the level 10 %.
 template <bool ALLPOS>
 __device__ __forceinline__ float pool4(float a0, float a1, float a2, float a3, float e0, float e1, float e2) {
     if constexpr (ALLPOS) {
         const float t = fmaxf(fmaxf(a0, a1), a2);
         return fmaxf(fmaxf(t, a3), e0) + e1;
     } else {
-        const float mx = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
-        const float mn = fminf(fminf(a0, a1), fminf(a2, a3));
-        const float sel = e1 >= 0.f ? mx : mn;
-        // an explicit fma: every kernel that shares this epilogue must round the same way whatever the compiler
-        // would otherwise contract (the carrier-frame and the stacked path are compared bit for bit)
-        float r = __builtin_fmaf(fmaxf(sel + e0, 0.f), e1, e2);
-        // ... and an opaque result: wherever the caller converts it to fp16, hipcc must not fold this fma and the
-        // conversion into one v_fma_mixlo_f16 (ONE rounding) in some instantiations and not in others
-        asm volatile("" : "+v"(r));
-        return r;
+        const float mx = fmaxf(fmaxf(fmaxf(a0, a1), a2), a3);
+        return __builtin_amdgcn_fmed3f(mx, e0, e2) + e1;
     }
 }
 
@@ -1679,21 +1673,21 @@ __global__ __launch_bounds__(ccbody::CC_THREADS) void dec3cc_mfma(Dec3ccArgs q) 
 }
 
 // ------------------------------------------------------------------ host-side weight preparation
-// Epilogue constants of an encoder level (see pool4): BN folded into the weights when every scale is >= 0.
+// Epilogue constants of an encoder level (see pool4): the BN scale is folded into the weights.
 void enc_epilogue(int cout, bool allpos, const float *bias, const float *gamma, const float *beta, const float *mean,
                   const float *var, std::vector<float> &wscale, float *epi) {
     wscale.assign(cout, 1.f);
     for (int c = 0; c < cout; c++) {
         const float sc = gamma[c] / std::sqrt(var[c] + BN_EPS), sh = beta[c] - mean[c] * sc;
+        wscale[c] = sc;                      // folded into the weights whatever its sign (see pool4)
+        const float bp = bias[c] * sc;
+        epi[cout + c] = bp + sh;
         if (allpos) {
-            wscale[c] = sc;
-            epi[c] = -(bias[c] * sc);
-            epi[cout + c] = bias[c] * sc + sh;
+            epi[c] = -bp;
             epi[2 * cout + c] = 0.f;
         } else {
-            epi[c] = bias[c];
-            epi[cout + c] = sc;
-            epi[2 * cout + c] = sh;
+            epi[c] = sc >= 0.f ? -bp : -3.0e38f;          // lo
+            epi[2 * cout + c] = sc >= 0.f ? 3.0e38f : -bp;  // hi
         }
     }
 }

@@ -16,6 +16,11 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 ctx = Context(0)
 ctx.set_lanes(int(os.environ.get("QB_LANES", "1")))      # per-kernel times want one step after the other
 flat = W.random_init(1234)
+if os.environ.get("QB_NEG_GAMMA"):          # mixed-sign BN gammas: the non-ALLPOS kernel variants
+    _p = W.unflatten(flat.copy())
+    for _i in range(4):
+        _p[f"enc{_i}.bn.gamma"][::2] *= -1.0
+    flat = W.flatten(_p)
 net = BlobNetInfer(ctx, flat, H, Wd, max_batch=B)
 if os.environ.get("QB_IMPL"):
     net.set_impl(os.environ["QB_IMPL"])
