@@ -295,6 +295,22 @@ def extra_legs(ctx, flat, steps):
     ctx.h2d(d_st, st)
     ms = timed_steps(ctx, lambda: net.infer_device(d_st, 32, None, d_mask), steps)
     out["config_blobnet_only_b32_68x120"] = {"frames_per_s": round(32 / ms * 1e3, 1), "ms_per_step": round(ms, 4)}
+    # ... and with batches in flight (filter entry on device pointers is what lanes apply to; bboxcc rides in the last launch)
+    d_bx = [ctx.malloc(32 * 512 * 20) for _ in range(4)]
+    d_ct = [ctx.malloc(32 * 4) for _ in range(4)]
+    tn = [0]
+
+    def step32():
+        tn[0] = (tn[0] + 1) % 4
+        net.filter_device(d_st, 32, CC_THRESHOLD, d_bx[tn[0]], d_ct[tn[0]], 512)
+    for nl in (1, 2, 4):
+        ctx.set_lanes(nl)
+        ms = timed_steps(ctx, step32, 2 * steps * nl, 8)
+        out["config_blobnet_only_b32_68x120"][f"filter_ms_per_step_{nl}_lanes"] = round(ms, 4)
+        out["config_blobnet_only_b32_68x120"][f"filter_frames_per_s_{nl}_lanes"] = round(32 / ms * 1e3, 1)
+    ctx.set_lanes(1)
+    for p in d_bx + d_ct:
+        ctx.free(p)
     ctx.free(d_st); ctx.free(d_mask)
     # the reference's own default: 720p grid 45x80, batch 512 (model/tasks.py:44-49)
     net = BlobNetInfer(ctx, flat, 45, 80, max_batch=512)
@@ -311,12 +327,25 @@ def extra_legs(ctx, flat, steps):
         wts[f"enc{i}.bn.gamma"][::2] *= -1.0
     net = BlobNetInfer(ctx, W.flatten(wts), H_MB, W_MB, max_batch=BATCH)
     st = synth.stacked_batch(BATCH, H_MB, W_MB, seed=7, streams=8)
-    d_st, d_b, d_c = ctx.malloc(st.nbytes), ctx.malloc(BATCH * MAX_BOXES * 20), ctx.malloc(BATCH * 4)
-    ctx.h2d(d_st, st)
-    ms = timed_steps(ctx, lambda: net.filter_device(d_st, BATCH, CC_THRESHOLD, d_b, d_c, MAX_BOXES), steps)
-    out["gamma_sign_mixed_b256_68x120"] = {"frames_per_s": round(BATCH / ms * 1e3, 1), "ms_per_step": round(ms, 4)}
-    for p in (d_st, d_b, d_c):
-        ctx.free(p)
+    frg, idg = synth.carrier_batch(BATCH, H_MB, W_MB, seed=7, streams=8)
+    d_fg = ctx.malloc(frg.nbytes)
+    ctx.h2d(d_fg, frg)
+    og = [(ctx.malloc(BATCH * MAX_BOXES * 20), ctx.malloc(BATCH * 4)) for _ in range(2)]
+    tg = [0]
+
+    def stepg():
+        tg[0] = 1 - tg[0]
+        net.filter_frames_device(d_fg, frg.shape[0], idg, BATCH, CC_THRESHOLD, og[tg[0]][0], og[tg[0]][1], MAX_BOXES)
+    ms1 = timed_steps(ctx, stepg, steps)
+    ctx.set_lanes(2)
+    ms2 = timed_steps(ctx, stepg, 2 * steps, 6)
+    ctx.set_lanes(1)
+    out["gamma_sign_mixed_b256_68x120"] = {"frames_per_s": round(BATCH / ms2 * 1e3, 1), "ms_per_step": round(ms2, 4),
+                                           "ms_per_step_one_lane": round(ms1, 4), "entry": "frames",
+                                           "note": "every other BN gamma of every encoder level negative (the med3 pooling epilogue)"}
+    ctx.free(d_fg)
+    for o in og:
+        ctx.free(o[0]); ctx.free(o[1])
     # the timed workload with a representative weight set (cova_amd.weights.blob_like: a few connected blobs per frame instead of
     # the ~500 one-macroblock components the seed-1234 random weights of `value` emit): bboxcc inside the fused tail has less to do
     net = BlobNetInfer(ctx, W.blob_like(7), H_MB, W_MB, max_batch=BATCH)
@@ -489,15 +518,30 @@ def main():
     assert np.array_equal(np.concatenate([frames[index[:, k]] for k in range(T)], axis=1), stack)
     d_frames = ctx.malloc(frames.nbytes)
     ctx.h2d(d_frames, frames)
+    # a SECOND batch (other streams, another stream interleaving -> a different stack table and different carrier frames): the
+    # timed steps alternate between the two, so that every step validates and uploads its table (a streaming caller's does change;
+    # an unchanged table is not uploaded again -- that cached figure is reported beside `value`)
+    frames_b, index_b = synth.carrier_batch(B, H_MB, W_MB, seed=seed + 77, streams=4)
+    stack_b = synth.stacked_batch(B, H_MB, W_MB, seed=seed + 77, streams=4)
+    d_frames_b, d_stack_b = ctx.malloc(frames_b.nbytes), ctx.malloc(stack_b.nbytes)
+    ctx.h2d(d_frames_b, frames_b)
+    ctx.h2d(d_stack_b, stack_b)
     turn = [0]
+    alternate = [True]
 
     def step_stack():
-        k = turn[0] = (turn[0] + 1) % NL
-        net.filter_device(d_stack, B, CC_THRESHOLD, d_boxes[k], d_counts[k], MAX_BOXES, d_mask[k])
+        turn[0] += 1
+        k = turn[0] % NL
+        second = alternate[0] and (turn[0] // NL) % 2 == 1
+        net.filter_device(d_stack_b if second else d_stack, B, CC_THRESHOLD, d_boxes[k], d_counts[k], MAX_BOXES, d_mask[k])
 
     def step_frames():
-        k = turn[0] = (turn[0] + 1) % NL
-        net.filter_frames_device(d_frames, frames.shape[0], index, B, CC_THRESHOLD, d_boxes[k], d_counts[k], MAX_BOXES, d_mask[k])
+        turn[0] += 1
+        k = turn[0] % NL
+        if alternate[0] and (turn[0] // NL) % 2 == 1:      # every lane sees the two batches in turn
+            net.filter_frames_device(d_frames_b, frames_b.shape[0], index_b, B, CC_THRESHOLD, d_boxes[k], d_counts[k], MAX_BOXES, d_mask[k])
+        else:
+            net.filter_frames_device(d_frames, frames.shape[0], index, B, CC_THRESHOLD, d_boxes[k], d_counts[k], MAX_BOXES, d_mask[k])
 
     step = step_frames if args.entry == "frames" else step_stack
     other = step_stack if args.entry == "frames" else step_frames
@@ -529,19 +573,40 @@ def main():
         n_w += 1
         if n_w % 64 == 0:
             ctx.sync()
-    # ---- timed region: K steps; only the dominant kernel carries HIP events (2 per step)
+    # ---- timed region: K steps between barriers; only the dominant kernel carries HIP events (2 per step).  A K-step region
+    # of a few tens of milliseconds is repeated (at least five times while it is shorter than 50 ms) and the MEDIAN region
+    # counts: `steps` stays K, every repeat is a complete barrier-to-barrier measurement of K steps.
     ctx.profile(True, only=dominant)
-    barrier()
-    t0 = time.perf_counter()
-    ctx.timer_start(0)
-    for _ in range(args.steps):
-        step()
-    ctx.timer_stop(0)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ev_ms = ctx.timer_ms(0)
+    regions, ev_regions = [], []
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        ctx.timer_start(0)
+        for _ in range(args.steps):
+            step()
+        ctx.timer_stop(0)
+        barrier()
+        regions.append(grp.max(time.perf_counter() - t0))     # the slowest rank's region (every rank appends the same number)
+        ev_regions.append(ctx.timer_ms(0))
+        if len(regions) >= 5 or (len(regions) >= 1 and regions[0] >= 0.05):
+            break
+    order = sorted(range(len(regions)), key=lambda i: regions[i])
+    mid = order[len(order) // 2]
+    elapsed = regions[mid]
+    ev_ms = ev_regions[mid]
     dom_ms, dom_n = ctx.profile_read()[dominant]
     ctx.profile(False)
+    # the same K steps with ONE batch (unchanged stack table: no validation upload after the first step), for comparison
+    alternate[0] = False
+    for _ in range(2 * NL):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed_cached = grp.max(time.perf_counter() - t0)
+    # (the legs and cross-checks below stay on the first batch)
     # shader clock under this load: a probe wave beside 60 more steps (untimed)
     for _ in range(60):
         step()
@@ -602,8 +667,6 @@ def main():
         rank0["frames_per_s_pcie_inclusive_pipelined_carrier_frames"] = pipelined_host_rate(net, frames, index, args.steps)
         ctx.set_lanes(1)
 
-    elapsed = grp.max(elapsed)
-
     if rank == 0:
         macs = kernel_macs_per_frame()
         kbytes = kernel_bytes_per_frame()
@@ -644,6 +707,10 @@ def main():
             "lanes": NL,
             **({"rehearsal": f"{world} ranks shared the GPUs present on this box: not a scaling result"} if args.rehearse_on_one_gpu else {}),
             "ms_per_step_one_lane": round(serial_ms, 4),
+            "value_one_lane": round(world * B / serial_ms * 1e3, 1),
+            "timed_regions_s": [round(r, 5) for r in regions],
+            "timed_region": f"median of {len(regions)} barrier-to-barrier regions of {args.steps} steps each",
+            "ms_per_step_table_cached": round(elapsed_cached / args.steps * 1e3, 4),
             "shader_clock_mhz_under_load": round(clock_mhz, 1),
             "blobnet_mfma_util_whole_net": round(total_flop / step_s / 1e12 / MFMA_PEAK_TFLOPS, 4),
             "blobnet_mfma_util_whole_net_executed": round(executed_flop / step_s / 1e12 / MFMA_PEAK_TFLOPS, 4),
@@ -712,7 +779,10 @@ def main():
                           "lanes_note": (f"{NL} batches of {B} in flight per GPU on {NL} HIP streams with a workspace each, as the reference keeps "
                                          "16 BlobNet engines busy on one GPU (experiment/cova/config.yaml:33-34); ms_per_step = wall time / steps; "
                                          "ms_per_step_one_lane = one step after the other"),
-                          "stack_table": "the same table every step: validated and uploaded once, then found unchanged (blobnet.hip prepare_frames)",
+                          "stack_table": ("two batches (different streams and interleaving: different carrier frames, different stack tables) alternate "
+                                          "across the timed steps of every lane; every step validates its table on the host and hands it to the "
+                                          "level-1 kernel by value, in its kernel arguments (blobnet.hip prepare_frames; no copy in front of the "
+                                          "kernels); ms_per_step_table_cached = the same steps on ONE batch"),
                           "batch_per_gpu": B, "grid_mb": [H_MB, W_MB], "timestep": T, "cc_threshold": CC_THRESHOLD,
                           "parallelism": f"{world} x independent per-GPU batches, no collective"}
         print(json.dumps(line), flush=True)

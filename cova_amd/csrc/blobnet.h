@@ -8,6 +8,7 @@
 
 constexpr int BN_T = 4;       // timestep the network is built for (utils/train-blobnet.py:58)
 constexpr int BN_LEVELS = 4;
+constexpr int BN_KTAB_STACKS = 256;   // stacks whose table (16-bit frame indices, 2 KB) travels in enc1_mfma's kernel arguments
 
 struct BnLevelGeom {
     int H, W;  // spatial size of the tensor at this level (level 0 = network input)
@@ -66,7 +67,10 @@ struct BnInput {
     const uint8_t *stack = nullptr;
     const uint8_t *frames = nullptr;
     int n_frames = 0;
-    const int32_t *index = nullptr;   // i32 [batch][4]
+    const int32_t *index = nullptr;   // i32 [batch][4] on the device, or null when h_index is used / for the stacked entry
+    // the same table on the host (validated): batches of at most BN_KTAB_STACKS stacks hand it to the level-1 kernel BY VALUE, in
+    // its kernel arguments -- no copy in front of the kernels, nothing to cache or to order
+    const int32_t *h_index = nullptr;
     bool dry = false;
 };
 int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, const BnInput &in, int batch, float *d_logits,

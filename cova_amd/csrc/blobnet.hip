@@ -87,6 +87,18 @@ static int prepare_frames(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws,
             if (f < 0 || f >= n_frames) return COVAHIP_ERR_INVALID_ARG;
             table[(size_t)b * BN_T + t] = f;
         }
+    // small batches: the table travels in the level-1 kernel's arguments (blobnet_mfma.hip); the device copy below is for
+    // larger ones and for the round-1..3 level-1 kernel
+    const bool by_value = batch <= BN_KTAB_STACKS && n_frames <= 65535 && m->enc1_tile16 && !ctx->enc_plan[1].nbands &&
+                          m->lv[1].W <= 62;
+    if (by_value) {
+        ws.last_table = std::move(table);      // (kept alive until the launch has copied it)
+        ws.last_n_frames = -1;                 // the device table, if any, is stale
+        in.h_index = ws.last_table.data();
+        in.frames = d_frames;
+        in.n_frames = n_frames;
+        return ensure_pbuf(ctx, m, ws, n_frames);
+    }
     const bool same = ws.d_index && table == ws.last_table && n_frames == ws.last_n_frames;
     if (!same) {
         const size_t need = table.size();

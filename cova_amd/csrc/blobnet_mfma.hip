@@ -852,6 +852,10 @@ struct Enc1Args {
     const int32_t *pidx; // frames of the T = 0..3 slices of every stack; null: stack b = frames 4b .. 4b+3 (stacked entry)
     __half *skip;        // [B][T][H][W][16], T = 0 written (the decoder's skip input)
     const float *tm_pre; // w1[16], w2[16] of the level below
+    // the stack table BY VALUE (use_ktab): frames of stack b = ktab[4b .. 4b+3]; read from the kernel-argument segment with
+    // scalar loads.  A table that changes from call to call then costs no copy in front of the kernels.
+    int use_ktab;
+    uint16_t ktab[BN_KTAB_STACKS * BN_T];
 };
 // Per-lane constants live in a small LDS table behind the scratch instead of registers (hipcc keeps every loop-invariant
 // load in a register for the whole kernel):
@@ -907,7 +911,13 @@ __global__ __launch_bounds__(512, 4) void enc1_mfma(Enc1Args p) {
         // launch and never written by a kernel); the stacked entry's frames are 4b .. 4b+3
         int fidx[BN_T] = {BN_T * b, BN_T * b + 1, BN_T * b + 2, BN_T * b + 3};
         const uint8_t *const fbase = reinterpret_cast<const uint8_t *>(p.in);
-        if (p.pidx) {
+        if (p.use_ktab) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            typedef const __attribute__((address_space(4))) u32x2 *const_u32x2_ptr;
+            const __attribute__((address_space(4))) uint8_t *ka = (const __attribute__((address_space(4))) uint8_t *)__builtin_amdgcn_kernarg_segment_ptr();
+            const u32x2 row = *(const_u32x2_ptr)(ka + offsetof(Enc1Args, ktab) + (size_t)b * 8);
+            fidx[0] = row[0] & 0xFFFF; fidx[1] = row[0] >> 16; fidx[2] = row[1] & 0xFFFF; fidx[3] = row[1] >> 16;
+        } else if (p.pidx) {
             typedef int i32x4 __attribute__((ext_vector_type(4)));
             typedef const __attribute__((address_space(4))) i32x4 *const_i32x4_ptr;
             const i32x4 row = *(const_i32x4_ptr)(uintptr_t)(p.pidx + b * BN_T);
@@ -2097,6 +2107,13 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
                 const int grid = std::min(batch * nbands, 2 * num_cu);
                 a.plan = make_plan(grid, num_cu, 2, batch, nbands, Hp);
                 a.pidx = d_index; a.skip = act[1]; a.tm_pre = (const float *)(prep + pr->enc[0].epi) + 48;
+                a.use_ktab = 0;
+                if (by_frames && inp.h_index && batch <= BN_KTAB_STACKS) {
+                    a.use_ktab = 1;
+                    for (int k = 0; k < batch * BN_T; k++) a.ktab[k] = (uint16_t)inp.h_index[k];
+                } else if (by_frames && !d_index && !dry) {
+                    return COVAHIP_ERR_INVALID_ARG;
+                }
                 const size_t lds = (size_t)BN_T * E1_TSZ + 8 * 1024 + E1_CONST;
                 int rc = pr->allpos[1] ? set_lds(ctx, enc1_mfma<true>, lds) : set_lds(ctx, enc1_mfma<false>, lds);
                 if (rc) return rc;
