@@ -373,16 +373,20 @@ def extra_legs(ctx, flat, steps):
 
 
 def pipelined_host_rate(net, frames, index, steps):
-    """PCIe-inclusive, carrier frames in / packed boxes out through covahip_pipe (pinned slots, three HIP streams)."""
-    from cova_amd.elements import FilterPipe
+    """PCIe-inclusive, carrier frames in / packed boxes out through covahip_pipe (pinned slots, three HIP streams).  The frames
+    cross PCIe as two-byte records (covahip_carrier_pack, what the batching element does too); "four_byte_frames" is the same with
+    the decoder's four bytes per macroblock."""
+    from cova_amd.elements import FilterPipe, pack_frames
     B, nf = index.shape[0], frames.shape[0]
-    pipe = FilterPipe(net, max_batch=B, max_frames=nf, max_boxes=MAX_BOXES, n_slots=3)
     res = {}
-    for fill in (False, True):
+    for packed, fill in ((True, False), (True, True), (False, False)):
+      pipe = FilterPipe(net, max_batch=B, max_frames=nf, max_boxes=MAX_BOXES, n_slots=3, packed=packed)
+      src = pack_frames(frames) if packed else frames
+      for fill in (fill,):
         slots = []
         for _ in range(3):                     # every slot holds the batch once; warms the plan and the speculative copy size
             slot, pf, pi = pipe.acquire()
-            pf[:nf] = frames; pi[:B] = index
+            pf[:nf] = src; pi[:B] = index
             pipe.submit(slot, nf, B, CC_THRESHOLD)
             slots.append(slot)
         for slot in slots:
@@ -395,15 +399,16 @@ def pipelined_host_rate(net, frames, index, steps):
                 pipe.collect(inflight.pop(0))
                 acq = pipe.acquire()
             slot, pf, pi = acq
-            if fill:
-                pf[:nf] = frames; pi[:B] = index
+            if fill:      # the element's per-frame work on ONE thread: pack every carrier frame into the slot
+                pf[:nf] = pack_frames(frames); pi[:B] = index
             pipe.submit(slot, nf, B, CC_THRESHOLD)
             inflight.append(slot)
         for slot in inflight:
             pipe.collect(slot)
-        res["with_host_fill_one_thread" if fill else "slots_prefilled"] = round(steps * B / (time.perf_counter() - t0), 1)
-    pipe.acquire()   # releases the held result views
-    pipe.close()
+        key = "four_byte_frames_slots_prefilled" if not packed else "with_host_fill_one_thread" if fill else "slots_prefilled"
+        res[key] = round(steps * B / (time.perf_counter() - t0), 1)
+      pipe.acquire()   # releases the held result views
+      pipe.close()
     return res
 
 

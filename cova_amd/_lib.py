@@ -99,6 +99,7 @@ PROTOTYPES = {
     "covahip_filter_forward_frames": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int]),
     "covahip_pipe_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "covahip_pipe_destroy": (None, [_P]),
+    "covahip_pipe_set_packed": (C.c_int, [_P, C.c_int]),
     "covahip_pipe_acquire": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(_P)]),
     "covahip_pipe_submit": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "covahip_pipe_wait": (C.c_int, [_P, C.c_int]),
@@ -133,6 +134,8 @@ PROTOTYPES = {
     "covahip_h264_open_avcc": (C.c_int, [_P, _SZ, C.POINTER(_P)]),
     "covahip_h264_decode_au": (C.c_int, [_P, _P, _SZ, _P, _SZ, _P, C.POINTER(C.c_int64)]),
     "covahip_carrier_write_records": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _SZ]),
+    "covahip_carrier_pack": (None, [_P, _SZ, _P]),
+    "covahip_filter_forward_frames_packed": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
     "covahip_stack_new": (C.c_int, [_SZ, C.c_uint, C.c_uint, C.POINTER(_P)]),
     "covahip_stack_free": (None, [_P]),
     "covahip_stack_push": (C.c_int, [_P, _P, _SZ, _P, _SZ, C.POINTER(C.c_int)]),

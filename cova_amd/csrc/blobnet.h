@@ -71,6 +71,7 @@ struct BnInput {
     // the same table on the host (validated): batches of at most BN_KTAB_STACKS stacks hand it to the level-1 kernel BY VALUE, in
     // its kernel arguments -- no copy in front of the kernels, nothing to cache or to order
     const int32_t *h_index = nullptr;
+    bool packed = false;   // carrier frames as two-byte records (covahip_carrier_pack) instead of the decoder's four bytes
     bool dry = false;
 };
 int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, const BnInput &in, int batch, float *d_logits,

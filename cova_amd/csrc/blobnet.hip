@@ -287,7 +287,7 @@ int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl) {
 // The hot path on device pointers, on ctx->stream with the current lane's workspace (the caller has placed the call).
 static int filter_placed(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_src, int n_frames, const int32_t *stack_index,
                          int batch, int area_thresh, covahip_box *d_boxes, int32_t *d_counts, int max_boxes, float *d_logits,
-                         uint8_t *d_mask) {
+                         uint8_t *d_mask, bool packed = false) {
     if (!d_mask) {
         CtxLane &l = ctx->lane();
         int rc = covahip_ensure_buffer(ctx, &l.cc_scratch, &l.cc_scratch_bytes, (size_t)batch * m->H * m->W);
@@ -298,6 +298,7 @@ static int filter_placed(covahip_ctx *ctx, covahip_blobnet *m, const uint8_t *d_
     if (n_frames > 0) {
         int rc = prepare_frames(ctx, m, m->ws[ctx->cur_lane], d_src, n_frames, stack_index, batch, in);
         if (rc) return rc;
+        in.packed = packed;
     } else {
         in.stack = d_src;
     }
@@ -367,6 +368,21 @@ int covahip_filter_forward_frames(covahip_ctx *ctx, const uint8_t *frames, int n
                                   float *logits, uint8_t *mask, int mem_kind) {
     if (n_frames <= 0) return COVAHIP_ERR_INVALID_ARG;
     return filter_any(ctx, frames, n_frames, stack_index, batch, area_thresh, boxes, counts, max_boxes, logits, mask, mem_kind);
+}
+
+int covahip_filter_forward_frames_packed(covahip_ctx *ctx, const uint16_t *d_records, int n_frames, const int32_t *stack_index,
+                                         int batch, int area_thresh, covahip_box *d_boxes, int32_t *d_counts, int max_boxes,
+                                         float *d_logits, uint8_t *d_mask) {
+    if (!ctx || batch < 0 || max_boxes < 0 || n_frames <= 0) return COVAHIP_ERR_INVALID_ARG;
+    covahip_blobnet *m = ctx->blobnet;
+    if (!m) return COVAHIP_ERR_NOT_LOADED;
+    if (batch == 0) return COVAHIP_OK;
+    if (!d_records || !d_counts || (!d_boxes && max_boxes > 0) || batch > m->max_batch) return COVAHIP_ERR_INVALID_ARG;
+    COVAHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    LaneScope lane(ctx);
+    if (!lane.ok()) return COVAHIP_ERR_HIP;
+    return filter_placed(ctx, m, reinterpret_cast<const uint8_t *>(d_records), n_frames, stack_index, batch, area_thresh, d_boxes, d_counts,
+                         max_boxes, d_logits, d_mask, true);
 }
 
 int covahip_blobnet_forward(covahip_ctx *ctx, const uint8_t *rgba_stack, int batch, float *logits, uint8_t *mask,

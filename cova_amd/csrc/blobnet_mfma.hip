@@ -351,7 +351,7 @@ struct Enc0pArgs {
     uint32_t mWp, mNb, mW4;
     int scr_off;        // per-wave output scratch (1 KB per wave) behind the tile
 };
-template <bool ALLPOS>
+template <bool ALLPOS, bool PACKED>
 __global__ __launch_bounds__(WG0, 4) void enc0p_mfma(Enc0pArgs p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     WGSPAN_BEGIN();
@@ -371,35 +371,56 @@ __global__ __launch_bounds__(WG0, 4) void enc0p_mfma(Enc0pArgs p) {
         {   // stage rows y0-1 .. y0+rows as fp16 (see enc0_mfma); the host keeps n2 * W/4 <= 2 * WG0
             const int W4 = p.W >> 2;
             const int per_t = n2 * W4;
-            const uint8_t *fb = p.in + (size_t)f * p.H * p.W * 4;
+            // PACKED: two bytes per macroblock, min(type, 6) | min(mv_x, 6) << 3 | min(mv_y, 6) << 6 (covahip_carrier_pack) --
+            // what the network keeps of a record anyway (clip at 6, preprocessing.py:6-7), at half the PCIe bytes
+            const uint8_t *fb = p.in + (size_t)f * p.H * p.W * (PACKED ? 2 : 4);
             uint4 v[2];
             int dsto[2];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 const int i = tid + k * WG0;
                 dsto[k] = -1;
+                v[k] = make_uint4(0, 0, 0, 0);
                 if (i < per_t) {
                     const int r = fdiv(i, p.mW4), c4 = i - r * W4;
                     const int y = y0 - 1 + r;
                     dsto[k] = r * TC * 8 + 16 + c4 * 32;
-                    v[k] = (y >= 0 && y < p.H) ? *reinterpret_cast<const uint4 *>(fb + ((size_t)y * p.W + c4 * 4) * 4)
-                                               : make_uint4(0, 0, 0, 0);
+                    if (y >= 0 && y < p.H) {
+                        if constexpr (PACKED) {
+                            const uint2 w = *reinterpret_cast<const uint2 *>(fb + ((size_t)y * p.W + c4 * 4) * 2);
+                            v[k].x = w.x; v[k].y = w.y;
+                        } else {
+                            v[k] = *reinterpret_cast<const uint4 *>(fb + ((size_t)y * p.W + c4 * 4) * 4);
+                        }
+                    }
                 }
             }
             const half2v clip = {(_Float16)1030.f, (_Float16)1030.f}, off = {(_Float16)1024.f, (_Float16)1024.f};
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 if (dsto[k] >= 0) {
-                    const uint32_t px[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
                     uint32_t o[8];
+                    if constexpr (PACKED) {
+                        const uint32_t pw[2] = {v[k].x, v[k].y};
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const uint32_t c01 = __builtin_amdgcn_perm(0x64646464u, px[q], 0x05010500u);
-                        const uint32_t c23 = __builtin_amdgcn_perm(0x64646464u, px[q], 0x05030502u);
-                        const half2v h01 = __builtin_elementwise_min(__builtin_bit_cast(half2v, c01), clip) - off;
-                        const half2v h23 = __builtin_elementwise_min(__builtin_bit_cast(half2v, c23), clip) - off;
-                        o[2 * q] = __builtin_bit_cast(uint32_t, h01);
-                        o[2 * q + 1] = __builtin_bit_cast(uint32_t, h23);
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t r = (pw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+                            const uint32_t c01 = 0x64006400u | (r & 7u) | (((r >> 3) & 7u) << 16);
+                            const uint32_t c23 = 0x64006400u | ((r >> 6) & 7u);
+                            o[2 * q] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, c01) - off);
+                            o[2 * q + 1] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, c23) - off);
+                        }
+                    } else {
+                        const uint32_t px[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t c01 = __builtin_amdgcn_perm(0x64646464u, px[q], 0x05010500u);
+                            const uint32_t c23 = __builtin_amdgcn_perm(0x64646464u, px[q], 0x05030502u);
+                            const half2v h01 = __builtin_elementwise_min(__builtin_bit_cast(half2v, c01), clip) - off;
+                            const half2v h23 = __builtin_elementwise_min(__builtin_bit_cast(half2v, c23), clip) - off;
+                            o[2 * q] = __builtin_bit_cast(uint32_t, h01);
+                            o[2 * q + 1] = __builtin_bit_cast(uint32_t, h23);
+                        }
                     }
                     uint8_t *d = smem + dsto[k];
                     *reinterpret_cast<uint4 *>(d) = make_uint4(o[0], o[1], o[2], o[3]);
@@ -2075,8 +2096,13 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
         const int grid = std::min(n_frames * nbands, 3 * num_cu);
         {
             ProfScope ps(ctx, "enc0p_mfma");
-            if (pr->allpos[0]) LAUNCH(enc0p_mfma<true>, dim3(grid), dim3(WG0), lds, ctx->stream, a);
-            else LAUNCH(enc0p_mfma<false>, dim3(grid), dim3(WG0), lds, ctx->stream, a);
+            if (inp.packed) {
+                if (pr->allpos[0]) LAUNCH((enc0p_mfma<true, true>), dim3(grid), dim3(WG0), lds, ctx->stream, a);
+                else LAUNCH((enc0p_mfma<false, true>), dim3(grid), dim3(WG0), lds, ctx->stream, a);
+            } else {
+                if (pr->allpos[0]) LAUNCH((enc0p_mfma<true, false>), dim3(grid), dim3(WG0), lds, ctx->stream, a);
+                else LAUNCH((enc0p_mfma<false, false>), dim3(grid), dim3(WG0), lds, ctx->stream, a);
+            }
         }
         COVAHIP_CHECK_HIP(ctx, hipGetLastError());
     }

@@ -13,6 +13,9 @@
 //   (min-cost perfect matching), bincode 1.3.3 default config (LE, fixed-width ints,
 //   u64 length prefix, 1-byte Option tag).
 #include <algorithm>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -361,6 +364,12 @@ struct Tracker {  // KalmanBoxTracker, tracker/mod.rs:15-69
     bool has_prior = false;
     P xp[7];
     Mat7 Pp;  // prior
+    // predict() derives the prior from the previous ESTIMATE (x, Pm), which only a matched update() changes: a tracker that
+    // goes unmatched recomputes the same prior -- and the same predicted box -- frame after frame.  At the experiment's
+    // parameters (maxage 60, minhits 30) a stream carries dozens of such trackers, and their 7x7 covariance products were
+    // 44 % of the element's host time: the prior is kept while the estimate has not changed (same values, bit for bit).
+    bool prior_valid = false;
+    covahip_bbox prior_box{};
 
     Tracker(uint64_t id_, const covahip_bbox &b, uint64_t start_) : id(id_), start(start_), last_match(start_) {
         P z[4];
@@ -371,13 +380,17 @@ struct Tracker {  // KalmanBoxTracker, tracker/mod.rs:15-69
     }
 
     const covahip_bbox &predict(uint64_t ts) {  // tracker/mod.rs:104-121
-        if (x[6] + x[2] <= 0.f) x[6] = 0.f;
-        kalman_predict(x, Pm, xp, Pp);
-        has_prior = true;
-        covahip_bbox b = from_x(xp);
-        b.has_track_id = 1;
-        b.track_id = id;
-        b.has_timestamp = 1;
+        if (!prior_valid) {
+            if (x[6] + x[2] <= 0.f) x[6] = 0.f;
+            kalman_predict(x, Pm, xp, Pp);
+            has_prior = true;
+            prior_box = from_x(xp);
+            prior_box.has_track_id = 1;
+            prior_box.track_id = id;
+            prior_box.has_timestamp = 1;
+            prior_valid = true;
+        }
+        covahip_bbox b = prior_box;
         b.timestamp = ts;
         age += 1;
         time_since_update += 1;
@@ -401,6 +414,7 @@ struct Tracker {  // KalmanBoxTracker, tracker/mod.rs:15-69
             if (!kalman_update(xp, Pp, z, xn, Pn)) return false;
             std::memcpy(x, xn, sizeof(x));
             Pm = Pn;
+            prior_valid = false;   // the estimate has moved
             covahip_bbox &last = history.back();
             last.has_class_id = det->has_class_id;
             last.class_id = det->class_id;
@@ -505,6 +519,8 @@ struct Sort {  // sort/src/lib.rs:14-23
     P iou_threshold;
     std::vector<Tracker> trackers;
     uint64_t frame_count = 0, id_counter = 0;
+    std::vector<long> match_of_trk;        // scratch of update()
+    std::vector<uint8_t> det_matched;
 
     std::vector<std::pair<size_t, size_t>> match_dets(const std::vector<covahip_bbox> &preds,
                                                       const std::vector<covahip_bbox> &dets) const {
@@ -512,11 +528,37 @@ struct Sort {  // sort/src/lib.rs:14-23
         const size_t np = preds.size(), nd = dets.size();
         if (np == 0 || nd == 0) return res;
         std::vector<P> cost(np * nd);  // column-major: rows = predictions, cols = detections
+        std::vector<uint8_t> overlaps(np, 0);
         for (size_t j = 0; j < nd; j++)
             for (size_t i = 0; i < np; i++) {
                 const P w = trackers[i].active ? 1.f : 2.f;  // lib.rs:108-113
-                cost[j * np + i] = -bbox_iou(dets[j], preds[i]) + w;
+                const P iou = bbox_iou(dets[j], preds[i]);
+                overlaps[i] |= iou != 0.f;
+                cost[j * np + i] = -iou + w;
             }
+        // Trackers that overlap NO detection all carry the same cost row (1 in every column when active, 2 when not), and an
+        // edge to one of them never survives the filters below (1 > 1 - iou_threshold; == 2.0).  Of each of the two classes at
+        // most n_dets members can take part in an optimal assignment and which ones is immaterial, so only the first n_dets of
+        // each class stay in the problem: same optimum value, same surviving edges, and the solver's work drops from
+        // n_dets^2 x trackers to about n_dets^3 (at the experiment's maxage 60 / minhits 30 a stream carries 100 - 250
+        // trackers, nearly all of them idle: 50 -> 3 us per frame at 11 detections x 256 trackers).
+        std::vector<size_t> keep;
+        keep.reserve(np);
+        size_t idle[2] = {0, 0};
+        for (size_t i = 0; i < np; i++)
+            if (overlaps[i] || idle[trackers[i].active ? 0 : 1]++ < nd) keep.push_back(i);
+        if (keep.size() < np) {
+            const size_t nk = keep.size();
+            std::vector<P> red(nk * nd);
+            for (size_t j = 0; j < nd; j++)
+                for (size_t k = 0; k < nk; k++) red[j * nk + k] = cost[j * np + keep[k]];
+            for (auto &e : linear_assignment(red, nk, nd)) {
+                const size_t i = keep[e.first];
+                const P thr = trackers[i].active ? (1.f - iou_threshold) : (2.f - iou_threshold);
+                if (cost[e.second * np + i] <= thr) res.emplace_back(i, e.second);
+            }
+            return res;
+        }
         for (auto &e : linear_assignment(cost, np, nd)) {
             const P thr = trackers[e.first].active ? (1.f - iou_threshold) : (2.f - iou_threshold);
             if (cost[e.second * np + e.first] <= thr) res.push_back(e);
@@ -532,21 +574,24 @@ struct Sort {  // sort/src/lib.rs:14-23
         preds.reserve(trackers.size());
         for (auto &t : trackers) preds.push_back(t.predict(pts));
         auto matches = match_dets(preds, dets);
-        std::vector<size_t> unmatched;
-        for (size_t j = 0; j < n_dets; j++) {
-            bool m = false;
-            for (auto &e : matches) m |= (e.second == j);
-            if (!m) unmatched.push_back(j);
+        // (a tracker / detection appears in at most one pair; the first pair of a tracker wins, as in the reference's `find`)
+        match_of_trk.assign(trackers.size(), -1);
+        det_matched.assign(n_dets, 0);
+        for (auto &e : matches) {
+            if (match_of_trk[e.first] < 0) match_of_trk[e.first] = (long)e.second;
+            det_matched[e.second] = 1;
         }
+        std::vector<size_t> unmatched;
+        for (size_t j = 0; j < n_dets; j++)
+            if (!det_matched[j]) unmatched.push_back(j);
         for (size_t i = 0; i < trackers.size(); i++) {
             const covahip_bbox *det = nullptr;
-            for (auto &e : matches)
-                if (e.first == i) {
-                    dets[e.second].has_timestamp = 1;
-                    dets[e.second].timestamp = pts;
-                    det = &dets[e.second];
-                    break;
-                }
+            if (match_of_trk[i] >= 0) {
+                covahip_bbox &d = dets[(size_t)match_of_trk[i]];
+                d.has_timestamp = 1;
+                d.timestamp = pts;
+                det = &d;
+            }
             if (!trackers[i].update(det)) return false;
         }
         for (auto &t : trackers) t.check_activate(min_hits);
@@ -619,6 +664,47 @@ struct covahip_sort {
 };
 
 extern "C" {
+
+// SSE2 (x86-64 baseline): 8 records per step -- byte minima, three masked shifts per 32-bit record, signed pack to 16 bits.
+// (The plain loop is not vectorised by gcc / clang -- stride-4 byte gathers -- and took 7 us per 1080p frame, against 1.9 us
+// for the memcpy it replaces; this form takes about 1 us.)
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static size_t carrier_pack_avx2(const uint8_t *frame, size_t n_mb, uint16_t *records) {
+    const __m256i six = _mm256_set1_epi8(6), m0 = _mm256_set1_epi32(0x7), m1 = _mm256_set1_epi32(0x38), m2 = _mm256_set1_epi32(0x1C0);
+    size_t i = 0;
+    for (; i + 16 <= n_mb; i += 16) {
+        __m256i a = _mm256_min_epu8(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(frame + 4 * i)), six);
+        __m256i b = _mm256_min_epu8(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(frame + 4 * i + 32)), six);
+        a = _mm256_or_si256(_mm256_or_si256(_mm256_and_si256(a, m0), _mm256_and_si256(_mm256_srli_epi32(a, 5), m1)), _mm256_and_si256(_mm256_srli_epi32(a, 10), m2));
+        b = _mm256_or_si256(_mm256_or_si256(_mm256_and_si256(b, m0), _mm256_and_si256(_mm256_srli_epi32(b, 5), m1)), _mm256_and_si256(_mm256_srli_epi32(b, 10), m2));
+        // packs works per 128-bit half: a.lo b.lo | a.hi b.hi -> restore the order with a 64-bit permute
+        _mm256_storeu_si256(reinterpret_cast<__m256i *>(records + i), _mm256_permute4x64_epi64(_mm256_packs_epi32(a, b), 0xD8));
+    }
+    return i;
+}
+#endif
+
+void covahip_carrier_pack(const uint8_t *frame, size_t n_mb, uint16_t *records) {
+    size_t i = 0;
+#if defined(__x86_64__)
+    static const bool have_avx2 = __builtin_cpu_supports("avx2");
+    if (have_avx2) i = carrier_pack_avx2(frame, n_mb, records);
+#endif
+#if defined(__SSE2__)
+    const __m128i six = _mm_set1_epi8(6), m0 = _mm_set1_epi32(0x7), m1 = _mm_set1_epi32(0x38), m2 = _mm_set1_epi32(0x1C0);
+    for (; i + 8 <= n_mb; i += 8) {
+        __m128i a = _mm_min_epu8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(frame + 4 * i)), six);
+        __m128i b = _mm_min_epu8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(frame + 4 * i + 16)), six);
+        a = _mm_or_si128(_mm_or_si128(_mm_and_si128(a, m0), _mm_and_si128(_mm_srli_epi32(a, 5), m1)), _mm_and_si128(_mm_srli_epi32(a, 10), m2));
+        b = _mm_or_si128(_mm_or_si128(_mm_and_si128(b, m0), _mm_and_si128(_mm_srli_epi32(b, 5), m1)), _mm_and_si128(_mm_srli_epi32(b, 10), m2));
+        _mm_storeu_si128(reinterpret_cast<__m128i *>(records + i), _mm_packs_epi32(a, b));
+    }
+#endif
+    for (; i < n_mb; i++) {
+        const unsigned t = frame[4 * i], x = frame[4 * i + 1], y = frame[4 * i + 2];
+        records[i] = (uint16_t)((t < 6 ? t : 6) | ((x < 6 ? x : 6) << 3) | ((y < 6 ? y : 6) << 6));
+    }
+}
 
 int covahip_sort_new(uint64_t max_age, uint64_t min_hits, float iou_threshold, covahip_sort **out) {
     if (!out) return COVAHIP_ERR_INVALID_ARG;

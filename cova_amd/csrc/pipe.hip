@@ -82,7 +82,7 @@ struct Slot {
 
 struct covahip_pipe {
     covahip_ctx *ctx = nullptr;
-    int max_batch = 0, max_frames = 0, max_boxes = 0, n_slots = 0, want_mask = 0;
+    int max_batch = 0, max_frames = 0, max_boxes = 0, n_slots = 0, want_mask = 0, packed = 0;
     size_t frame_bytes = 0, hw = 0;
     int spec = 0;                    // packed boxes copied back by the pipelined D2H; grows to what the stream produces
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
@@ -166,6 +166,15 @@ int covahip_pipe_create(covahip_ctx *ctx, int max_batch, int max_frames, int max
     return COVAHIP_OK;
 }
 
+int covahip_pipe_set_packed(covahip_pipe *p, int on) {
+    if (!p) return COVAHIP_ERR_INVALID_ARG;
+    for (const Slot &s : p->slots)
+        if (s.state != 0) return COVAHIP_ERR_INVALID_ARG;   // not with slots acquired or in flight
+    p->packed = on != 0;
+    p->frame_bytes = p->hw * (p->packed ? 2 : 4);
+    return COVAHIP_OK;
+}
+
 int covahip_pipe_acquire(covahip_pipe *p, int *slot, uint8_t **frames, int32_t **stack_index) {
     if (!p || !slot || !frames || !stack_index) return COVAHIP_ERR_INVALID_ARG;
     for (int k = 0; k < p->n_slots; k++) {
@@ -196,8 +205,10 @@ int covahip_pipe_submit(covahip_pipe *p, int slot, int n_frames, int batch, int 
     if (!lane.ok()) return COVAHIP_ERR_HIP;
     PIPE_CHECK(hipStreamWaitEvent(ctx->stream, s.ev_in, 0));
     int32_t *d_counts = s.d_meta, *d_offsets = s.d_meta + p->max_batch;
-    int rc = covahip_filter_forward_frames(ctx, s.d_frames, n_frames, s.h_index, batch, area_thresh, s.d_boxes, d_counts, p->max_boxes,
-                                           nullptr, s.d_mask, COVAHIP_MEM_DEVICE);
+    int rc = p->packed ? covahip_filter_forward_frames_packed(ctx, reinterpret_cast<const uint16_t *>(s.d_frames), n_frames, s.h_index, batch,
+                                                              area_thresh, s.d_boxes, d_counts, p->max_boxes, nullptr, s.d_mask)
+                       : covahip_filter_forward_frames(ctx, s.d_frames, n_frames, s.h_index, batch, area_thresh, s.d_boxes, d_counts,
+                                                       p->max_boxes, nullptr, s.d_mask, COVAHIP_MEM_DEVICE);
     if (rc) return rc;
     {
         ProfScope ps(ctx, "pack_boxes");

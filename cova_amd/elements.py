@@ -249,18 +249,29 @@ class BlobNetInfer:
                 "covahip_filter_forward", self.ctx.handle)
 
 
+def pack_frames(frames: np.ndarray) -> np.ndarray:
+    """covahip_carrier_pack: carrier frames u8 [..][h][w][4] -> two-byte records u16 [..][h][w]."""
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    out = np.empty(frames.shape[:-1], dtype=np.uint16)
+    L.lib().covahip_carrier_pack(frames.ctypes.data_as(C.c_void_p), frames.size // 4, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 class FilterPipe:
     """covahip_pipe_*: batches of carrier frames in pinned host memory, H2D / kernels / D2H of consecutive batches
     overlapped on three HIP streams, boxes compacted on the device."""
 
     def __init__(self, net: "BlobNetInfer", max_batch: int, max_frames: int, max_boxes: int = 256, n_slots: int = 3,
-                 want_mask: bool = False):
+                 want_mask: bool = False, packed: bool = False):
         self.net, self.max_batch, self.max_frames, self.max_boxes = net, max_batch, max_frames, max_boxes
+        self.packed = packed
         self._lib = L.lib()
         h = C.c_void_p()
         L.check(self._lib.covahip_pipe_create(net.ctx.handle, max_batch, max_frames, max_boxes, n_slots, int(want_mask),
                                               C.byref(h)), "covahip_pipe_create", net.ctx.handle)
         self._h = h
+        if packed:      # the slots take two-byte records (pack_frames) instead of the decoder's four bytes per macroblock
+            L.check(self._lib.covahip_pipe_set_packed(h, 1), "covahip_pipe_set_packed")
         self._batch = {}
         self._views = {}     # slot -> numpy views of its pinned input buffers (the addresses never change)
         self._held = []      # collected slots whose result views are still handed out
@@ -273,8 +284,9 @@ class FilterPipe:
     __del__ = close
 
     def acquire(self):
-        """-> (slot, frames u8 [max_frames][h][w][4], index i32 [max_batch][4]): numpy views of the slot's pinned buffers,
-        or None when every slot is in flight.  Result views of earlier collect() calls become invalid."""
+        """-> (slot, frames u8 [max_frames][h][w][4] -- u16 [max_frames][h][w] records when packed --, index i32 [max_batch][4]):
+        numpy views of the slot's pinned buffers, or None when every slot is in flight.  Result views of earlier collect() calls
+        become invalid."""
         for held in self._held:
             L.check(self._lib.covahip_pipe_release(self._h, held), "covahip_pipe_release")
         self._held = []
@@ -285,7 +297,10 @@ class FilterPipe:
         L.check(rc, "covahip_pipe_acquire")
         if slot.value not in self._views:
             n = self.max_frames * self.net.h * self.net.w * 4
-            frames = np.ctypeslib.as_array(C.cast(fp.value, C.POINTER(C.c_uint8)), shape=(n,)).reshape(self.max_frames, self.net.h, self.net.w, 4)
+            if self.packed:
+                frames = np.ctypeslib.as_array(C.cast(fp.value, C.POINTER(C.c_uint16)), shape=(n // 4,)).reshape(self.max_frames, self.net.h, self.net.w)
+            else:
+                frames = np.ctypeslib.as_array(C.cast(fp.value, C.POINTER(C.c_uint8)), shape=(n,)).reshape(self.max_frames, self.net.h, self.net.w, 4)
             index = np.ctypeslib.as_array(C.cast(ip.value, C.POINTER(C.c_int32)), shape=(self.max_batch * 4,)).reshape(self.max_batch, 4)
             self._views[slot.value] = (frames, index)
         return (slot.value,) + self._views[slot.value]

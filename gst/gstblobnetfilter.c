@@ -137,6 +137,7 @@ static gboolean bf_ensure_model(GstBlobNetFilter *s) {   /* lock held */
     if (rc == COVAHIP_OK) rc = covahip_blobnet_load(s->ctx, blob, len, s->h_mb, s->w_mb, BF_TIMESTEP, (int)s->batch_size);
     g_free(blob);
     if (rc == COVAHIP_OK) rc = covahip_pipe_create(s->ctx, (int)s->batch_size, BF_TIMESTEP * (int)s->batch_size, (int)s->max_boxes, BF_SLOTS, 0, &s->pipe);
+    if (rc == COVAHIP_OK) rc = covahip_pipe_set_packed(s->pipe, 1);
     if (rc == COVAHIP_OK) rc = covahip_pipe_acquire(s->pipe, &s->slot, &s->pf, &s->pi);
     if (rc != COVAHIP_OK) {
         GST_ELEMENT_ERROR(s, LIBRARY, INIT, ("covahip: %s (%s)", covahip_strerror(rc), covahip_last_hip_error(s->ctx)), (NULL));
@@ -417,6 +418,16 @@ static gboolean bf_try_reserve(GstBlobNetFilter *s, BfPad *p, GstBuffer *buf, ui
 /* One carrier frame of one stream.  The streaming threads of the N decoder branches take their slot positions without a
  * lock and copy their 32 KB into the pinned slot in parallel; the element's mutex is for the rest: loading the model,
  * submitting a batch, waiting for a free slot. */
+static void bf_pack_into(GstBuffer *buf, uint16_t *dst, gsize frame_bytes) {
+    GstMapInfo mi;
+    if (gst_buffer_map(buf, &mi, GST_MAP_READ)) {
+        covahip_carrier_pack(mi.data, frame_bytes / 4, dst);
+        gst_buffer_unmap(buf, &mi);
+    } else {
+        memset(dst, 0, frame_bytes / 2);
+    }
+}
+
 static GstFlowReturn bf_chain(GstPad *pad, GstObject *parent, GstBuffer *buf) {
     GstBlobNetFilter *s = (GstBlobNetFilter *)parent;
     BfPad *p = bf_pad_of(s, pad);
@@ -465,10 +476,12 @@ static GstFlowReturn bf_chain(GstPad *pad, GstObject *parent, GstBuffer *buf) {
         }
     }
 
-    gst_buffer_extract(buf, 0, pf + (gsize)pos * s->frame_bytes, s->frame_bytes);   /* metapreprocess copies the same bytes (imp.rs:311-312) */
+    /* metapreprocess copies these bytes (imp.rs:311-312); here they go into the slot as two-byte records (covahip_carrier_pack:
+     * what BlobNet keeps of them), so that the host-to-device copy -- the bound of this element -- moves half the bytes */
+    bf_pack_into(buf, (uint16_t *)(pf + (gsize)pos * (s->frame_bytes / 2)), s->frame_bytes);
     for (int k = 0; k < BF_TIMESTEP - 1; k++)
         if (need[k]) {
-            gst_buffer_extract(need[k], 0, pf + (gsize)need_pos[k] * s->frame_bytes, s->frame_bytes);
+            bf_pack_into(need[k], (uint16_t *)(pf + (gsize)need_pos[k] * (s->frame_bytes / 2)), s->frame_bytes);
             gst_buffer_unref(need[k]);
         }
     __atomic_fetch_add(&s->done, (guint64)taken, __ATOMIC_RELEASE);

@@ -194,6 +194,8 @@ typedef struct covahip_pipe covahip_pipe;
 int covahip_pipe_create(covahip_ctx *ctx, int max_batch, int max_frames, int max_boxes, int n_slots, int want_mask,
                         covahip_pipe **out);
 void covahip_pipe_destroy(covahip_pipe *pipe);
+/* Before the first acquire: the slots' frame area holds packed records (covahip_carrier_pack), hw * 2 bytes per carrier frame. */
+int covahip_pipe_set_packed(covahip_pipe *p, int on);
 int covahip_pipe_acquire(covahip_pipe *pipe, int *slot, uint8_t **frames, int32_t **stack_index);
 int covahip_pipe_submit(covahip_pipe *pipe, int slot, int n_frames, int batch, int area_thresh);
 /* Gives an ACQUIRED slot back without submitting it (after a failed covahip_pipe_submit, or when the caller shuts down with
@@ -330,6 +332,16 @@ int covahip_h264_decode_au(covahip_h264 *h, const uint8_t *au, size_t len, uint8
  * `frame` (metapreprocess/imp.rs:233,311-312; tfrecordsink/imp.rs:105-112). */
 int covahip_carrier_write_records(const uint8_t *mb_type, const uint8_t *mv_x, const uint8_t *mv_y, int width_mbs, int height_mbs,
                                   uint8_t *frame, size_t frame_bytes);
+
+/* Packed carrier records: two bytes per macroblock, min(mb_type, 6) | min(mv_x, 6) << 3 | min(mv_y, 6) << 6 -- everything BlobNet
+ * keeps of a record (its first operation is clip(x, 0, 6) on all three channels, utils/model/preprocessing.py:6-7), at half the
+ * bytes: the host-to-device copy is what bounds the element path (9.1 MB per 256-frame batch over PCIe).  The pinned host
+ * pipeline takes its frames in this form when asked to (covahip_pipe_set_packed); results are bit-identical. */
+void covahip_carrier_pack(const uint8_t *frame, size_t n_mb, uint16_t *records);
+/* covahip_filter_forward_frames on packed records [n_frames][H][W] (device pointers only). */
+int covahip_filter_forward_frames_packed(covahip_ctx *ctx, const uint16_t *d_records, int n_frames, const int32_t *stack_index,
+                                         int batch, int area_thresh, covahip_box *d_boxes, int32_t *d_counts, int max_boxes,
+                                         float *d_logits, uint8_t *d_mask);
 
 /* ------------------------------------------------- metapreprocess stacking
  * Host state of the `metapreprocess` element (cova-rs/gst-plugins/src/metapreprocess/

@@ -113,3 +113,32 @@ def test_abort_returns_an_acquired_slot_and_bad_submits_leave_the_pipe_usable(ct
     np.testing.assert_array_equal(counts, rcounts)
     pipe.abort(c[0])
     pipe.close()
+
+
+def test_packed_records_give_identical_results(ctx, weights_flat):
+    """covahip_pipe_set_packed: two-byte records (min(type, 6) | min(mv_x, 6) << 3 | min(mv_y, 6) << 6, covahip_carrier_pack) instead
+    of the decoder's four bytes per macroblock -- half the PCIe bytes, the same boxes bit for bit (the network clips at 6 anyway,
+    utils/model/preprocessing.py:6-7).  The pack itself against its definition, values above 6 and the unused byte included."""
+    from cova_amd.elements import pack_frames
+    h, w, b, streams = 68, 120, 48, 3
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=b)
+    frames, index = synth.carrier_batch(b, h, w, seed=23, streams=streams)
+    frames = frames.copy()
+    frames[::3, ::5, ::7, 1] = 200          # a motion-vector magnitude far above the clip
+    frames[..., 3] = 0xA5                   # the byte the network ignores
+    rec = pack_frames(frames)
+    m = np.minimum(frames[..., :3].astype(np.uint16), 6)
+    np.testing.assert_array_equal(rec, m[..., 0] | (m[..., 1] << 3) | (m[..., 2] << 6))
+    res = []
+    for packed in (False, True):
+        pipe = FilterPipe(net, max_batch=b, max_frames=frames.shape[0], max_boxes=512, n_slots=2, want_mask=True, packed=packed)
+        slot, pf, pi = pipe.acquire()
+        pf[:frames.shape[0]] = rec if packed else frames
+        pi[:b] = index
+        pipe.submit(slot, frames.shape[0], b, 1)
+        counts, offsets, boxes, mask = pipe.collect(slot)
+        res.append((counts.copy(), offsets.copy(), boxes.copy(), mask.copy()))
+        pipe.close()
+    for a, c in zip(res[0], res[1]):
+        np.testing.assert_array_equal(a, c)
+    assert res[0][0].sum() > 0

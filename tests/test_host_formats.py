@@ -168,3 +168,15 @@ def test_python_wrappers_agree_with_raw_calls():
     assert E.bbox_csv(b, with_header=False) == "1.0,2.0,3.0,4.0,12.0,,,,\n"
     assert E.tracks_export(0, 0, b, np.array([1], np.uint32)) == \
         struct.pack(">I", len(E.serialize_frame(0, 0, b))) + E.serialize_frame(0, 0, b)
+
+
+def test_carrier_pack_records():
+    """covahip_carrier_pack: min(type, 6) | min(mv_x, 6) << 3 | min(mv_y, 6) << 6 per macroblock, the fourth byte ignored --
+    vector body and scalar tail (a length that is not a multiple of 16)."""
+    from cova_amd.elements import pack_frames
+    rng = np.random.default_rng(1)
+    for shape in ((3, 68, 120, 4), (1, 5, 7, 4), (2, 45, 80, 4)):
+        f = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        f[0] = rng.integers(0, 9, size=shape[1:])
+        m = np.minimum(f[..., :3].astype(np.uint16), 6)
+        np.testing.assert_array_equal(pack_frames(f), m[..., 0] | (m[..., 1] << 3) | (m[..., 2] << 6))
