@@ -487,7 +487,7 @@ int parse_slice_header(const covahip_h264 *h, const uint8_t *nal, size_t n, cova
 
 // Picture order count of the next access unit in decode order (8.2.1.1 type 0, 8.2.1.3 type 2; frames only) as a key whose
 // ascending order is the output order: (IDR period << 32) + POC + 2^31.  false for POC type 1.
-bool poc_step(const Sps &sp, covahip_h264::PocState &st, const covahip_h264_slice &sl, int64_t &key) {
+bool poc_step(const Sps &sp, covahip_h264::PocState &st, const covahip_h264_slice &sl, int64_t &key, int64_t *out_key = nullptr) {
     if (sp.poc_type == 1) return false;
     const int64_t max_lsb = 1ll << sp.log2_max_poc_lsb, max_fn = 1ll << sp.log2_max_frame_num;
     const bool idr = sl.idr != 0, ref = sl.nal_ref_idc != 0;
@@ -501,15 +501,25 @@ bool poc_step(const Sps &sp, covahip_h264::PocState &st, const covahip_h264_slic
         else if (lsb > st.prev_lsb && lsb - st.prev_lsb > max_lsb / 2) msb = st.prev_msb - max_lsb;
         poc = msb + lsb;
         if (ref) {
-            if (sl.has_mmco5) { st.prev_msb = 0; st.prev_lsb = poc; }   // after memory_management_control_operation 5 (frames: tempPicOrderCnt)
-            else { st.prev_msb = msb; st.prev_lsb = lsb; }
+            st.prev_msb = msb; st.prev_lsb = lsb;
         }
     } else {
         if (!idr && sl.frame_num < st.prev_fn) st.fn_off += max_fn;
         poc = idr ? 0 : 2 * (st.fn_off + sl.frame_num) - (ref ? 0 : 1);
     }
     st.prev_fn = sl.frame_num;
+    // A reference picture that carries memory_management_control_operation 5 starts an output period the way an IDR picture
+    // does: everything decoded before it leaves first (C.4.4), its own count becomes 0 once tempPicOrderCnt is subtracted
+    // (8.2.1, frames) and the pictures behind it count from there (prevPicOrderCntMsb/Lsb 0, prevFrameNumOffset 0, frame_num 0)
+    // `key` is the count the picture predicts with (its lists, temporal direct); `out_key` the one it leaves the decoder by
     key = (st.period << 32) + poc + (1ll << 31);
+    if (ref && sl.has_mmco5) {
+        st.period++;
+        st.prev_msb = st.prev_lsb = 0;
+        st.fn_off = 0;
+        st.prev_fn = 0;
+        if (out_key) *out_key = (st.period << 32) + (1ll << 31);
+    } else if (out_key) *out_key = key;
     return true;
 }
 
@@ -526,6 +536,7 @@ void compute_display_order(covahip_h264 *h) {
     h->lists0.assign(n, {});
     h->lists1.assign(n, {});
     covahip_h264::PocState st;
+    std::vector<int64_t> out_key(n, 0);
     Dpb dpb;
     for (size_t i = 0; i < n; i++) {
         covahip_h264_slice sl[1];
@@ -533,7 +544,7 @@ void compute_display_order(covahip_h264 *h) {
         int cnt = 0;
         const Sample &sm = h->samples[i];
         const int rc = au_slices(h, h->data + sm.off, sm.size, sm.off, sl, 1, &cnt, &ext);
-        if ((rc != COVAHIP_OK && rc != COVAHIP_ERR_OVERFLOW) || cnt < 1 || !poc_step(h->sps, st, sl[0], h->order_key[i])) {
+        if ((rc != COVAHIP_OK && rc != COVAHIP_ERR_OVERFLOW) || cnt < 1 || !poc_step(h->sps, st, sl[0], h->order_key[i], &out_key[i])) {
             h->order_key.clear();
             h->col_sample.assign(n, -1);
             h->lists0.assign(n, {});
@@ -557,7 +568,7 @@ void compute_display_order(covahip_h264 *h) {
     }
     h->display.resize(n);
     for (size_t i = 0; i < n; i++) h->display[i] = (int32_t)i;
-    std::stable_sort(h->display.begin(), h->display.end(), [&](int32_t a, int32_t b) { return h->order_key[a] < h->order_key[b]; });
+    std::stable_sort(h->display.begin(), h->display.end(), [&](int32_t a, int32_t b) { return out_key[a] < out_key[b]; });
 }
 
 // Slice NAL units of one access unit (length-prefixed NAL units at au[0, len)); nal_offset = base + offset inside au.
@@ -858,11 +869,11 @@ int covahip_h264_decode_au(covahip_h264 *h, const uint8_t *au, size_t len, uint8
     const int rc = au_slices(h, au, len, 0, sl, 2, &n, &ext);
     if (rc == COVAHIP_ERR_OVERFLOW || (rc == COVAHIP_OK && n != 1)) return COVAHIP_ERR_UNSUPPORTED;
     if (rc) return rc;
-    int64_t key = 0;
-    const bool have_key = poc_step(h->sps, h->poc, sl[0], key);
+    int64_t key = 0, okey = 0;
+    const bool have_key = poc_step(h->sps, h->poc, sl[0], key, &okey);
     if (order_key) {
         if (!have_key) return COVAHIP_ERR_UNSUPPORTED;
-        *order_key = key;
+        *order_key = okey;
     }
     if (hdr) *hdr = sl[0];
     // access units arrive in decoding order: the reference pictures so far give RefPicList1[0] of a B picture, whose "does

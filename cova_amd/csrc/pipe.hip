@@ -240,6 +240,10 @@ int covahip_pipe_wait(covahip_pipe *p, int slot) {
 
 int covahip_pipe_abort(covahip_pipe *p, int slot) {
     if (!p || slot < 0 || slot >= p->n_slots || p->slots[slot].state != 1) return COVAHIP_ERR_INVALID_ARG;
+    // a submit that failed half way may have enqueued the slot's upload (and kernels that read its device buffers): nothing may
+    // reuse the pinned frames before that work has drained
+    if (hipStreamSynchronize(p->s_h2d) != hipSuccess) (void)hipGetLastError();
+    covahip_sync_all(p->ctx);
     p->slots[slot].state = 0;
     return COVAHIP_OK;
 }

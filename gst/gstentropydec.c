@@ -69,8 +69,19 @@ static GstFlowReturn ed_chain(GstPad *pad, GstObject *parent, GstBuffer *buf) {
         return GST_FLOW_NOT_NEGOTIATED;
     }
     GstBuffer *ob = gst_buffer_new_allocate(NULL, s->frame_bytes, NULL);
-    gst_buffer_map(buf, &in, GST_MAP_READ);
-    gst_buffer_map(ob, &out, GST_MAP_WRITE);
+    if (!ob || !gst_buffer_map(buf, &in, GST_MAP_READ)) {
+        if (ob) gst_buffer_unref(ob);
+        gst_buffer_unref(buf);
+        GST_ELEMENT_ERROR(s, RESOURCE, FAILED, ("cannot allocate / map a %" G_GSIZE_FORMAT "-byte frame", s->frame_bytes), (NULL));
+        return GST_FLOW_ERROR;
+    }
+    if (!gst_buffer_map(ob, &out, GST_MAP_WRITE)) {
+        gst_buffer_unmap(buf, &in);
+        gst_buffer_unref(ob);
+        gst_buffer_unref(buf);
+        GST_ELEMENT_ERROR(s, RESOURCE, FAILED, ("cannot map the output frame"), (NULL));
+        return GST_FLOW_ERROR;
+    }
     rc = covahip_h264_decode_au(s->h, in.data, in.size, out.data, out.size, &hdr, &key);
     if (rc == COVAHIP_OK) memset(out.data + s->rec_bytes, 0, out.size - s->rec_bytes);
     gst_buffer_unmap(ob, &out);
@@ -82,6 +93,7 @@ static GstFlowReturn ed_chain(GstPad *pad, GstObject *parent, GstBuffer *buf) {
         return GST_FLOW_ERROR;
     }
     gst_buffer_copy_into(ob, buf, GST_BUFFER_COPY_TIMESTAMPS, 0, -1);
+    GST_BUFFER_DTS(ob) = GST_CLOCK_TIME_NONE;   /* raw frames leave in output order: the access unit's decode time means nothing on them */
     if (hdr.slice_type != 2) GST_BUFFER_FLAG_SET(ob, GST_BUFFER_FLAG_DELTA_UNIT);
     gst_buffer_unref(buf);
     if (hdr.idr) ret = ed_pop(s, TRUE);   /* an IDR picture follows everything before it in output order */
@@ -114,7 +126,11 @@ static gboolean ed_sink_event(GstPad *pad, GstObject *parent, GstEvent *ev) {
         }
         s->fps_n = 30; s->fps_d = 1;
         gst_structure_get_fraction(st, "framerate", &s->fps_n, &s->fps_d);
-        if (s->h) { covahip_h264_close(s->h); s->h = NULL; }
+        if (s->h) {   /* new parameter sets: what the old stream still holds leaves first, in its own output order */
+            ed_pop(s, TRUE);
+            covahip_h264_close(s->h);
+            s->h = NULL;
+        }
         gst_buffer_map(cdb, &m, GST_MAP_READ);
         rc = covahip_h264_open_avcc(m.data, m.size, &s->h);
         gst_buffer_unmap(cdb, &m);
