@@ -298,8 +298,12 @@ __device__ unsigned long long g_phase[80];
         ph_[i] += now_ - last_;                                           \
         last_ = now_;                                                     \
     } while (0)
+#else
+#define PHASE_MARK(i) do { } while (0)
+#endif
+#if defined(PHASE_TIMING) || defined(WGSPAN_ONLY)
 // per-workgroup life span of the last launch of a kernel: {start, end} in s_memrealtime ticks (10 ns) and the hardware id
-// (which workgroups shared a CU)
+// (which workgroups shared a CU).  -DWGSPAN_ONLY: the spans without the phase marks (which add waits to the item loop)
 __device__ unsigned long long g_wgspan[6][1024][4];
 #define WGSPAN_BEGIN() const unsigned long long wg_t0_ = __builtin_amdgcn_s_memrealtime(), wg_c0_ = __builtin_amdgcn_s_memtime()
 #define WGSPAN_END(kid)                                                                          \
@@ -312,9 +316,16 @@ __device__ unsigned long long g_wgspan[6][1024][4];
         }                                                                                        \
     } while (0)
 #else
-#define PHASE_MARK(i) do { } while (0)
 #define WGSPAN_BEGIN() do { } while (0)
 #define WGSPAN_END(kid) do { } while (0)
+#endif
+#ifdef WGSPAN_ONLY
+// time line of the first four items of every workgroup of enc_mfma (wave 0): item start, band requested, band landed (after the
+// barrier), tiles done -- s_memrealtime ticks
+__device__ unsigned long long g_itemspan[3][1024][4][4];
+#define ITEM_MARK(j) do { if (it_n_ < 4) it_t_[it_n_][j] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ITEM_MARK(j) do { } while (0)
 #endif
 // ------------------------------------------------------------------ enc level 0
 // u8 RGBA carrier frame -> conv3x3 (3->16) on v_mfma_f32_16x16x32_f16.
@@ -485,7 +496,14 @@ __global__ __launch_bounds__(WG0, 4) void enc0p_mfma(Enc0pArgs p) {
 // ------------------------------------------------------------------ enc levels 1..3
 // conv3x3 CIN -> COUT on v_mfma_f32_32x32x16_f16.  Wave roles: N-tile = wave % NT,
 // M-group = wave / NT.  One K-step = one tap x 16 input channels.
-template <int CIN, int COUT, int TPAR, int OCC, int NWV, bool WIDE, bool ALLPOS, bool PRE = false>
+// TSZ > 0 (round 4, levels 2 and 3 where the geometry suits it): ROW-ALIGNED tiles -- a tile is eight consecutive windows of ONE
+// window row (tile column tc = windows 8 tc .. 8 tc + 7; lanes of windows past the row's end compute on whatever the band holds
+// there and store nothing) -- on a band whose T slices lie TSZ bytes apart (compile time), with a swizzle that is periodic over
+// 16 pixels and 2 rows (the host picks one: choose_swz(periodic)).  A fragment's LDS address is then
+//     [tile base: wave-uniform] + [lane constant of the tap, set once per kernel] ^ [channel chunk << 5] + [T slice: immediate],
+// i.e. one add per tap and one xor per further channel chunk per tile, where the general form below evaluates the swizzle and
+// the pixel address for every tap of every tile (216 of the 270 vector instructions of a level-2 tile's matrix part).
+template <int CIN, int COUT, int TPAR, int OCC, int NWV, bool WIDE, bool ALLPOS, bool PRE = false, int TSZ = 0>
 __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     constexpr int WGS = NWV * 64;
     constexpr int NT = COUT / 32, MG = NWV / NT, KC = CIN / 16, KSTEPS = 9 * KC;
@@ -495,7 +513,8 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntile = wave % NT, mgroup = wave / NT;
     const int TR = p.TR, TC = p.TC;
-    const int tsz = TR * TC * PS;
+    const int tsz = TSZ > 0 ? TSZ : TR * TC * PS;
+    static_assert(TSZ == 0 || (TSZ % 16 == 0 && (TPAR - 1) * TSZ < 65536 && !PRE), "T-slice offsets must fit a DS instruction's offset field");
 
     WGSPAN_BEGIN();
 #ifdef PHASE_TIMING
@@ -508,6 +527,19 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     const int co = ntile * 32 + (lane & 31);
     const float e0 = p.epi[co], e1 = p.epi[COUT + co], e2 = p.epi[2 * COUT + co];   // see pool4
     const TmixW tm = load_tmix(p.epi + 3 * COUT, lane);
+    // TSZ > 0: the lane's part of a fragment address per tap: pixel (lane's window of the tile, position, tap) of tile (0, 0),
+    // xor the 16-byte chunk (kh ^ swizzle) -- the K half kh and the swizzle meet in the chunk bits, which the pixel address
+    // leaves clear
+    [[maybe_unused]] uint32_t kq[9];
+    if constexpr (TSZ > 0) {
+        const int m0 = lane & 31, kh0 = lane >> 5;
+        const int yl = (m0 >> 1) & 1, xl = 2 * (m0 >> 2) + (m0 & 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int yy = yl + tap / 3, xx = xl + tap % 3;
+            kq[tap] = (uint32_t)((yy * TC + xx) * PS) ^ (uint32_t)((kh0 ^ swz_eval<CPP>(p.swz, xx, yy)) << 4);
+        }
+    }
 #ifdef PHASE_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PHASE_MARK(8);   // weight fragments and epilogue constants in registers
@@ -587,6 +619,10 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     // found room) the next item's band is in flight while this one is computed: ONE barrier per item, right after
     // the item's own band has landed -- every wave has then left the previous item, whose buffer the next band may
     // overwrite.  With one buffer: barrier, stage, wait, barrier.
+#ifdef WGSPAN_ONLY
+    unsigned long long it_t_[4][4] = {};
+    int it_n_ = 0;
+#endif
     ItemIter it;
     bool more = it.start(p.plan, p.B, p.nbands);
     const bool dbl = p.nbuf == 2;
@@ -607,6 +643,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
         asm volatile("" : "+v"(ll));
         uint8_t *const bandp = smem + cur * p.buf_stride;   // this item's band in LDS
         PHASE_MARK(0);   // item bookkeeping
+        ITEM_MARK(0);
         // the weights of the level below's temporal MLP: fetched here so that the loads are in flight together with the
         // band's (they are waited for with it), not on their own between two barriers
         TmixW tmp;
@@ -616,12 +653,14 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
             PHASE_MARK(1);   // waiting for the workgroup's other waves to finish the previous item
             stage(b, band, bandp, ll);
             PHASE_MARK(2);   // issuing the band's LDS-DMA
+            ITEM_MARK(1);
             wait_vmem();
             if constexpr (PRE) mlp_own(bandp, band, tmp);
             PHASE_MARK(4);   // own pieces landed, temporal MLP applied
         }
         lds_barrier();
         PHASE_MARK(3);   // the band landing / the other waves leaving the previous item
+        ITEM_MARK(2);
         more = it.next(p.plan, p.B, p.nbands);
         // Two buffers: the next band is requested now and waited for (vmcnt(0), in `landed()`) right before this item's
         // first global store -- NOT at the top of the next item: the counter is in order, and a wait placed behind the
@@ -657,12 +696,23 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
         PHASE_MARK(5);   // skip slice out
         // ---- compute
         const int nwin = (rows / 2) * p.Wp;
-        const int ntiles = (nwin + 7) / 8;
+        const int ntc = (p.Wp + 7) >> 3;                    // TSZ > 0: tile columns of a window row
+        const int ntiles = TSZ > 0 ? (rows / 2) * ntc : (nwin + 7) / 8;
         const int m = ll & 31, kh = ll >> 5;
-        for (int tile = mgroup; tile < ntiles; tile += MG) {
-            const int win = min(tile * 8 + (m >> 2), nwin - 1);
-            const int wy = fdiv(win, p.mWp), wx = win - wy * p.Wp;
-            const int yy0 = 2 * wy + ((m >> 1) & 1), xx0 = 2 * wx + (m & 1);
+        int t_wy = 0, t_tc = mgroup;                        // TSZ > 0: the tile's window row and tile column (wave-uniform)
+        for (int tile = mgroup; tile < ntiles; tile += MG, t_tc += MG) {
+            [[maybe_unused]] int yy0 = 0, xx0 = 0;
+            [[maybe_unused]] uint32_t fa[9];                // TSZ > 0: fragment addresses of the nine taps, channel chunk 0, T slice 0
+            if constexpr (TSZ > 0) {
+                while (t_tc >= ntc) { t_tc -= ntc; t_wy++; }
+                const uint32_t tbase = (uint32_t)(cur * p.buf_stride + ((2 * t_wy) * TC + 16 * t_tc) * PS);
+#pragma unroll
+                for (int tap = 0; tap < 9; tap++) fa[tap] = kq[tap] + tbase;
+            } else {
+                const int win = min(tile * 8 + (m >> 2), nwin - 1);
+                const int wy = fdiv(win, p.mWp), wx = win - wy * p.Wp;
+                yy0 = 2 * wy + ((m >> 1) & 1); xx0 = 2 * wx + (m & 1);
+            }
             // TPAR T-slices are accumulated at a time (register budget); the pooled values of all
             // four slices are kept for the temporal MLP.
             half4 pb4[4];   // the pooled values of window g, T = 0..3, already as the temporal MLP's fp16 operand
@@ -675,6 +725,10 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
             auto frag = [&](int s) -> half8 {
                 const int grp = s / NSG, r = s % NSG;
                 const int tap = r / (KC * TPAR), kc = (r / TPAR) % KC, t = r % TPAR;
+                if constexpr (TSZ > 0) {
+                    const uint8_t *a = smem + (fa[tap] ^ (uint32_t)(kc << 5));
+                    return *reinterpret_cast<const half8 *>(__builtin_assume_aligned(a + (grp * TPAR + t) * TSZ, 16));
+                }
                 const int yy = yy0 + tap / 3, xx = xx0 + tap % 3;
                 const int pbase = (yy * TC + xx) * PS;
                 const int sw = swz_eval<CPP>(p.swz, xx, yy);
@@ -729,10 +783,12 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
                             const int sw = swz_eval<CPP>(p.swz, xx, yy);
 #pragma unroll
                             for (int kc = 0; kc < KC; kc++) {
-                                const int off = pbase + (((kc * 2 + kh) ^ sw) * 16);
+                                const int off = TSZ > 0 ? 0 : pbase + (((kc * 2 + kh) ^ sw) * 16);
 #pragma unroll
                                 for (int t = 0; t < TPAR; t++) {
-                                    const half8 a = *reinterpret_cast<const half8 *>(bandp + (grp * TPAR + t) * tsz + off);
+                                    const uint8_t *ap = TSZ > 0 ? smem + ((fa[ky * 3 + kx] + (uint32_t)(grp * TPAR * TSZ)) ^ (uint32_t)(kc << 5)) + t * TSZ
+                                                                : bandp + (grp * TPAR + t) * tsz + off;
+                                    const half8 a = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(ap, 16));
                                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[(ky * 3 + kx) * KC + kc], acc[t], 0, 0, 0);
                                 }
                             }
@@ -783,9 +839,9 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int owin = tile * 8 + ((ll >> 2) & 7);
-                if (owin < nwin) {
-                    const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
+                const int owin = TSZ > 0 ? 8 * t_tc + ((ll >> 2) & 7) : tile * 8 + ((ll >> 2) & 7);   // TSZ > 0: window within its row
+                if (owin < (TSZ > 0 ? p.Wp : nwin)) {
+                    const int owy = TSZ > 0 ? t_wy : (int)fdiv(owin, p.mWp), owx = TSZ > 0 ? owin : owin - owy * p.Wp;
                     const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
                     const uint32_t eo = (uint32_t)((gy * p.Wo + gx) * COUT + ntile * 32 + 8 * (ll & 3));
 #pragma unroll
@@ -808,9 +864,9 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const half4 o = o4[g];
-                    const int owin = tile * 8 + 2 * g + kh;
-                    if (owin < nwin) {
-                        const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
+                    const int owin = (TSZ > 0 ? 8 * t_tc : tile * 8) + 2 * g + kh;
+                    if (owin < (TSZ > 0 ? p.Wp : nwin)) {
+                        const int owy = TSZ > 0 ? t_wy : (int)fdiv(owin, p.mWp), owx = TSZ > 0 ? owin : owin - owy * p.Wp;
                         const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
                         const uint32_t eo = (uint32_t)((gy * p.Wo + gx) * COUT + co);
 #pragma unroll
@@ -823,7 +879,16 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
         }
         landed();   // a wave without a tile in this item
         PHASE_MARK(6);
+#ifdef WGSPAN_ONLY
+        ITEM_MARK(3);
+        it_n_++;
+#endif
     }
+#ifdef WGSPAN_ONLY
+    if (tid == 0 && blockIdx.x < 1024)
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) g_itemspan[COUT == 32 ? 0 : COUT == 64 ? 1 : 2][blockIdx.x][i][j] = it_t_[i][j];
+#endif
 #ifdef PHASE_TIMING
 #ifndef PHASE_WAVE
 #define PHASE_WAVE 0
@@ -855,6 +920,9 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
 // waves of 16 channels each (64 registers, eight waves per SIMD -- the candidate round 3 named) 34.6: it reads every
 // fragment for ONE product and needs the LDS array's full 256 B/clk to keep the matrix pipe busy.
 // Reference semantics: encoder.py:58-80 (conv -> ReLU -> BN -> pool -> pad -> PointWiseTN), pointwise.py:16-26.
+// T-slice strides of the row-aligned forms of levels 2 and 3 (enc_mfma<.., TSZ>): the 1080p bands exactly (8 rows x 32 pixels x
+// 64 B; 12 rows x 17 pixels x 128 B); smaller bands leave the tail of a slice unused
+constexpr int E2_TSZ = 16384, E3_TSZ = 26112;
 constexpr int E1_RS = 2176;              // bytes per band row: 66 pixels x 32 B + 64 B, == 128 mod 256
 constexpr int E1_TR = 8;                 // band rows per T slice (three pool-window rows + halo)
 constexpr int E1_TSZ = E1_RS * E1_TR;    // bytes per T slice
@@ -1876,6 +1944,27 @@ long long model_enc(int cin, int W, int Wp, int rb, const Swz &w) {
                 }
     return tot;
 }
+// encoder level on ROW-ALIGNED tiles (enc_mfma<.., TSZ>): eight windows of one window row; lanes of windows past the row's end
+// read on (what they fetch is discarded, but their bank conflicts count).  Two window rows cover every (tile column, row parity)
+// a periodic swizzle can tell apart.
+long long model_enc_rows(int cin, int W, int Wp, const Swz &w) {
+    const int TC = W + 2, PS = cin * 2, KC = cin / 16, CPP = cin / 8;
+    long long tot = 0;
+    for (int tc = 0; tc < (Wp + 7) / 8; tc++)
+        for (int wy = 0; wy < 2; wy++)
+            for (int ky = 0; ky < 3; ky++)
+                for (int kx = 0; kx < 3; kx++)
+                    for (int kc = 0; kc < KC; kc++) {
+                        int addr[64];
+                        for (int lane = 0; lane < 64; lane++) {
+                            const int m = lane & 31, kh = lane >> 5;
+                            const int yy = 2 * wy + ((m >> 1) & 1) + ky, xx = 2 * (8 * tc + (m >> 2)) + (m & 1) + kx;
+                            addr[lane] = (yy * TC + xx) * PS + (((kc * 2 + kh) ^ swz_host(w, CPP, xx, yy)) * 16);
+                        }
+                        tot += lds_cycles(addr);
+                    }
+    return tot;
+}
 // decoder block: tiles of 32 consecutive grid positions (dec_mfma), band of nu grid rows
 long long model_dec(int C, int Wi, int nu, const Swz &w) {
     const int TC = Wi + 2, PS = C * 2, KC = C / 16, CPP = C / 8, GW = Wi + 1, npos = nu * GW;
@@ -1919,6 +2008,30 @@ Swz choose_swz(bool enc, int C, int W, int Wp, int rows) {
                         if (ideal && cost == ideal) done = true;   // conflict free
                     }
     cache.push_back(Key{enc, C, W, Wp, rows, best});
+    return best;
+}
+
+// The member of the family that is periodic over 16 pixels and 2 rows (L = 0, b = 0, (16 >> p) * a = 0 mod chunks per pixel)
+// with the fewest conflicts on row-aligned tiles: what enc_mfma<.., TSZ> needs for its per-kernel lane constants.
+Swz choose_swz_periodic(int C, int W, int Wp) {
+    struct Key { int C, W, Wp; Swz s; };
+    static std::vector<Key> cache;
+    std::lock_guard<std::mutex> lock(g_swz_mutex);
+    for (auto &k : cache)
+        if (k.C == C && k.W == W && k.Wp == Wp) return k.s;
+    const int cpp = C / 8;
+    Swz best{0, 0, 0, 0, 0};
+    long long best_cost = -1;
+    for (int p = 0; p < 4; p++)
+        for (int a = 0; a < cpp; a++) {
+            if (((16 >> p) * a) % cpp) continue;
+            for (int c = 0; c < cpp; c++) {
+                const Swz w{p, a, 0, c, 0};
+                const long long cost = model_enc_rows(C, W, Wp, w);
+                if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = w; }
+            }
+        }
+    cache.push_back(Key{C, W, Wp, best});
     return best;
 }
 
@@ -2185,7 +2298,17 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
             }
             if (!nbands) return COVAHIP_ERR_UNSUPPORTED;
         }
-        const size_t tile_bytes = (((size_t)BN_T * (RB + 2) * TC * px_bytes) + 15) & ~(size_t)15;
+        // levels 2 and 3 on row-aligned tiles (enc_mfma<.., TSZ>) when a T slice of the band fits the kernel's compile-time
+        // slice stride and a row's windows fill its tile columns about as well as the general form's tiles fill a band
+        const int fix_tsz = i == 2 ? E2_TSZ : i == 3 ? E3_TSZ : 0;
+        bool rowtiles = false;
+        if (fix_tsz && m->enc_rowtiles && !ctx->enc_plan[i].nbands && cin == (i == 2 ? 32 : 64) && m->enc_c[i + 1] == 2 * cin &&
+            (size_t)(RB + 2) * TC * px_bytes <= (size_t)fix_tsz) {
+            long long t_rows = (long long)Hp * ((Wp + 7) / 8), t_gen = 0;
+            for (int k = 0; k < nbands; k++) t_gen += ((((k + 1) * Hp) / nbands - (k * Hp) / nbands) * Wp + 7) / 8;
+            rowtiles = t_rows <= t_gen;
+        }
+        const size_t tile_bytes = rowtiles ? (size_t)BN_T * fix_tsz : (((size_t)BN_T * (RB + 2) * TC * px_bytes) + 15) & ~(size_t)15;
         const size_t lds = nbuf * tile_bytes + scr_bytes;
         if (lds > 160 * 1024 - 256) return COVAHIP_ERR_UNSUPPORTED;
         const int items = batch * nbands;
@@ -2199,7 +2322,7 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
         a.mWp = magic(Wp); a.mNb = magic(nbands); a.mRC = magic(TC * (cin / 8)); a.zero = prep + pr->zero;
         a.nbuf = nbuf; a.buf_stride = (int)tile_bytes; a.scr_off = (int)(nbuf * tile_bytes);
         a.plan = make_plan(grid, num_cu, wgs_per_cu, batch, nbands, Hp);
-        a.swz = choose_swz(true, cin, W, Wp, RB / 2);
+        a.swz = rowtiles ? choose_swz_periodic(cin, W, Wp) : choose_swz(true, cin, W, Wp, RB / 2);
         a.pidx = d_index; a.skip = act[1]; a.tm_pre = (const float *)(prep + pr->enc[0].epi) + 48;
         int rc = COVAHIP_OK;
         if (i == 1) {
@@ -2209,12 +2332,26 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
             ProfScope ps(ctx, "enc1_mfma");
             if (pr->allpos[i]) LAUNCH((enc_mfma<16, 32, 2, 4, 8, true, true, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
             else LAUNCH((enc_mfma<16, 32, 2, 4, 8, true, false, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
+        } else if (i == 2 && rowtiles) {
+            rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<32, 64, 4, 2, 4, true, true, false, E2_TSZ>, lds)
+                               : set_lds(ctx, enc_mfma<32, 64, 4, 2, 4, true, false, false, E2_TSZ>, lds);
+            if (rc) return rc;
+            ProfScope ps(ctx, "enc2_mfma");
+            if (pr->allpos[i]) LAUNCH((enc_mfma<32, 64, 4, 2, 4, true, true, false, E2_TSZ>), dim3(grid), dim3(WG), lds, ctx->stream, a);
+            else LAUNCH((enc_mfma<32, 64, 4, 2, 4, true, false, false, E2_TSZ>), dim3(grid), dim3(WG), lds, ctx->stream, a);
         } else if (i == 2) {
             rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<32, 64, 4, 2, 4, true, true>, lds) : set_lds(ctx, enc_mfma<32, 64, 4, 2, 4, true, false>, lds);
             if (rc) return rc;
             ProfScope ps(ctx, "enc2_mfma");
             if (pr->allpos[i]) LAUNCH((enc_mfma<32, 64, 4, 2, 4, true, true>), dim3(grid), dim3(WG), lds, ctx->stream, a);
             else LAUNCH((enc_mfma<32, 64, 4, 2, 4, true, false>), dim3(grid), dim3(WG), lds, ctx->stream, a);
+        } else if (rowtiles) {
+            rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<64, 128, 2, 2, 8, true, true, false, E3_TSZ>, lds)
+                               : set_lds(ctx, enc_mfma<64, 128, 2, 2, 8, true, false, false, E3_TSZ>, lds);
+            if (rc) return rc;
+            ProfScope ps(ctx, "enc3_mfma");
+            if (pr->allpos[i]) LAUNCH((enc_mfma<64, 128, 2, 2, 8, true, true, false, E3_TSZ>), dim3(grid), dim3(512), lds, ctx->stream, a);
+            else LAUNCH((enc_mfma<64, 128, 2, 2, 8, true, false, false, E3_TSZ>), dim3(grid), dim3(512), lds, ctx->stream, a);
         } else {
             rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<64, 128, 2, 2, 8, true, true>, lds) : set_lds(ctx, enc_mfma<64, 128, 2, 2, 8, true, false>, lds);
             if (rc) return rc;
@@ -2364,10 +2501,17 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
     return COVAHIP_OK;
 }
 
-#ifdef PHASE_TIMING
+#if defined(PHASE_TIMING) || defined(WGSPAN_ONLY)
 extern "C" int covahip_dev_wgspan_read(unsigned long long *out, int kid) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgspan), sizeof(unsigned long long) * 1024 * 4, sizeof(unsigned long long) * 1024 * 4 * kid) != hipSuccess;
 }
+#endif
+#ifdef WGSPAN_ONLY
+extern "C" int covahip_dev_itemspan_read(unsigned long long *out, int kid) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_itemspan), sizeof(unsigned long long) * 1024 * 16, sizeof(unsigned long long) * 1024 * 16 * kid) != hipSuccess;
+}
+#endif
+#ifdef PHASE_TIMING
 extern "C" int covahip_dev_phase_read(unsigned long long *out64, int reset) {
     if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase), sizeof(g_phase)) != hipSuccess) return 1;
     if (reset) {

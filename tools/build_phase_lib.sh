@@ -4,6 +4,6 @@
 cd "$(dirname "$0")/../cova_amd/csrc" || exit 1
 mkdir -p ../../tools/abl /tmp/isa
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result -Wno-unused-value -I../../include -I. -fno-honor-nans \
-    -mllvm -pragma-unroll-threshold=1000000 -DPHASE_TIMING -c blobnet_mfma.hip -o /tmp/isa/phase.o 2>&1 | grep -E "error" -A5
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../tools/abl/libPHASE.so build/ctx.hip.o build/bboxcc.hip.o build/blobnet.hip.o \
+    -mllvm -pragma-unroll-threshold=1000000 ${PHASE_DEFS:--DPHASE_TIMING} -c blobnet_mfma.hip -o /tmp/isa/phase.o 2>&1 | grep -E "error" -A5
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../tools/abl/${PHASE_OUT:-libPHASE.so} build/ctx.hip.o build/bboxcc.hip.o build/blobnet.hip.o \
     /tmp/isa/phase.o build/pipe.hip.o build/hostlib.cpp.o build/h264_front.cpp.o build/h264_cabac.cpp.o

@@ -17,6 +17,8 @@ ctx = Context(0)
 net = BlobNetInfer(ctx, W.random_init(1234), H, Wd, max_batch=B)
 if os.environ.get("QB_IMPL"):
     net.set_impl(os.environ["QB_IMPL"])
+for spec in filter(None, os.environ.get("QB_PLAN", "").split(",")):      # level:nbands:nbuf (covahip_blobnet_set_enc_plan)
+    net.set_enc_plan(*[int(x) for x in spec.split(":")])
 frames, index = synth.carrier_batch(B, H, Wd, seed=1, streams=8)
 d_frames = ctx.malloc(frames.nbytes)
 ctx.h2d(d_frames, frames)
@@ -50,3 +52,18 @@ for kid, name, nwg in ((5, "level 0 (enc0p)", 768), (0, "level 1", 512), (1, "le
     if first:
         print(f"   CUs with two workgroups: {len(first)}; first-started life {np.median(first):.2f} us, second-started {np.median(second):.2f} us; "
               f"role by block index: blocks < {nwg // 2} end at {np.median(en[:nwg // 2]):.2f}, blocks >= {nwg // 2} at {np.median(en[nwg // 2:]):.2f}")
+    if os.environ.get("WGSPAN_DETAIL") == str(kid):
+        life = en - st
+        print("   life histogram (us):", np.histogram(life, bins=12)[1].round(1).tolist(), np.histogram(life, bins=12)[0].tolist())
+        print("   end histogram (us): ", np.histogram(en, bins=12)[1].round(1).tolist(), np.histogram(en, bins=12)[0].tolist())
+        for c in np.unique(cu)[:12]:
+            idx = sorted(np.where(cu == c)[0], key=lambda i: st[i])
+            print("   cu", hex(int(c)), " ".join(f"[wg {i}: {st[i]:.2f}-{en[i]:.2f} clk {clk[i]:.0f}]" for i in idx))
+        if kid in (1, 2) and hasattr(lib, "covahip_dev_itemspan_read"):
+            io = (ctypes.c_ulonglong * (1024 * 16))()
+            assert lib.covahip_dev_itemspan_read(io, kid) == 0
+            t = (np.array(list(io), dtype=np.int64).reshape(1024, 4, 4)[:nwg] - t0) / 100.0
+            for name2, sel in (("workgroups < half", slice(0, nwg // 2)), ("workgroups >= half", slice(nwg // 2, nwg))):
+                for i in range(4):
+                    if (t[sel, i, 0] > -1e6).all() and (t[sel, i, 0] > 0).any():
+                        print(f"   {name2}, item {i}: start {np.median(t[sel, i, 0]):.2f}, requested {np.median(t[sel, i, 1]):.2f}, landed+barrier {np.median(t[sel, i, 2]):.2f}, tiles done {np.median(t[sel, i, 3]):.2f}")
