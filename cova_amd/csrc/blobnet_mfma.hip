@@ -1467,7 +1467,7 @@ __device__ __forceinline__ void dec012_load(Dec012W<C, COUT> &w, const half8 *wf
     }
 }
 template <int C1, int C2, int COUT, int CN>
-__device__ __forceinline__ void dec012_block(const uint8_t *tile, uint8_t *next_tile, __half *gout, uint8_t *scr_base,
+__device__ __forceinline__ void dec012_block(const uint8_t *lds0, const uint8_t *tile, uint8_t *next_tile, __half *gout, uint8_t *scr_base,
                                              const Dec012W<C1 + C2, COUT> &w, const DecLvl &g, const DecLvl &gn,
                                              int wave, int lane) {
     constexpr int C = C1 + C2, MT = 4 * COUT / 32, PG = 8 / MT;
@@ -1485,16 +1485,20 @@ __device__ __forceinline__ void dec012_block(const uint8_t *tile, uint8_t *next_
         const int qc = min(q, npos - 1);
         const int u = fdiv(qc, g.mGW), v = qc - u * GW;
         // the four taps' tile offsets and swizzles, then the K steps in dec_mfma's order with their B fragments AD steps ahead
-        int pbase[4], sw[4];
+        // chunk (2 kc + kh) ^ swizzle = (kc << 1) ^ (kh ^ swizzle): the tap's pixel address (from the start of LDS: the tiles start
+        // at multiples of 256 bytes) and (kh ^ swizzle) << 4 once per tile, then one xor per K step (the pixel address leaves
+        // the chunk bits clear)
+        const uint32_t toff = (uint32_t)(uintptr_t)(lds_void *)tile;   // LDS address (dec012_mfma aligns its LDS to 256)
+        uint32_t pk[4];
 #pragma unroll
         for (int tp = 0; tp < 4; tp++) {
             const int yy = u + 1 - (tp >> 1), xx = v + 1 - (tp & 1);   // tile coordinates of input (u-a, v-b)
-            pbase[tp] = (yy * TC + xx) * PS;
-            sw[tp] = swz_eval<CPP>(g.swz, xx, yy);
+            pk[tp] = (toff + (uint32_t)((yy * TC + xx) * PS)) | (uint32_t)((kh ^ swz_eval<CPP>(g.swz, xx, yy)) << 4);
         }
         auto frag = [&](int ks) -> half8 {
             const int tp = ks / KC, kc = ks % KC;
-            return *reinterpret_cast<const half8 *>(tile + pbase[tp] + (((kc * 2 + kh) ^ sw[tp]) * 16));
+            typedef const __attribute__((address_space(3))) half8 *lds_half8_ptr;
+            return *(lds_half8_ptr)(uintptr_t)(pk[tp] ^ (uint32_t)(kc << 5));
         };
         half8 ring[AD];
 #pragma unroll
@@ -1517,21 +1521,23 @@ __device__ __forceinline__ void dec012_block(const uint8_t *tile, uint8_t *next_
             // reg 4g+j <-> row n0 + j, n0 = mtile*32 + 8g + 4kh: one parity, four consecutive channels
             constexpr int CPPN = CN / 8, PSN = CN * 2;
             const int TCN = gn.Wi + 2;
-            if (q < npos) {
+            // rows n0 + 8 gq, n0 = mtile*32 + 4kh: with COUT >= 32 the four register groups of a lane are four 8-channel chunks of
+            // ONE output pixel (same parity), so the pixel, its bounds test and its swizzle are computed once per tile
+            static_assert(COUT >= 32 && COUT % 32 == 0, "one output pixel per lane and tile");
+            const int nb = mtile * 32 + 4 * kh;
+            const int phase = nb / COUT, cob = nb % COUT;
+            const int Y = 2 * u + (phase >> 1) - g.cy, X = 2 * v + (phase & 1) - g.cx;
+            if (q < npos && Y >= 0 && Y < g.Hd && X >= 0 && X < g.Wd) {
+                const int yy = Y + 1, xx = X + 1;
+                uint8_t *const pix = next_tile + (yy * TCN + xx) * PSN + (cob & 7) * 2;
+                const int sw = swz_eval<CPPN>(gn.swz, xx, yy);
 #pragma unroll
                 for (int gq = 0; gq < 4; gq++) {
-                    const int n0 = mtile * 32 + 8 * gq + 4 * kh;
-                    const int phase = n0 / COUT, co0 = n0 % COUT;
-                    const int Y = 2 * u + (phase >> 1) - g.cy, X = 2 * v + (phase & 1) - g.cx;
-                    if (Y >= 0 && Y < g.Hd && X >= 0 && X < g.Wd) {
-                        half4 o;
+                    half4 o;
 #pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            o[j] = (_Float16)fmaxf(acc[4 * gq + j] * es[4 * gq + j] + eb[4 * gq + j], 0.f);
-                        const int yy = Y + 1, xx = X + 1;
-                        *reinterpret_cast<half4 *>(next_tile + (yy * TCN + xx) * PSN +
-                                                   (((co0 >> 3) ^ swz_eval<CPPN>(gn.swz, xx, yy)) * 16) + (co0 & 7) * 2) = o;
-                    }
+                    for (int j = 0; j < 4; j++)
+                        o[j] = (_Float16)fmaxf(acc[4 * gq + j] * es[4 * gq + j] + eb[4 * gq + j], 0.f);
+                    *reinterpret_cast<half4 *>(pix + ((((cob >> 3) + gq) ^ sw) * 16)) = o;
                 }
             }
         } else {
@@ -1571,7 +1577,7 @@ __device__ __forceinline__ void dec012_block(const uint8_t *tile, uint8_t *next_
 }
 
 __global__ __launch_bounds__(512, 2) void dec012_mfma(Dec012Args p) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    extern __shared__ __attribute__((aligned(256))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t *const t0 = smem + p.lv[0].tile_off, *const t1 = smem + p.lv[1].tile_off, *const t2 = smem + p.lv[2].tile_off;
     WGSPAN_BEGIN();
@@ -1596,7 +1602,7 @@ __global__ __launch_bounds__(512, 2) void dec012_mfma(Dec012Args p) {
             wait_vmem();
             lds_barrier();
             PHASE_MARK(2);   // tiles landing
-            dec012_block<0, 128, 64, 128>(t0, t1, nullptr, nullptr, w0, p.lv[0], p.lv[1], wave, lane);
+            dec012_block<0, 128, 64, 128>(smem, t0, t1, nullptr, nullptr, w0, p.lv[0], p.lv[1], wave, lane);
         }
         PHASE_MARK(3);       // block 0: tiles
         {
@@ -1607,7 +1613,7 @@ __global__ __launch_bounds__(512, 2) void dec012_mfma(Dec012Args p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
             PHASE_MARK(4);   // block 1: weights + barrier
-            dec012_block<64, 64, 32, 64>(t1, t2, nullptr, nullptr, w1, p.lv[1], p.lv[2], wave, lane);
+            dec012_block<64, 64, 32, 64>(smem, t1, t2, nullptr, nullptr, w1, p.lv[1], p.lv[2], wave, lane);
         }
         PHASE_MARK(5);       // block 1: tiles
         {
@@ -1618,7 +1624,7 @@ __global__ __launch_bounds__(512, 2) void dec012_mfma(Dec012Args p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
             PHASE_MARK(6);   // block 2: weights + barrier
-            dec012_block<32, 32, 16, 0>(t2, nullptr, p.out + (size_t)b * p.lv[2].Hd * p.lv[2].Wd * 16, smem + p.scr_off, w2,
+            dec012_block<32, 32, 16, 0>(smem, t2, nullptr, p.out + (size_t)b * p.lv[2].Hd * p.lv[2].Wd * 16, smem + p.scr_off, w2,
                                         p.lv[2], p.lv[2], wave, lane);
         }
         PHASE_MARK(7);       // block 2: tiles + stores
@@ -2375,7 +2381,7 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
             g.mRC = magic((in.W + 2) * (m->dec_ci[j] / 8));
             g.swz = choose_swz(false, m->dec_ci[j], in.W, 0, in.H + 1);
             g.tile_off = (int)off;
-            off += (((size_t)(in.H + 2) * (in.W + 2) * m->dec_ci[j] * 2) + 15) & ~(size_t)15;
+            off += (((size_t)(in.H + 2) * (in.W + 2) * m->dec_ci[j] * 2) + 255) & ~(size_t)255;   // 256: dec012_block's xor addressing
             a.skip[j] = act[BN_LEVELS - j];
             a.Ts[j] = j == 0 ? 1 : BN_T;
             a.wf[j] = (const half8 *)(prep + pr->dec[j].wfrag);
