@@ -372,6 +372,10 @@ __global__ __launch_bounds__(WG0, 4) void enc0p_mfma(Enc0pArgs p) {
     const half8 bo0 = p.wfrag[128 + lane], bo1 = p.wfrag[192 + lane];
     const int co = lane & 15;
     const float e0 = p.epi[co], e1 = p.epi[16 + co], e2 = p.epi[32 + co];
+    // the lane's part of its fragment addresses: window m >> 1 of a tile, conv row m & 1; g: K half (kernel row) and pixel pair
+    const int m = lane & 15, g = lane >> 4;
+    const uint32_t lc0 = (uint32_t)((((m & 1) + (g >> 1)) * TC + 2 * (m >> 1) + 2 * (g & 1)) * 8);
+    const uint32_t lc1 = (uint32_t)((((m & 1) + 2) * TC + 2 * (m >> 1) + 2 * (g & 1)) * 8);
     const int n_items = p.F * p.nbands;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int f = fdiv(item, p.mNb), band = item - f * p.nbands;
@@ -442,26 +446,27 @@ __global__ __launch_bounds__(WG0, 4) void enc0p_mfma(Enc0pArgs p) {
                 *reinterpret_cast<uint4 *>(smem + (i >> 1) * TC * 8 + ((i & 1) ? (p.W + 2) * 8 : 0)) = make_uint4(0, 0, 0, 0);
         }
         lds_barrier();
-        // four tiles of 8 pool windows per wave pass (tile layout of enc0_mfma): the 32 windows x 16 channels leave
-        // the wave as one 16-byte store per lane
-        const int nwin = (rows / 2) * p.Wp;
-        const int ngroups = (nwin + 31) / 32;
-        const int m = lane & 15, g = lane >> 4;
+        // four tiles of 8 pool windows per wave pass: 32 consecutive windows of ONE window row (round 4: a pass is (window row,
+        // half-row index) -- wave-uniform -- so a fragment's address is a lane constant + the pass's base + 128 bytes per tile as an
+        // immediate, where passes over a band-wide window index cost a division and twelve vector instructions per tile; the lanes
+        // of windows past the row's end compute on what the band holds there and store nothing).  The 32 windows x 16 channels
+        // leave the wave as one 16-byte store per lane
+        const int nhalf = (p.Wp + 31) >> 5;
+        const int ngroups = (rows / 2) * nhalf;
         uint8_t *const scr = smem + p.scr_off + wave * 1024;
         __half *const ob = p.out + (size_t)f * p.Ho * p.Wo * 16;
-        for (int grp = wave; grp < ngroups; grp += WG0 / 64) {
+        int g_wy = 0, g_h = wave;
+        for (int grp = wave; grp < ngroups; grp += WG0 / 64, g_h += WG0 / 64) {
+            while (g_h >= nhalf) { g_h -= nhalf; g_wy++; }
+            const uint32_t gbase = (uint32_t)(((2 * g_wy) * TC + 64 * g_h) * 8);
+            // 16-byte aligned (even tile column, row stride a multiple of 16): one ds_read_b128 each
+            const uint8_t *const a0 = smem + (gbase + lc0), *const a1 = smem + (gbase + lc1);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int win = min((grp * 4 + k) * 8 + (m >> 1), nwin - 1);
-                const int wy = fdiv(win, p.mWp), wx = win - wy * p.Wp;
-                const int yy = 2 * wy + (m & 1), xe = 2 * wx;
-                const int offe0 = ((yy + (g >> 1)) * TC + xe + 2 * (g & 1)) * 8;
-                const int offe1 = ((yy + 2) * TC + xe + 2 * (g & 1)) * 8;
-                // 16-byte aligned (even tile column, row stride a multiple of 16): one ds_read_b128 each
-                const half8 ae0 = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(smem + offe0, 16));
-                const half8 ae1 = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(smem + offe1, 16));
-                const half8 ao0 = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(smem + offe0 + 16, 16));
-                const half8 ao1 = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(smem + offe1 + 16, 16));
+                const half8 ae0 = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(a0 + k * 128, 16));
+                const half8 ae1 = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(a1 + k * 128, 16));
+                const half8 ao0 = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(a0 + k * 128 + 16, 16));
+                const half8 ao1 = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(a1 + k * 128 + 16, 16));
                 f32x4 ce = {0.f, 0.f, 0.f, 0.f}, co_ = {0.f, 0.f, 0.f, 0.f};
                 ce = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae0, be0, ce, 0, 0, 0);
                 co_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao0, bo0, co_, 0, 0, 0);
@@ -479,10 +484,9 @@ __global__ __launch_bounds__(WG0, 4) void enc0p_mfma(Enc0pArgs p) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int owin = grp * 32 + (lane >> 1);
-            if (owin < nwin) {
-                const int owy = fdiv(owin, p.mWp), owx = owin - owy * p.Wp;
-                const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
+            const int owx = 32 * g_h + (lane >> 1);
+            if (owx < p.Wp) {
+                const int gy = y0 / 2 + g_wy + p.oy, gx = owx + p.ox;
                 *reinterpret_cast<uint4 *>(ob + (gy * p.Wo + gx) * 16 + 8 * (lane & 1)) =
                     *reinterpret_cast<const uint4 *>(scr + lane * 16);
             }
