@@ -525,29 +525,6 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
     unsigned long long ph_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-    half8 bf[KSTEPS];
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ks++) bf[ks] = p.wfrag[(ntile * KSTEPS + ks) * 64 + lane];
-    const int co = ntile * 32 + (lane & 31);
-    const float e0 = p.epi[co], e1 = p.epi[COUT + co], e2 = p.epi[2 * COUT + co];   // see pool4
-    const TmixW tm = load_tmix(p.epi + 3 * COUT, lane);
-    // TSZ > 0: the lane's part of a fragment address per tap: pixel (lane's window of the tile, position, tap) of tile (0, 0),
-    // xor the 16-byte chunk (kh ^ swizzle) -- the K half kh and the swizzle meet in the chunk bits, which the pixel address
-    // leaves clear
-    [[maybe_unused]] uint32_t kq[9];
-    if constexpr (TSZ > 0) {
-        const int m0 = lane & 31, kh0 = lane >> 5;
-        const int yl = (m0 >> 1) & 1, xl = 2 * (m0 >> 2) + (m0 & 1);
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            const int yy = yl + tap / 3, xx = xl + tap % 3;
-            kq[tap] = (uint32_t)((yy * TC + xx) * PS) ^ (uint32_t)((kh0 ^ swz_eval<CPP>(p.swz, xx, yy)) << 4);
-        }
-    }
-#ifdef PHASE_TIMING
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PHASE_MARK(8);   // weight fragments and epilogue constants in registers
-#endif
     // ---- PRE: temporal MLP of the level below, in place, on the 16-byte pieces THIS thread requested (the staging loop
     // and this one walk the same piece indices): a thread needs nothing but its own vmcnt(0) before it, so the pass
     // runs while other waves' pieces are still landing and no workgroup barrier separates it from the staging.  A lane
@@ -636,6 +613,33 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
         wait_vmem();
         if constexpr (PRE) mlp_own(smem, it.band, load_tmix(p.tm_pre, lane));
     }
+    // one buffer: the first band is requested BEFORE the weight fragments (36 - 144 registers per lane, every workgroup of
+    // the launch pulling the same 37 - 295 KB through L2 at once), so that both are in flight together
+    bool first_staged = false;
+    if (more && !dbl) { stage(it.b, it.band, smem, lane); first_staged = true; }
+    half8 bf[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++) bf[ks] = p.wfrag[(ntile * KSTEPS + ks) * 64 + lane];
+    const int co = ntile * 32 + (lane & 31);
+    const float e0 = p.epi[co], e1 = p.epi[COUT + co], e2 = p.epi[2 * COUT + co];   // see pool4
+    const TmixW tm = load_tmix(p.epi + 3 * COUT, lane);
+    // TSZ > 0: the lane's part of a fragment address per tap: pixel (lane's window of the tile, position, tap) of tile (0, 0),
+    // xor the 16-byte chunk (kh ^ swizzle) -- the K half kh and the swizzle meet in the chunk bits, which the pixel address
+    // leaves clear
+    [[maybe_unused]] uint32_t kq[9];
+    if constexpr (TSZ > 0) {
+        const int m0 = lane & 31, kh0 = lane >> 5;
+        const int yl = (m0 >> 1) & 1, xl = 2 * (m0 >> 2) + (m0 & 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int yy = yl + tap / 3, xx = xl + tap % 3;
+            kq[tap] = (uint32_t)((yy * TC + xx) * PS) ^ (uint32_t)((kh0 ^ swz_eval<CPP>(p.swz, xx, yy)) << 4);
+        }
+    }
+#ifdef PHASE_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PHASE_MARK(8);   // weight fragments and epilogue constants in registers
+#endif
     while (more) {
         const int b = it.b, band = it.band;
         // balanced bands of whole pool-window rows
@@ -653,9 +657,12 @@ __global__ __launch_bounds__(NWV * 64, OCC) void enc_mfma(EncArgs p) {
         TmixW tmp;
         if constexpr (PRE) tmp = load_tmix(p.tm_pre, ll);
         if (!dbl) {
-            lds_barrier();
-            PHASE_MARK(1);   // waiting for the workgroup's other waves to finish the previous item
-            stage(b, band, bandp, ll);
+            if (!first_staged) {
+                lds_barrier();
+                PHASE_MARK(1);   // waiting for the workgroup's other waves to finish the previous item
+                stage(b, band, bandp, ll);
+            }
+            first_staged = false;
             PHASE_MARK(2);   // issuing the band's LDS-DMA
             ITEM_MARK(1);
             wait_vmem();
