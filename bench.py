@@ -469,13 +469,15 @@ def main():
             pre["through_gstreamer_elements"] = element_rate()
             # BASELINE config 4: metapreprocess -> BlobNet -> bboxcc -> cova (embedded SORT + GoP filter) per stream, the
             # experiment's tracker parameters, blob-like weights (a few boxes per frame, as a trained BlobNet gives)
-            chain = element_rate("chain_bench.sh", ("20000", "16"))
+            chain = element_rate("chain_bench.sh", ("60000", "16"))
             if "frames_per_s_full_chain" in chain:
                 t_cova = chain["seconds"] * min(16, effective_cores()) / max(1, chain["frames_in"])
-                chain["limiter"] = ("host: the per-stream cova elements (SORT with the experiment's minhits 30 / maxage 60 keeps "
-                                    "dozens of young trackers per stream alive); the GPU side of the same element runs at "
-                                    "through_gstreamer_elements")
-                chain["host_threads"] = "16 decoder-branch threads + 8 pusher threads of blobnetfilter on this box's CPU share"
+                chain["limiter"] = ("host: every core of the box's share is busy (the per-stream cova elements -- SORT with the "
+                                    "experiment's minhits 30 / maxage 60 keeps ~130 young trackers per stream alive -- on the pusher "
+                                    "threads, the feeders' packing into the slots, GStreamer's per-buffer costs); 8 or 16 pusher threads "
+                                    "give the same rate")
+                chain["host_threads"] = ("16 carrier-frame feeders + 16 access-unit feeders + 8 pusher threads + collector + submitter on "
+                                         "this box's CPU share")
                 chain["cova_us_per_frame_upper_bound"] = round(t_cova * 1e6, 1)
             pre["full_filter_chain"] = chain
         if not args.no_cpu_baseline:

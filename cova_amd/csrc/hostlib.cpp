@@ -24,6 +24,7 @@
 #include <list>
 #include <map>
 #include <new>
+#include <memory>
 #include <vector>
 
 #include "covahip.h"
@@ -359,38 +360,44 @@ struct Tracker {  // KalmanBoxTracker, tracker/mod.rs:15-69
     bool active = false;
     std::vector<covahip_bbox> history;
     uint64_t hits = 0, time_since_update = 0, hit_streaks = 0, age = 0;
-    P x[7];
-    Mat7 Pm;  // previous_estimate
+    // The filter state lives in its own block: Sort::update's retain moves every tracker behind the first one that died -- at
+    // the experiment's parameters ~130 trackers per stream and frame -- and a tracker with its two 7x7 matrices inline is 600
+    // bytes to move, with the state out of line a few pointers and counters.
+    struct KState {
+        P x[7];
+        Mat7 Pm;  // previous_estimate
+        P xp[7];
+        Mat7 Pp;  // prior
+        covahip_bbox prior_box;
+    };
+    std::unique_ptr<KState> k{new KState()};
     bool has_prior = false;
-    P xp[7];
-    Mat7 Pp;  // prior
     // predict() derives the prior from the previous ESTIMATE (x, Pm), which only a matched update() changes: a tracker that
     // goes unmatched recomputes the same prior -- and the same predicted box -- frame after frame.  At the experiment's
     // parameters (maxage 60, minhits 30) a stream carries dozens of such trackers, and their 7x7 covariance products were
     // 44 % of the element's host time: the prior is kept while the estimate has not changed (same values, bit for bit).
     bool prior_valid = false;
-    covahip_bbox prior_box{};
 
     Tracker(uint64_t id_, const covahip_bbox &b, uint64_t start_) : id(id_), start(start_), last_match(start_) {
         P z[4];
         into_z(b, z);
-        for (int i = 0; i < 7; i++) x[i] = i < 4 ? z[i] : 0.f;
+        for (int i = 0; i < 7; i++) k->x[i] = i < 4 ? z[i] : 0.f;
         for (int i = 0; i < 7; i++)
-            for (int j = 0; j < 7; j++) Pm.m[i][j] = (i == j) ? (i < 4 ? 10.f : 10000.f) : 0.f;
+            for (int j = 0; j < 7; j++) k->Pm.m[i][j] = (i == j) ? (i < 4 ? 10.f : 10000.f) : 0.f;
     }
 
     const covahip_bbox &predict(uint64_t ts) {  // tracker/mod.rs:104-121
         if (!prior_valid) {
-            if (x[6] + x[2] <= 0.f) x[6] = 0.f;
-            kalman_predict(x, Pm, xp, Pp);
+            if (k->x[6] + k->x[2] <= 0.f) k->x[6] = 0.f;
+            kalman_predict(k->x, k->Pm, k->xp, k->Pp);
             has_prior = true;
-            prior_box = from_x(xp);
-            prior_box.has_track_id = 1;
-            prior_box.track_id = id;
-            prior_box.has_timestamp = 1;
+            k->prior_box = from_x(k->xp);
+            k->prior_box.has_track_id = 1;
+            k->prior_box.track_id = id;
+            k->prior_box.has_timestamp = 1;
             prior_valid = true;
         }
-        covahip_bbox b = prior_box;
+        covahip_bbox b = k->prior_box;
         b.timestamp = ts;
         age += 1;
         time_since_update += 1;
@@ -411,9 +418,9 @@ struct Tracker {  // KalmanBoxTracker, tracker/mod.rs:15-69
             if (!has_prior) return false;
             P xn[7];
             Mat7 Pn;
-            if (!kalman_update(xp, Pp, z, xn, Pn)) return false;
-            std::memcpy(x, xn, sizeof(x));
-            Pm = Pn;
+            if (!kalman_update(k->xp, k->Pp, z, xn, Pn)) return false;
+            std::memcpy(k->x, xn, sizeof(k->x));
+            k->Pm = Pn;
             prior_valid = false;   // the estimate has moved
             covahip_bbox &last = history.back();
             last.has_class_id = det->has_class_id;
@@ -522,37 +529,61 @@ struct Sort {  // sort/src/lib.rs:14-23
     std::vector<long> match_of_trk;        // scratch of update()
     std::vector<uint8_t> det_matched;
 
+    // scratch of match_dets (kept between frames: a frame allocates nothing here)
+    mutable std::vector<P> cost_, red_, px1_, py1_, px2_, py2_, pa_, pw_;
+    mutable std::vector<uint8_t> ov_;
+    mutable std::vector<size_t> keep_;
+
     std::vector<std::pair<size_t, size_t>> match_dets(const std::vector<covahip_bbox> &preds,
                                                       const std::vector<covahip_bbox> &dets) const {
         std::vector<std::pair<size_t, size_t>> res;
         const size_t np = preds.size(), nd = dets.size();
         if (np == 0 || nd == 0) return res;
-        std::vector<P> cost(np * nd);  // column-major: rows = predictions, cols = detections
-        std::vector<uint8_t> overlaps(np, 0);
-        for (size_t j = 0; j < nd; j++)
+        // the predictions as arrays: the IoU of every (detection, prediction) pair -- n_dets x ~130 per frame at the experiment's
+        // parameters -- is then a loop the compiler vectorises; same expressions in the same order as bbox_iou (bbox.rs:39-56)
+        cost_.resize(np * nd);  // column-major: rows = predictions, cols = detections
+        ov_.assign(np, 0);
+        px1_.resize(np); py1_.resize(np); px2_.resize(np); py2_.resize(np); pa_.resize(np); pw_.resize(np);
+        for (size_t i = 0; i < np; i++) {
+            const covahip_bbox &t = preds[i];
+            px1_[i] = t.left; py1_[i] = t.top; px2_[i] = t.left + t.width; py2_[i] = t.top + t.height; pa_[i] = t.area;
+            pw_[i] = trackers[i].active ? 1.f : 2.f;  // lib.rs:108-113
+        }
+        std::vector<P> &cost = cost_;
+        for (size_t j = 0; j < nd; j++) {
+            const covahip_bbox &d = dets[j];
+            const P dx1 = d.left, dy1 = d.top, dx2 = d.left + d.width, dy2 = d.top + d.height, da = d.area;
+            const P *x1 = px1_.data(), *y1 = py1_.data(), *x2 = px2_.data(), *y2 = py2_.data(), *pa = pa_.data(), *pw = pw_.data();
+            P *c = cost.data() + j * np;
+            uint8_t *ov = ov_.data();
             for (size_t i = 0; i < np; i++) {
-                const P w = trackers[i].active ? 1.f : 2.f;  // lib.rs:108-113
-                const P iou = bbox_iou(dets[j], preds[i]);
-                overlaps[i] |= iou != 0.f;
-                cost[j * np + i] = -iou + w;
+                const P x_left = std::fmax(dx1, x1[i]), y_top = std::fmax(dy1, y1[i]);
+                const P x_right = std::fmin(dx2, x2[i]), y_bottom = std::fmin(dy2, y2[i]);
+                const bool none = x_right <= x_left || y_bottom <= y_top;
+                const P inter = (x_right - x_left) * (y_bottom - y_top);
+                const P uni = da + pa[i] - inter;
+                const P iou = none ? 0.f : inter / uni;
+                ov[i] |= iou != 0.f;
+                c[i] = -iou + pw[i];
             }
+        }
         // Trackers that overlap NO detection all carry the same cost row (1 in every column when active, 2 when not), and an
         // edge to one of them never survives the filters below (1 > 1 - iou_threshold; == 2.0).  Of each of the two classes at
         // most n_dets members can take part in an optimal assignment and which ones is immaterial, so only the first n_dets of
         // each class stay in the problem: same optimum value, same surviving edges, and the solver's work drops from
         // n_dets^2 x trackers to about n_dets^3 (at the experiment's maxage 60 / minhits 30 a stream carries 100 - 250
         // trackers, nearly all of them idle: 50 -> 3 us per frame at 11 detections x 256 trackers).
-        std::vector<size_t> keep;
-        keep.reserve(np);
+        std::vector<size_t> &keep = keep_;
+        keep.clear();
         size_t idle[2] = {0, 0};
         for (size_t i = 0; i < np; i++)
-            if (overlaps[i] || idle[trackers[i].active ? 0 : 1]++ < nd) keep.push_back(i);
+            if (ov_[i] || idle[trackers[i].active ? 0 : 1]++ < nd) keep.push_back(i);
         if (keep.size() < np) {
             const size_t nk = keep.size();
-            std::vector<P> red(nk * nd);
+            red_.resize(nk * nd);
             for (size_t j = 0; j < nd; j++)
-                for (size_t k = 0; k < nk; k++) red[j * nk + k] = cost[j * np + keep[k]];
-            for (auto &e : linear_assignment(red, nk, nd)) {
+                for (size_t k = 0; k < nk; k++) red_[j * nk + k] = cost[j * np + keep[k]];
+            for (auto &e : linear_assignment(red_, nk, nd)) {
                 const size_t i = keep[e.first];
                 const P thr = trackers[i].active ? (1.f - iou_threshold) : (2.f - iou_threshold);
                 if (cost[e.second * np + i] <= thr) res.emplace_back(i, e.second);
@@ -756,7 +787,7 @@ int covahip_sort_tracker_info(const covahip_sort *s, size_t i, uint64_t *id, int
     if (active) *active = t.active ? 1 : 0;
     if (hit_streaks) *hit_streaks = t.hit_streaks;
     if (time_since_update) *time_since_update = t.time_since_update;
-    if (state) *state = from_x(t.x);  // get_state(): box of the current estimate
+    if (state) *state = from_x(t.k->x);  // get_state(): box of the current estimate
     return COVAHIP_OK;
 }
 
