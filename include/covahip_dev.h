@@ -15,8 +15,10 @@ extern "C" {
  * before the fused decoder; measured slower on MI355X, kept because it is the fallback for grids whose three decoder
  * tiles do not fit in LDS together, and tests compare the two bit for bit).  (2 and 3 were single-launch forms of encoder
  * levels 0 + 1, measured slower and removed in round 3; DESIGN.md has their numbers.)  5 = encoder level 1 on the
- * round-1..3 kernel (32x32x16 products, 32 channels per wave, swizzled LDS band) instead of enc1w_mfma (16x16x32 products,
- * 16 channels per wave, round 4): the fallback for grids wider than enc1w_mfma's fixed LDS row, and the A/B partner. */
+ * round-1..3 kernel (32x32x16 products, swizzled LDS band, LDS-DMA) instead of enc1_mfma (16x16x32 products, affine band,
+ * round 4): the fallback for grids wider than enc1_mfma's fixed LDS row, and the A/B partner.  6 = encoder levels 2 and 3
+ * on the general tiles (eight consecutive windows of a band) instead of the row-aligned ones (eight windows of one window
+ * row, fragment addresses from per-kernel lane constants; round 4), which are the default where the geometry suits them. */
 int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl);
 
 /* bboxcc kernel choice: cap > 0 = run capacity of the wave-per-frame kernel's first pass (frames with more runs get a
