@@ -260,6 +260,33 @@ def test_encoder_band_plans_give_identical_bits(ctx, weights_flat, plans):
     np.testing.assert_array_equal(got[1], ref[1])
 
 
+@pytest.mark.parametrize("hw", [(68, 120), (67, 120)])
+@pytest.mark.parametrize("mixed_gamma", [False, True])
+def test_row_aligned_tiles_match_general_tiles_bitwise(ctx, weights_flat, hw, mixed_gamma):
+    """Encoder levels 2 and 3 on row-aligned tiles (eight windows of one window row, fragment addresses from per-kernel lane
+    constants, periodic swizzle; the default at 1080p) vs the general tiles (developer switch "enc_general_tiles"): another
+    tile enumeration and LDS layout, the same products in the same order -- logits, masks and boxes bit for bit, both gamma
+    sign classes, both entries."""
+    h, w = hw
+    b = 20
+    flat = _mixed_gamma_weights(78) if mixed_gamma else weights_flat
+    stack = synth.stacked_batch(b, h, w, seed=23, streams=2)
+    frames, index = synth.carrier_batch(b, h, w, seed=23, streams=2)
+    net = BlobNetInfer(ctx, flat, h, w, max_batch=b)
+    logits, mask = net.infer(stack)
+    got = net.filter_frames(frames, index, 2, max_boxes=1024, want_mask=True, want_logits=True)
+    net.set_impl("enc_general_tiles")
+    try:
+        logits2, mask2 = net.infer(stack)
+        got2 = net.filter_frames(frames, index, 2, max_boxes=1024, want_mask=True, want_logits=True)
+    finally:
+        net.set_impl("mfma")
+    np.testing.assert_array_equal(logits, logits2)
+    np.testing.assert_array_equal(mask, mask2)
+    for a, c in zip(got, got2):
+        np.testing.assert_array_equal(a, c)
+
+
 @pytest.mark.parametrize("hw", [(68, 120), (67, 120), (45, 80), (35, 60)])
 def test_fused_decoder_blocks_match_separate_launches_bitwise(ctx, weights_flat, hw):
     """Decoder blocks 0..2 as one launch (one workgroup per frame, intermediates in LDS) vs the three launches of
