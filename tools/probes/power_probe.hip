@@ -121,7 +121,9 @@ int main(int argc, char **argv) {
     const double seconds = argc > 2 ? atof(argv[2]) : 3.0;
     unsigned long long *d;
     (void)hipMalloc(&d, 4096);
-    const size_t bytes = (size_t)4 << 30;   // 4 GB: larger than the last-level cache
+    // 4 GB: larger than the last-level cache; a third argument (MB, power of two) makes the read / write streams walk a smaller
+    // buffer (128 MB: misses the 32 MB of L2, fits the 256 MB Infinity Cache)
+    const size_t bytes = argc > 3 ? (size_t)atoi(argv[3]) << 20 : (size_t)4 << 30;
     uint4 *src = nullptr;
     if (kind == 5 || kind == 9) { (void)hipMalloc(&src, bytes); (void)hipMemset(src, 1, bytes); }
     const size_t n16 = bytes / 16;
