@@ -169,6 +169,8 @@ DEV_PROTOTYPES = {
     "covahip_bboxcc_set_wave_cap": (C.c_int, [_P, C.c_int]),
     "covahip_blobnet_set_enc_plan": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "covahip_dev_clock_mhz": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
+    "covahip_dev_graph_probe": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int, C.POINTER(C.c_float),
+                                          C.POINTER(C.c_float)]),
     "covahip_dev_bboxcc_overflow": (C.c_int, [_P, C.POINTER(C.c_int32)]),
 }
 

@@ -386,6 +386,48 @@ int covahip_filter_forward_frames_packed(covahip_ctx *ctx, const uint16_t *d_rec
                          max_boxes, d_logits, d_mask, true);
 }
 
+// Developer probe (include/covahip_dev.h): the same carrier-frame step `iters` times as stream launches and as launches of ONE
+// captured HIP graph of it -- what the gaps between the six launches of a step cost on their own.
+int covahip_dev_graph_probe(covahip_ctx *ctx, const uint8_t *d_frames, int n_frames, const int32_t *stack_index, int batch,
+                            int area_thresh, covahip_box *d_boxes, int32_t *d_counts, int max_boxes, uint8_t *d_mask, int iters,
+                            float *ms_direct, float *ms_graph) {
+    if (!ctx || !ctx->blobnet || !ms_direct || !ms_graph || iters < 1) return COVAHIP_ERR_INVALID_ARG;
+    covahip_blobnet *m = ctx->blobnet;
+    COVAHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc = covahip_primary_op(ctx)) return rc;
+    hipEvent_t e0, e1;
+    COVAHIP_CHECK_HIP(ctx, hipEventCreate(&e0));
+    COVAHIP_CHECK_HIP(ctx, hipEventCreate(&e1));
+    for (int i = 0; i < 3; i++)
+        if (int rc = filter_placed(ctx, m, d_frames, n_frames, stack_index, batch, area_thresh, d_boxes, d_counts, max_boxes, nullptr, d_mask)) return rc;
+    COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    COVAHIP_CHECK_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < iters; i++)
+        if (int rc = filter_placed(ctx, m, d_frames, n_frames, stack_index, batch, area_thresh, d_boxes, d_counts, max_boxes, nullptr, d_mask)) return rc;
+    COVAHIP_CHECK_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    COVAHIP_CHECK_HIP(ctx, hipEventSynchronize(e1));
+    COVAHIP_CHECK_HIP(ctx, hipEventElapsedTime(ms_direct, e0, e1));
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    COVAHIP_CHECK_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+    const int crc = filter_placed(ctx, m, d_frames, n_frames, stack_index, batch, area_thresh, d_boxes, d_counts, max_boxes, nullptr, d_mask);
+    COVAHIP_CHECK_HIP(ctx, hipStreamEndCapture(ctx->stream, &graph));
+    if (crc) return crc;
+    COVAHIP_CHECK_HIP(ctx, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    for (int i = 0; i < 3; i++) COVAHIP_CHECK_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
+    COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    COVAHIP_CHECK_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < iters; i++) COVAHIP_CHECK_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
+    COVAHIP_CHECK_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    COVAHIP_CHECK_HIP(ctx, hipEventSynchronize(e1));
+    COVAHIP_CHECK_HIP(ctx, hipEventElapsedTime(ms_graph, e0, e1));
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return COVAHIP_OK;
+}
+
 int covahip_blobnet_forward(covahip_ctx *ctx, const uint8_t *rgba_stack, int batch, float *logits, uint8_t *mask,
                             int mem_kind) {
     if (!ctx || batch < 0) return COVAHIP_ERR_INVALID_ARG;

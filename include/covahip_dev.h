@@ -41,6 +41,12 @@ int covahip_blobnet_set_enc_plan(covahip_ctx *ctx, int level, int nbands, int nb
  * (MI355X_MICROARCH.md, DVFS give-back).  bench.py prints it so that step times of different boxes can be compared. */
 int covahip_dev_clock_mhz(covahip_ctx *ctx, int busy_us, float *mhz);
 
+/* The same carrier-frame step (device pointers, one lane) `iters` times as stream launches and as launches of ONE captured HIP
+ * graph of it: total milliseconds of each.  Synchronises the ctx.  (tools/graph_probe.py) */
+int covahip_dev_graph_probe(covahip_ctx *ctx, const uint8_t *d_frames, int n_frames, const int32_t *stack_index, int batch,
+                            int area_thresh, covahip_box *d_boxes, int32_t *d_counts, int max_boxes, uint8_t *d_mask, int iters,
+                            float *ms_direct, float *ms_graph);
+
 #ifdef __cplusplus
 }
 #endif
