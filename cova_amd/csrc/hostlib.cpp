@@ -354,11 +354,16 @@ covahip_bbox from_x(const P x[7]) {  // state.rs:18-28 -- `top` uses width (refe
     return bbox_new(xx - width / 2.f, y - width / 2.f, width, height);
 }
 
-struct Tracker {  // KalmanBoxTracker, tracker/mod.rs:15-69
+struct TrackerBody {  // KalmanBoxTracker, tracker/mod.rs:15-69
     uint64_t id = 0, start = 0, last_match = 0;
     std::vector<uint64_t> seen_ts;
     bool active = false;
-    std::vector<covahip_bbox> history;
+    // The predictions of consecutive UNMATCHED frames are the same box with another timestamp (the prior is kept, below), and at
+    // the experiment's parameters ~125 of a stream's ~130 trackers are in that state: predict() then only notes the timestamp,
+    // and the boxes are written out when somebody looks (hist(): a match, the export of a finished track, the introspection
+    // calls).  Same history, entry for entry.
+    mutable std::vector<covahip_bbox> history;
+    mutable std::vector<uint64_t> pending_ts;
     uint64_t hits = 0, time_since_update = 0, hit_streaks = 0, age = 0;
     // The filter state lives in its own block: Sort::update's retain moves every tracker behind the first one that died -- at
     // the experiment's parameters ~130 trackers per stream and frame -- and a tracker with its two 7x7 matrices inline is 600
@@ -378,7 +383,7 @@ struct Tracker {  // KalmanBoxTracker, tracker/mod.rs:15-69
     // 44 % of the element's host time: the prior is kept while the estimate has not changed (same values, bit for bit).
     bool prior_valid = false;
 
-    Tracker(uint64_t id_, const covahip_bbox &b, uint64_t start_) : id(id_), start(start_), last_match(start_) {
+    TrackerBody(uint64_t id_, const covahip_bbox &b, uint64_t start_) : id(id_), start(start_), last_match(start_) {
         P z[4];
         into_z(b, z);
         for (int i = 0; i < 7; i++) k->x[i] = i < 4 ? z[i] : 0.f;
@@ -386,8 +391,20 @@ struct Tracker {  // KalmanBoxTracker, tracker/mod.rs:15-69
             for (int j = 0; j < 7; j++) k->Pm.m[i][j] = (i == j) ? (i < 4 ? 10.f : 10000.f) : 0.f;
     }
 
-    const covahip_bbox &predict(uint64_t ts) {  // tracker/mod.rs:104-121
-        if (!prior_valid) {
+    void flush() const {
+        for (uint64_t ts : pending_ts) {
+            covahip_bbox b = k->prior_box;
+            b.timestamp = ts;
+            history.push_back(b);
+        }
+        pending_ts.clear();
+    }
+    const std::vector<covahip_bbox> &hist() const { flush(); return history; }
+    size_t hist_len() const { return history.size() + pending_ts.size(); }
+
+    bool predict(uint64_t ts) {  // tracker/mod.rs:104-121; the predicted box is k->prior_box with this timestamp.  true: the prior moved
+        const bool moved = !prior_valid;
+        if (!prior_valid) {      // (nothing is pending here: the estimate only moves in update(), which writes the pending boxes out)
             if (k->x[6] + k->x[2] <= 0.f) k->x[6] = 0.f;
             kalman_predict(k->x, k->Pm, k->xp, k->Pp);
             has_prior = true;
@@ -397,12 +414,10 @@ struct Tracker {  // KalmanBoxTracker, tracker/mod.rs:15-69
             k->prior_box.has_timestamp = 1;
             prior_valid = true;
         }
-        covahip_bbox b = k->prior_box;
-        b.timestamp = ts;
         age += 1;
         time_since_update += 1;
-        history.push_back(b);
-        return history.back();
+        pending_ts.push_back(ts);
+        return moved;
     }
 
     bool update(const covahip_bbox *det) {  // tracker/mod.rs:71-102
@@ -419,6 +434,7 @@ struct Tracker {  // KalmanBoxTracker, tracker/mod.rs:15-69
             P xn[7];
             Mat7 Pn;
             if (!kalman_update(k->xp, k->Pp, z, xn, Pn)) return false;
+            flush();               // this frame's prediction becomes a box of its own (class and confidence below)
             std::memcpy(k->x, xn, sizeof(k->x));
             k->Pm = Pn;
             prior_valid = false;   // the estimate has moved
@@ -442,19 +458,36 @@ struct Tracker {  // KalmanBoxTracker, tracker/mod.rs:15-69
             if (start <= ts && last_match >= ts) return true;
         return false;
     }
-    void trim_dead_history() {  // tracker/mod.rs:144-151
-        const uint64_t drop_idx = (uint64_t)history.size() - time_since_update;
-        if (drop_idx < history.size()) history.resize((size_t)drop_idx);
+    void trim_dead_history() {  // tracker/mod.rs:144-151: the last time_since_update entries go (mostly pending ones)
+        if (time_since_update > hist_len()) return;   // (drop_idx wraps in the reference's u64 arithmetic: nothing is dropped)
+        size_t drop = (size_t)time_since_update;
+        const size_t from_pending = std::min(drop, pending_ts.size());
+        pending_ts.resize(pending_ts.size() - from_pending);
+        drop -= from_pending;
+        if (drop) { flush(); history.resize(history.size() - drop); }
     }
+};
+
+// What Sort keeps in its vector: a handle.  The retain of Sort::update closes the gaps the dead trackers leave -- at the
+// experiment's parameters two trackers die per frame near the front of ~130 -- and moving a tracker with its three vectors cost
+// 25 ns apiece; a handle is a pointer.
+struct Tracker {
+    std::unique_ptr<TrackerBody> b;
+    Tracker(uint64_t id, const covahip_bbox &box, uint64_t start) : b(new TrackerBody(id, box, start)) {}
+    TrackerBody *operator->() const { return b.get(); }
 };
 
 // Min-cost assignment of every row of an n x m matrix (n <= m) to a distinct column (shortest augmenting paths with
 // potentials, O(n^2 m)); a[i][j] row-major.  Returns col_of_row.
 std::vector<int> assign_rows(const std::vector<double> &a, int n, int m) {
     const double INF = std::numeric_limits<double>::infinity();
-    std::vector<double> u(n + 1, 0.0), v(m + 1, 0.0), minv(m + 1);
-    std::vector<int> p(m + 1, 0), way(m + 1, 0);
-    std::vector<char> used(m + 1);
+    // scratch kept per thread: the tracker calls this once per frame and stream, and six allocations were a fifth of its time
+    static thread_local std::vector<double> u, v, minv;
+    static thread_local std::vector<int> p, way;
+    static thread_local std::vector<char> used;
+    u.assign(n + 1, 0.0); v.assign(m + 1, 0.0); minv.resize(m + 1);
+    p.assign(m + 1, 0); way.assign(m + 1, 0);
+    used.resize(m + 1);
     for (int i = 1; i <= n; i++) {
         p[0] = i;
         int j0 = 0;
@@ -501,7 +534,8 @@ std::vector<std::pair<size_t, size_t>> linear_assignment(const std::vector<P> &c
     if (n_rows == 0 || n_cols == 0) return out;
     const bool by_rows = n_rows <= n_cols;           // the side that is assigned completely
     const size_t n = by_rows ? n_rows : n_cols, m = by_rows ? n_cols : n_rows;
-    std::vector<double> a(n * m);
+    static thread_local std::vector<double> a;
+    a.resize(n * m);
     for (size_t i = 0; i < n_rows; i++)
         for (size_t j = 0; j < n_cols; j++) {
             const P c = cost_colmajor[j * n_rows + i];
@@ -533,22 +567,17 @@ struct Sort {  // sort/src/lib.rs:14-23
     mutable std::vector<P> cost_, red_, px1_, py1_, px2_, py2_, pa_, pw_;
     mutable std::vector<uint8_t> ov_;
     mutable std::vector<size_t> keep_;
+    bool soa_stale = false;   // trackers were reordered or stepped outside update(): the next update() rewrites every array entry
 
-    std::vector<std::pair<size_t, size_t>> match_dets(const std::vector<covahip_bbox> &preds,
-                                                      const std::vector<covahip_bbox> &dets) const {
+    // the predictions are the trackers' prior boxes (Tracker::predict has run for every tracker of this frame)
+    std::vector<std::pair<size_t, size_t>> match_dets(const std::vector<covahip_bbox> &dets) const {
         std::vector<std::pair<size_t, size_t>> res;
-        const size_t np = preds.size(), nd = dets.size();
+        const size_t np = trackers.size(), nd = dets.size();
         if (np == 0 || nd == 0) return res;
         // the predictions as arrays: the IoU of every (detection, prediction) pair -- n_dets x ~130 per frame at the experiment's
         // parameters -- is then a loop the compiler vectorises; same expressions in the same order as bbox_iou (bbox.rs:39-56)
         cost_.resize(np * nd);  // column-major: rows = predictions, cols = detections
         ov_.assign(np, 0);
-        px1_.resize(np); py1_.resize(np); px2_.resize(np); py2_.resize(np); pa_.resize(np); pw_.resize(np);
-        for (size_t i = 0; i < np; i++) {
-            const covahip_bbox &t = preds[i];
-            px1_[i] = t.left; py1_[i] = t.top; px2_[i] = t.left + t.width; py2_[i] = t.top + t.height; pa_[i] = t.area;
-            pw_[i] = trackers[i].active ? 1.f : 2.f;  // lib.rs:108-113
-        }
         std::vector<P> &cost = cost_;
         for (size_t j = 0; j < nd; j++) {
             const covahip_bbox &d = dets[j];
@@ -557,8 +586,11 @@ struct Sort {  // sort/src/lib.rs:14-23
             P *c = cost.data() + j * np;
             uint8_t *ov = ov_.data();
             for (size_t i = 0; i < np; i++) {
-                const P x_left = std::fmax(dx1, x1[i]), y_top = std::fmax(dy1, y1[i]);
-                const P x_right = std::fmin(dx2, x2[i]), y_bottom = std::fmin(dy2, y2[i]);
+                // fmax / fmin of bbox_iou written as selects (one maxps / minps each): the same value whenever the detection's side
+                // is a number, which it always is -- a NaN can only come from a diverged tracker, and then both forms return the
+                // detection's coordinate
+                const P x_left = x1[i] > dx1 ? x1[i] : dx1, y_top = y1[i] > dy1 ? y1[i] : dy1;
+                const P x_right = x2[i] < dx2 ? x2[i] : dx2, y_bottom = y2[i] < dy2 ? y2[i] : dy2;
                 const bool none = x_right <= x_left || y_bottom <= y_top;
                 const P inter = (x_right - x_left) * (y_bottom - y_top);
                 const P uni = da + pa[i] - inter;
@@ -577,7 +609,7 @@ struct Sort {  // sort/src/lib.rs:14-23
         keep.clear();
         size_t idle[2] = {0, 0};
         for (size_t i = 0; i < np; i++)
-            if (ov_[i] || idle[trackers[i].active ? 0 : 1]++ < nd) keep.push_back(i);
+            if (ov_[i] || idle[trackers[i]->active ? 0 : 1]++ < nd) keep.push_back(i);
         if (keep.size() < np) {
             const size_t nk = keep.size();
             red_.resize(nk * nd);
@@ -585,13 +617,13 @@ struct Sort {  // sort/src/lib.rs:14-23
                 for (size_t k = 0; k < nk; k++) red_[j * nk + k] = cost[j * np + keep[k]];
             for (auto &e : linear_assignment(red_, nk, nd)) {
                 const size_t i = keep[e.first];
-                const P thr = trackers[i].active ? (1.f - iou_threshold) : (2.f - iou_threshold);
+                const P thr = trackers[i]->active ? (1.f - iou_threshold) : (2.f - iou_threshold);
                 if (cost[e.second * np + i] <= thr) res.emplace_back(i, e.second);
             }
             return res;
         }
         for (auto &e : linear_assignment(cost, np, nd)) {
-            const P thr = trackers[e.first].active ? (1.f - iou_threshold) : (2.f - iou_threshold);
+            const P thr = trackers[e.first]->active ? (1.f - iou_threshold) : (2.f - iou_threshold);
             if (cost[e.second * np + e.first] <= thr) res.push_back(e);
         }
         return res;
@@ -601,10 +633,20 @@ struct Sort {  // sort/src/lib.rs:14-23
     bool update(std::vector<covahip_bbox> dets, uint64_t pts, std::vector<Tracker> &dead) {
         frame_count += 1;
         const size_t n_dets = dets.size();
-        std::vector<covahip_bbox> preds;
-        preds.reserve(trackers.size());
-        for (auto &t : trackers) preds.push_back(t.predict(pts));
-        auto matches = match_dets(preds, dets);
+        // the arrays match_dets reads (prediction i = prior box of tracker i) follow the trackers: an entry is rewritten when its
+        // tracker's prior moves (predict() says so), the retain below compacts them with the trackers
+        const size_t nt = trackers.size();
+        px1_.resize(nt); py1_.resize(nt); px2_.resize(nt); py2_.resize(nt); pa_.resize(nt); pw_.resize(nt);
+        for (size_t i = 0; i < nt; i++) {
+            Tracker &t = trackers[i];
+            if (t->predict(pts) || soa_stale) {
+                const covahip_bbox &b = t->k->prior_box;
+                px1_[i] = b.left; py1_[i] = b.top; px2_[i] = b.left + b.width; py2_[i] = b.top + b.height; pa_[i] = b.area;
+            }
+            pw_[i] = t->active ? 1.f : 2.f;  // lib.rs:108-113
+        }
+        soa_stale = false;
+        auto matches = match_dets(dets);
         // (a tracker / detection appears in at most one pair; the first pair of a tracker wins, as in the reference's `find`)
         match_of_trk.assign(trackers.size(), -1);
         det_matched.assign(n_dets, 0);
@@ -623,20 +665,23 @@ struct Sort {  // sort/src/lib.rs:14-23
                 d.timestamp = pts;
                 det = &d;
             }
-            if (!trackers[i].update(det)) return false;
+            if (!trackers[i]->update(det)) return false;
         }
-        for (auto &t : trackers) t.check_activate(min_hits);
+        for (auto &t : trackers) t->check_activate(min_hits);
         // retain (lib.rs:166-177) in place: nothing moves in the usual frame in which no tracker dies
         size_t w = 0;
         for (size_t i = 0; i < trackers.size(); i++) {
             Tracker &t = trackers[i];
-            if (!t.should_live(max_age)) {
-                if (t.active) {
-                    t.trim_dead_history();
+            if (!t->should_live(max_age)) {
+                if (t->active) {
+                    t->trim_dead_history();
                     dead.push_back(std::move(t));
                 }
             } else {
-                if (w != i) trackers[w] = std::move(t);
+                if (w != i) {
+                    trackers[w] = std::move(t);
+                    px1_[w] = px1_[i]; py1_[w] = py1_[i]; px2_[w] = px2_[i]; py2_[w] = py2_[i]; pa_[w] = pa_[i];
+                }
                 w++;
             }
         }
@@ -651,18 +696,19 @@ struct Sort {  // sort/src/lib.rs:14-23
     std::vector<Tracker> finalize() {  // lib.rs:207-213
         std::vector<Tracker> out, keep;
         for (auto &t : trackers) {
-            if (t.active) {
-                if (t.history.size() > (size_t)min_hits) out.push_back(std::move(t));
+            if (t->active) {
+                if (t->hist_len() > (size_t)min_hits) out.push_back(std::move(t));
             } else {
                 keep.push_back(std::move(t));
             }
         }
         trackers.swap(keep);
+        soa_stale = true;
         return out;
     }
 
     void mark_seen(uint64_t ts) {
-        for (auto &t : trackers) t.seen_ts.push_back(ts);
+        for (auto &t : trackers) t->seen_ts.push_back(ts);
     }
 };
 
@@ -672,10 +718,10 @@ int emit_tracks(const std::vector<Tracker> &tracks, covahip_bbox *boxes, size_t 
     bool overflow = false;
     for (size_t k = 0; k < tracks.size(); k++) {
         if (track_lens) {
-            if (k < cap_tracks) track_lens[k] = (uint32_t)tracks[k].history.size();
+            if (k < cap_tracks) track_lens[k] = (uint32_t)tracks[k]->hist_len();
             else overflow = true;
         }
-        for (const auto &b : tracks[k].history) {
+        for (const auto &b : tracks[k]->hist()) {
             if (boxes) {
                 if (nb < cap) boxes[nb] = b;
                 else overflow = true;
@@ -783,24 +829,26 @@ int covahip_sort_tracker_info(const covahip_sort *s, size_t i, uint64_t *id, int
                               uint64_t *hit_streaks, uint64_t *time_since_update, covahip_bbox *state) {
     if (!s || i >= s->s.trackers.size()) return COVAHIP_ERR_INVALID_ARG;
     const Tracker &t = s->s.trackers[i];
-    if (id) *id = t.id;
-    if (active) *active = t.active ? 1 : 0;
-    if (hit_streaks) *hit_streaks = t.hit_streaks;
-    if (time_since_update) *time_since_update = t.time_since_update;
-    if (state) *state = from_x(t.k->x);  // get_state(): box of the current estimate
+    if (id) *id = t->id;
+    if (active) *active = t->active ? 1 : 0;
+    if (hit_streaks) *hit_streaks = t->hit_streaks;
+    if (time_since_update) *time_since_update = t->time_since_update;
+    if (state) *state = from_x(t->k->x);  // get_state(): box of the current estimate
     return COVAHIP_OK;
 }
 
 int covahip_sort_tracker_predict(covahip_sort *s, size_t i, uint64_t ts, covahip_bbox *last) {
     if (!s || i >= s->s.trackers.size()) return COVAHIP_ERR_INVALID_ARG;
-    const covahip_bbox &b = s->s.trackers[i].predict(ts);
-    if (last) *last = b;
+    s->s.trackers[i]->predict(ts);
+    s->s.soa_stale = true;
+    if (last) *last = s->s.trackers[i]->hist().back();
     return COVAHIP_OK;
 }
 
 int covahip_sort_tracker_update(covahip_sort *s, size_t i, const covahip_bbox *det) {
     if (!s || i >= s->s.trackers.size()) return COVAHIP_ERR_INVALID_ARG;
-    return s->s.trackers[i].update(det) ? COVAHIP_OK : COVAHIP_ERR_BAD_DATA;
+    s->s.soa_stale = true;
+    return s->s.trackers[i]->update(det) ? COVAHIP_OK : COVAHIP_ERR_BAD_DATA;
 }
 
 size_t covahip_linear_assignment(const float *cost_colmajor, size_t n_rows, size_t n_cols, uint32_t *pairs,
@@ -873,19 +921,20 @@ struct OutSink {
 // frames already in its buffer for every further track of the same call -- not reproduced.)
 uint64_t oldest_start(const covahip_gopfilter *g) {   // get_oldest_timestamp (cova/tracker.rs:85-90)
     uint64_t oldest = UINT64_MAX;
-    for (const Tracker &t : g->sort->trackers) oldest = std::min(oldest, t.start);
+    for (const Tracker &t : g->sort->trackers) oldest = std::min(oldest, t->start);
     return oldest;
 }
 void export_tracks(covahip_gopfilter *g, const std::vector<Tracker> &tracks, uint64_t oldest) {
     if (tracks.empty()) return;
     for (const Tracker &t : tracks) {
-        const size_t fl = covahip_frame_serialize(g->range_start, oldest, t.history.data(), t.history.size(), nullptr, 0, nullptr);
+        const std::vector<covahip_bbox> &h = t->hist();
+        const size_t fl = covahip_frame_serialize(g->range_start, oldest, h.data(), h.size(), nullptr, 0, nullptr);
         const size_t at = g->track_wire.size();
         g->track_wire.resize(at + 4 + fl);
         uint8_t *o = g->track_wire.data() + at;
         o[0] = (uint8_t)(fl >> 24); o[1] = (uint8_t)(fl >> 16); o[2] = (uint8_t)(fl >> 8); o[3] = (uint8_t)fl;
         int st = 0;
-        covahip_frame_serialize(g->range_start, oldest, t.history.data(), t.history.size(), o + 4, fl, &st);
+        covahip_frame_serialize(g->range_start, oldest, h.data(), h.size(), o + 4, fl, &st);
     }
 }
 
@@ -950,11 +999,11 @@ int covahip_gopfilter_push_boxes(covahip_gopfilter *g, const covahip_bbox *boxes
     }
     std::vector<Tracker> dead;
     if (!g->sort->update(std::vector<covahip_bbox>(boxes, boxes + n), pts, dead)) return COVAHIP_ERR_BAD_DATA;
-    export_tracks(g, dead, oldest_start(g));   // after the update, over the trackers that are left (tracker.rs:51-58)
+    if (!dead.empty()) export_tracks(g, dead, oldest_start(g));   // after the update, over the trackers that are left (tracker.rs:51-58)
     bool have_min = !dead.empty();
     uint64_t min_track_pts = 0;
     for (const Tracker &t : dead)
-        if (!t.is_seen()) min_track_pts = std::max(min_track_pts, t.start);
+        if (!t->is_seen()) min_track_pts = std::max(min_track_pts, t->start);
 
     const uint64_t clk30 = SECOND / 30;
     const uint64_t maxage_pts = clk30 * ((uint64_t)g->cfg.sort_maxage + 10);  // SAFETY_BUFFER = 10

@@ -15,6 +15,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#define __USE_GNU
+#include <sys/resource.h>
+#include <unistd.h>
 
 typedef struct { uint8_t kind; uint64_t pts; uint32_t flags, len; uint8_t *data; } rec_t;
 
@@ -249,6 +252,7 @@ static int run_mux(const char *desc, int n_pads, const char *caps, const char *i
 
 /* ---- muxbench: blobnetfilter fed by one thread per stream with in-memory carrier frames; prints frames/s ---- */
 typedef struct { GstPad *src; GstBuffer **bufs; int n_bufs, n_frames, first, eos; } bench_feed_t;
+static volatile gint feeder_cpu_us;   /* CPU time of the feeder threads that have finished (getrusage) */
 static gpointer bench_feeder(gpointer data) {
     bench_feed_t *f = data;
     gint64 tp = 0;
@@ -261,6 +265,11 @@ static gpointer bench_feeder(gpointer data) {
         if (fr != GST_FLOW_OK) break;
     }
     if (getenv("FEED_TIMING")) fprintf(stderr, "feeder: %d frames, %lld us inside gst_pad_push\n", f->n_frames, (long long)tp);
+    {
+        struct rusage ru;
+        if (!getrusage(RUSAGE_THREAD, &ru))
+            g_atomic_int_add(&feeder_cpu_us, (gint)((ru.ru_utime.tv_sec + ru.ru_stime.tv_sec) * 1000000 + ru.ru_utime.tv_usec + ru.ru_stime.tv_usec));
+    }
     if (f->eos) gst_pad_push_event(f->src, gst_event_new_eos());
     return NULL;
 }
@@ -355,6 +364,37 @@ static int run_muxbench(const char *desc, int n_pads, int w_px, int h_px, int fr
     return 0;
 }
 
+/* CPU seconds per thread name of this process (/proc/self/task): where the host time of a bench run went */
+#include <dirent.h>
+static void print_thread_cpu(const char *tag) {
+    DIR *d = opendir("/proc/self/task");
+    struct { char name[32]; double sec; int n; } acc[32];
+    int na = 0;
+    struct dirent *de;
+    const double tick = 1.0 / (double)sysconf(_SC_CLK_TCK);
+    if (!d) return;
+    while ((de = readdir(d))) {
+        char path[128], comm[64] = "?", buf[1024];
+        FILE *f;
+        unsigned long ut = 0, st = 0;
+        if (de->d_name[0] == '.') continue;
+        snprintf(path, sizeof path, "/proc/self/task/%s/comm", de->d_name);
+        if ((f = fopen(path, "r"))) { if (fgets(comm, sizeof comm, f)) comm[strcspn(comm, "\n")] = 0; fclose(f); }
+        snprintf(path, sizeof path, "/proc/self/task/%s/stat", de->d_name);
+        if ((f = fopen(path, "r"))) {
+            if (fgets(buf, sizeof buf, f)) { char *q = strrchr(buf, ')'); if (q) sscanf(q + 2, "%*c %*d %*d %*d %*d %*d %*u %*u %*u %*u %*u %lu %lu", &ut, &st); }
+            fclose(f);
+        }
+        int k = 0;
+        for (; k < na; k++) if (!strcmp(acc[k].name, comm)) break;
+        if (k == na && na < 32) { snprintf(acc[na].name, sizeof acc[na].name, "%s", comm); acc[na].sec = 0; acc[na].n = 0; na++; }
+        if (k < 32) { acc[k].sec += (ut + st) * tick; acc[k].n++; }
+    }
+    closedir(d);
+    fprintf(stderr, "cpu seconds by thread name (%s):", tag);
+    for (int k = 0; k < na; k++) fprintf(stderr, " %s x%d %.2f;", acc[k].name, acc[k].n, acc[k].sec);
+    fprintf(stderr, "\n");
+}
 /* ---- chainbench: BASELINE config 4 as a throughput number.  N streams -> blobnetfilter (metapreprocess + nvstreammux + nvinfer +
  * nvstreamdemux + maskcopy + bboxcc stand-in) -> per stream a `cova` element (embedded SORT + GoP frame filter) whose sink_enc gets
  * the stream's encoded access units (dummy payloads; key frame every 250) -> counting sink.  pipeline/cova/pipeline.py:104-261.
@@ -490,6 +530,10 @@ static int run_chainbench(const char *desc, const char *cova_props, int n_pads, 
         if (phase) t1 = g_get_monotonic_time(); else g_usleep(300000);
     }
     g_usleep(200000);   /* the last batches drain through the pusher threads */
+    if (getenv("CHAINBENCH_CPU")) {
+        print_thread_cpu("live threads at the end");
+        fprintf(stderr, "cpu seconds of the carrier-frame feeders (both phases): %.2f; wall seconds of the timed phase %.3f\n", feeder_cpu_us * 1e-6, (t1 - t0) * 1e-6);
+    }
     g_object_get(e, "batches", &batches, NULL);
     {
         guint64 fwd = 0, d = 0, dd = 0, di = 0;
