@@ -64,5 +64,8 @@ int main(int argc, char **argv) {
     const double s = (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9;
     printf("%d frames, %.2f boxes per frame, %ld access units forwarded: %.2f us per frame (%.0f frames/s on one thread)\n", frames,
            (double)boxes / frames, outs, s / frames * 1e6, frames / s);
+    covahip_gopfilter_free(g);
+    free(bb);
+    free(out);
     return 0;
 }
