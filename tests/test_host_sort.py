@@ -159,6 +159,32 @@ def test_sequence_matches_numpy_restatement(params):
     assert n_dead_total + len(rfin) >= 1
 
 
+def test_updates_after_finalize_match_numpy_restatement():
+    """finalize() (lib.rs:207-213) takes the active trackers out and keeps the others: the updates that follow run on the
+    reordered set (the port keeps its prediction arrays in tracker order and histories partly unwritten -- both must survive it)."""
+    max_age, min_hits, iou = 10, 5, 0.1
+    frames = _scripted_sequence(120, seed=4)
+    s = E._SortHandle(max_age, min_hits, iou)
+    r = R.Sort(max_age, min_hits, iou)
+    for i, dets in enumerate(frames):
+        pts = i * 33_333_333
+        dead, lens = s.update(_bb(dets), pts)
+        rdead = r.update([R.Bbox(*d) for d in dets], pts)
+        assert [len(t.history) for t in rdead] == list(lens)
+        assert s.num_trackers() == len(r.trackers)
+        if i in (50, 51, 90):
+            fin, flens = s.finalize()
+            rfin = r.finalize()
+            assert [len(t.history) for t in rfin] == list(flens)
+            flat = [b for t in rfin for b in t.history]
+            assert [(g["track_id"], g["timestamp"]) for g in fin] == [(e.track_id, e.timestamp) for e in flat]
+            assert s.num_trackers() == len(r.trackers)
+        for j, t in enumerate(r.trackers):
+            info = s.tracker_info(j)
+            assert (info["id"], info["active"], info["hit_streaks"], info["time_since_update"]) == \
+                (t.id, t.active, t.hit_streaks, t.time_since_update)
+
+
 def test_young_track_ages_while_matched_quirk():
     """tracker/mod.rs:77-80: time_since_update only resets once hit_streaks >= 5."""
     s = E._SortHandle(30, 3, 0.1)
