@@ -271,9 +271,71 @@ def cpu_tracking_baseline(frames_per_stream=600):
 
 
 # ------------------------------------------------------------------------------------------------ extra legs (rank 0)
-def timed_steps(ctx, fn, steps, warmup=5):
-    for _ in range(warmup):
+def board_power_file():
+    """sysfs power sensor (microwatts) and cap of THIS process's GPU: hipDeviceGetPCIBusId(0) -> /sys/bus/pci/devices/<id>/hwmon."""
+    import ctypes
+    import glob
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, 0) != 0:
+            return None, None
+        base = "/sys/bus/pci/devices/" + buf.value.decode().lower() + "/hwmon/hwmon*/"
+        f = (glob.glob(base + "power1_input") or glob.glob(base + "power1_average") or [None])[0]
+        cap = (glob.glob(base + "power1_cap") or [None])[0]
+        return f, (int(open(cap).read()) / 1e6 if cap else None)
+    except (OSError, ValueError):
+        return None, None
+
+
+def board_power_under(ctx, step, seconds=2.0, settle=0.8):
+    """Mean / max board power (W) while `step` loops for `seconds` (samples of the first `settle` seconds dropped), and the
+    step time of that loop.  None when the sensor is not readable."""
+    import threading
+    path, cap = board_power_file()
+    if not path:
+        return None
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                samples.append((time.perf_counter(), int(open(path).read()) / 1e6))
+            except (OSError, ValueError):
+                pass
+            time.sleep(0.01)
+    th = threading.Thread(target=sampler, daemon=True)
+    ctx.sync()
+    t0 = time.perf_counter()
+    th.start()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(64):
+            step()
+        n += 64
+        ctx.sync()
+    t1 = time.perf_counter()
+    stop.set()
+    th.join()
+    w = [p for (t, p) in samples if t - t0 >= settle]
+    if not w:
+        return None
+    ms = (t1 - t0) / n * 1e3
+    return {"mean_w": round(sum(w) / len(w), 1), "max_w": round(max(w), 1), "cap_w": cap, "samples": len(w),
+            "ms_per_step_in_this_loop": round(ms, 4), "mj_per_step": round(sum(w) / len(w) * ms, 1)}
+
+
+
+def timed_steps(ctx, fn, steps, warmup=5, warm_s=0.15):
+    """ms per call of `fn` over `steps` calls, after `warmup` calls and at least `warm_s` seconds of them (the clocks of an idle
+    chip take that long to come up: 50 steps right after start-up measured a step on its own 12 % slow)."""
+    t_w = time.perf_counter()
+    n = 0
+    while n < warmup or time.perf_counter() - t_w < warm_s:
         fn()
+        n += 1
+        if n % 32 == 0:
+            ctx.sync()
     ctx.sync()
     ctx.timer_start(2)
     for _ in range(steps):
@@ -569,7 +631,6 @@ def main():
     per_kernel_us = {k: t / n * 1e3 for k, (t, n) in prof.items()}
     blob_kernels = {k: v for k, v in per_kernel_us.items() if k not in ("bboxcc_kernel", "bboxcc_wave_kernel", "dec3_bboxcc_fused")}
     dominant = max(blob_kernels, key=blob_kernels.get)
-    serial_ms = timed_steps(ctx, step, max(20, args.steps // 4), 5)
 
     # ---- warm-up with the lanes of the timed region: --warmup steps and at least --min-warmup-s of them (clocks and caches settle)
     ctx.set_lanes(NL)
@@ -613,6 +674,36 @@ def main():
         step()
     barrier()
     elapsed_cached = grp.max(time.perf_counter() - t0)
+    # ---- one lane: a step on its own, measured like the timed region (warm clocks, alternating batches, median of five
+    # barrier-to-barrier regions of K steps) -- rounds 1-3 timed 50 steps right after start-up, before the clocks had settled
+    ctx.set_lanes(1)
+    alternate[0] = True
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < args.min_warmup_s:
+        for _ in range(32):
+            step()
+        ctx.sync()
+    regions1 = []
+    for _ in range(5):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        regions1.append(grp.max(time.perf_counter() - t0))
+    serial_ms = sorted(regions1)[len(regions1) // 2] / args.steps * 1e3
+    # per-kernel times of a step on its own, warm (the pass before the timed region only picked the dominant kernel)
+    ctx.profile(True)
+    for _ in range(20):
+        step()
+    ctx.sync()
+    per_kernel_us = {k: t / n * 1e3 for k, (t, n) in ctx.profile_read().items()}
+    ctx.profile(False)
+    alternate[0] = False
+    ctx.set_lanes(NL)
+    for _ in range(2 * NL):
+        step()
+    barrier()
     # (the legs and cross-checks below stay on the first batch)
     # shader clock under this load: a probe wave beside 60 more steps (untimed)
     for _ in range(60):
@@ -664,6 +755,16 @@ def main():
             "frames_per_s": round(B / msn * 1e3, 1), "ms_per_step": round(msn, 4), "ms_per_step_one_lane": round(ms1, 4),
             "carrier_frames_per_step": int(frames.shape[0]), "carrier_input_bytes_per_step": int(frames.nbytes),
             "stacked_input_bytes_per_step": int(stack.nbytes)}
+        # board power while the timed workload loops ("The roof over the step is the board's power"): with NL lanes
+        # the board sits at or near its cap, and power x step time is the same with one lane
+        ctx.set_lanes(NL)
+        pw_n = board_power_under(ctx, step)
+        ctx.set_lanes(1)
+        pw_1 = board_power_under(ctx, step)
+        if pw_n and pw_1:
+            rank0["board_power"] = {f"{NL}_lanes": pw_n, "one_lane": pw_1,
+                                    "note": "hwmon power sensor of this GPU sampled every 10 ms over a 2 s loop of the timed step "
+                                            "(untimed leg; the first 0.8 s dropped)"}
         # PCIe-inclusive rates (never `value`)
         net.filter(stack, CC_THRESHOLD, max_boxes=MAX_BOXES)        # warm the staging buffers
         t1 = time.perf_counter()
@@ -741,7 +842,7 @@ def main():
                          "one_lane": {"avg_launch_us": round(serial_dom_s * 1e6, 2),
                                       "achieved": round(dom_flop / serial_dom_s / 1e12, 2),
                                       "frac": round(dom_flop / serial_dom_s / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                                      "measured": "HIP events, the launch alone on the chip (per-kernel pass before the timed region)"},
+                                      "measured": "HIP events, the launch alone on the chip (per-kernel pass of 20 one-lane steps after the timed regions, warm)"},
                          "hbm_view": {"algorithmic_bytes_per_launch": dom_bytes,
                                       "achieved_GBs": round(dom_bytes / dom_s / 1e9, 1),
                                       "frac_of_8TBs": round(dom_bytes / dom_s / 1e9 / HBM_PEAK_GBS, 4)},
