@@ -47,7 +47,7 @@ AU_OUT_DTYPE = np.dtype([("id", "<u8"), ("pts", "<u8"), ("flags", "<u4"), ("list
 
 H264_INFO_DTYPE = np.dtype([(n, "<i4") for n in ("width_mbs", "height_mbs", "n_samples", "profile_idc", "level_idc", "entropy_cabac",
                                                 "transform_8x8", "num_ref_frames", "frame_mbs_only", "weighted_pred",
-                                                "weighted_bipred", "poc_type")])
+                                                "weighted_bipred", "poc_type", "max_num_reorder_frames", "max_dec_frame_buffering")])
 H264_SLICE_DTYPE = np.dtype([("nal_offset", "<u8"), ("nal_bytes", "<u4"), ("data_bit_offset", "<u4")] +
                             [(n, "<i4") for n in ("nal_type", "slice_type", "first_mb", "frame_num", "idr", "poc_lsb", "qp",
                                                   "cabac_init_idc", "num_ref_l0", "num_ref_l1", "direct_spatial", "nal_ref_idc", "has_mmco5")] + [("_pad", "<u4")])

@@ -78,6 +78,7 @@ struct Sps {
     int profile = 0, level = 0, chroma_format = 1, log2_max_frame_num = 4, poc_type = 0, log2_max_poc_lsb = 4;
     int delta_pic_order_always_zero = 0, num_ref_frames = 0, width_mbs = 0, height_map_units = 0, frame_mbs_only = 1, mbaff = 0;
     int direct_8x8 = 0, bit_depth = 8;
+    int max_num_reorder = -1, max_dec_frame_buffering = -1;   // VUI bitstream_restriction (E.1.1); -1: the stream does not say
     bool ok = false;
 };
 struct Pps {
@@ -118,7 +119,39 @@ bool parse_sps(const std::vector<uint8_t> &rbsp, Sps &s) {
     s.direct_8x8 = (int)r.u(1);
     s.ok = !r.bad && s.log2_max_frame_num <= 16 && s.log2_max_poc_lsb <= 16 && s.width_mbs <= 1024 && s.height_map_units <= 1024 &&
            s.chroma_format <= 3 && s.num_ref_frames <= 16;
-    return s.ok;
+    if (!s.ok) return false;
+    // frame cropping, then the VUI as far as bitstream_restriction (E.1.1): max_num_reorder_frames is how many pictures a decoder
+    // has to hold back before the first one may leave in output order (h264entropydec's queue).  A VUI that does not parse
+    // leaves the two fields unknown; the parameters above stand.
+    if (r.u(1)) { r.ue(); r.ue(); r.ue(); r.ue(); }
+    if (r.u(1) && !r.bad) {
+        auto hrd = [&]() {
+            const uint32_t cnt = r.ue() + 1;
+            r.u(8);
+            for (uint32_t i = 0; i < cnt && i < 32 && !r.bad; i++) { r.ue(); r.ue(); r.u(1); }
+            r.u(20);
+        };
+        if (r.u(1)) { if (r.u(8) == 255) { r.u(16); r.u(16); } }   // aspect ratio
+        if (r.u(1)) r.u(1);                                          // overscan
+        if (r.u(1)) { r.u(4); if (r.u(1)) r.u(24); }                 // video signal type (+ colour description)
+        if (r.u(1)) { r.ue(); r.ue(); }                              // chroma sample location
+        if (r.u(1)) { r.u(32); r.u(32); r.u(1); }                    // timing
+        const uint32_t nal_hrd = r.u(1);
+        if (nal_hrd) hrd();
+        const uint32_t vcl_hrd = r.u(1);
+        if (vcl_hrd) hrd();
+        if (nal_hrd || vcl_hrd) r.u(1);
+        r.u(1);                                                      // pic_struct_present_flag
+        if (r.u(1)) {
+            r.u(1); r.ue(); r.ue(); r.ue(); r.ue();
+            const uint32_t reorder = r.ue(), buffering = r.ue();
+            if (!r.bad && reorder <= 16 && buffering <= 16 && reorder <= buffering) {
+                s.max_num_reorder = (int)reorder;
+                s.max_dec_frame_buffering = (int)buffering;
+            }
+        }
+    }
+    return true;
 }
 
 bool parse_pps(const std::vector<uint8_t> &rbsp, Pps &p) {
@@ -817,6 +850,8 @@ int covahip_h264_get_info(const covahip_h264 *h, covahip_h264_info *info) {
     info->weighted_pred = h->pps.weighted_pred;
     info->weighted_bipred = h->pps.weighted_bipred;
     info->poc_type = h->sps.poc_type;
+    info->max_num_reorder_frames = h->sps.max_num_reorder;
+    info->max_dec_frame_buffering = h->sps.max_dec_frame_buffering;
     return COVAHIP_OK;
 }
 

@@ -7,7 +7,7 @@
  *
  *   sink: video/x-h264, stream-format=avc, alignment=au (codec_data = avcC), access units in decode order
  *   src:  video/x-raw, format=I420, width = 16 * width_mbs, height = 16 * height_mbs, frames in OUTPUT order: a picture waits in a
- *         reorder queue until num_ref_frames + 1 later pictures have arrived (or an IDR picture / EOS comes), then the one with
+ *         reorder queue until max_num_reorder_frames (VUI; num_ref_frames + 1 without one) later pictures have arrived (or an IDR picture / EOS comes), then the one with
  *         the smallest picture order count leaves; every frame keeps the timestamps of its access unit
  *   property max-threads: accepted for launch-line compatibility with avdec_h264, ignored (one streaming thread per element,
  *         as the reference configures it)
@@ -27,7 +27,7 @@ typedef struct {
     covahip_h264 *h;
     covahip_h264_info info;
     gsize rec_bytes, frame_bytes;
-    GArray *held;          /* EdHeld, unsorted; at most num_ref_frames + 1 entries */
+    GArray *held;          /* EdHeld, unsorted; at most max_num_reorder_frames (or num_ref_frames + 1) + 1 entries */
     guint max_threads;
     gint fps_n, fps_d;
 } GstEntropyDec;
@@ -41,7 +41,10 @@ static GstStaticPadTemplate ed_src_t = GST_STATIC_PAD_TEMPLATE("src", GST_PAD_SR
 
 static GstFlowReturn ed_pop(GstEntropyDec *s, gboolean all) {
     GstFlowReturn ret = GST_FLOW_OK;
-    while (s->held->len > (all ? 0u : (guint)s->info.num_ref_frames + 1u) && ret == GST_FLOW_OK) {
+    /* how many pictures stay behind: max_num_reorder_frames when the stream's VUI says (E.2.1: no picture is preceded in decoding
+     * order and followed in output order by more than that many), num_ref_frames + 1 otherwise */
+    const guint depth = s->info.max_num_reorder_frames >= 0 ? (guint)s->info.max_num_reorder_frames : (guint)s->info.num_ref_frames + 1u;
+    while (s->held->len > (all ? 0u : depth) && ret == GST_FLOW_OK) {
         guint best = 0;
         for (guint i = 1; i < s->held->len; i++)
             if (g_array_index(s->held, EdHeld, i).key < g_array_index(s->held, EdHeld, best).key) best = i;

@@ -288,6 +288,7 @@ typedef struct covahip_h264_info {
     int32_t width_mbs, height_mbs, n_samples;
     int32_t profile_idc, level_idc, entropy_cabac, transform_8x8, num_ref_frames, frame_mbs_only;
     int32_t weighted_pred, weighted_bipred, poc_type;
+    int32_t max_num_reorder_frames, max_dec_frame_buffering;   /* VUI bitstream_restriction (E.1.1); -1 when the stream does not say */
 } covahip_h264_info;
 typedef struct covahip_h264_slice {
     uint64_t nal_offset;       /* file offset of the NAL unit (its header byte) */

@@ -35,6 +35,8 @@ def test_stream_parameters(demo):
     assert (i["profile_idc"], i["level_idc"]) == (100, 31)                           # High@3.1
     assert i["entropy_cabac"] == 1 and i["transform_8x8"] == 1 and i["frame_mbs_only"] == 1
     assert i["num_ref_frames"] == 5 and i["poc_type"] == 0
+    # VUI bitstream_restriction: what x264 writes for 3 B frames with a B pyramid and 5 reference frames
+    assert (i["max_num_reorder_frames"], i["max_dec_frame_buffering"]) == (2, 5)
 
 
 def test_every_access_unit_has_one_slice_and_key_frames_every_250(demo):
@@ -145,6 +147,22 @@ def test_output_order_from_picture_order_counts_is_the_containers_composition_or
     np.testing.assert_array_equal(order, np.argsort(cts, kind="stable"))
     assert (order[:1] == [0]).all() and (np.abs(order - np.arange(1802)) <= 8).all()      # reordering stays within a few frames
     assert not (order == np.arange(1802)).all()                                          # and there is some (B pictures)
+
+
+def test_no_picture_is_overtaken_by_more_than_max_num_reorder_frames(demo):
+    """E.2.1: max_num_reorder_frames bounds how many pictures can precede a picture in decoding order and follow it in output
+    order -- the depth of h264entropydec's queue.  The order computed from the picture order counts must respect what the
+    stream's own VUI promises (2), and reach it."""
+    lib, h, _ = demo
+    order = np.zeros(1802, dtype=np.int32)
+    n = C.c_int()
+    assert lib.covahip_h264_display_order(h, order.ctypes.data, order.size, C.byref(n)) == 0 and n.value == 1802
+    pos = np.empty(1802, dtype=np.int64)
+    pos[order] = np.arange(1802)                      # output position of the access unit decoded i-th
+    worst = 0
+    for i in range(1802):
+        worst = max(worst, int((pos[max(0, i - 16):i] > pos[i]).sum()))
+    assert worst == 2
 
 
 def test_colocated_picture_of_every_b_picture_is_the_nearest_following_reference(demo):
