@@ -1222,6 +1222,299 @@ __global__ __launch_bounds__(512, 4) void enc1_mfma(Enc1Args p) {
     WGSPAN_END(0);
 }
 
+// ------------------------------------------------------------------ enc levels 2 + 3 in one launch (round 5)
+// One eight-wave workgroup takes a frame through level 2 AND level 3.  A frame's level-2 output (4 x 9 x 15 x 64 fp16 at
+// 1080p, 69 KB) IS level 3's input band, so it is written -- after level 2's temporal MLP -- straight into that band in LDS,
+// with the band's swizzle, and never crosses the fabric; only its T = 0 slice leaves for HBM (the decoder's skip input,
+// blobnet.py:32).  Against the two launches (enc_mfma<32,64,..,E2_TSZ> + enc_mfma<64,128,..,E3_TSZ>):
+//   * level 2's input streams through a RING of six input rows per T slice (48 KB): the step of window row s computes on
+//     rows 2s-1 .. 2s+2 while the LDS-DMA of rows 2s+3, 2s+4 lands in the two slots step s-1 has left -- the request +
+//     landing of a band (2.5 - 3.7 us per item in the two-launch form, serial in front of its tiles) is off the critical path;
+//   * a window row of level 2 is two tile columns x two N tiles = four 32x32 tiles for eight waves, so a wave takes a tile
+//     and HALF of its T slices (T-half th = wave >> 2: 36 products instead of 72, 32 accumulator registers), the two waves
+//     of a tile swap their pooled values through LDS (8 bytes per lane each way) and each runs the temporal MLP for half of
+//     the tile's windows: every wave has work in every step, one frame per CU, no second round of items;
+//   * level 3 starts on a band that is already in LDS (the two-launch form: 3 us of landing per frame), its weights are
+//     requested while the T = 0 slice of level 2 is copied out.
+// Same products in the same order per accumulator, same pooling / rounding / MLP expressions: bit-identical to the two
+// launches (tests/test_gpu_blobnet.py).  Reference semantics: encoder.py:58-80, pointwise.py:16-26.
+constexpr int E23_RP2 = 2048;                     // ring row pitch per T slice: 32 pixels x 64 B
+constexpr int E23_NSLOT = 6;                      // ring rows per T slice
+constexpr int E23_TSZ2 = E23_NSLOT * E23_RP2;     // bytes per T slice of the ring
+struct Enc23Args {
+    const __half *in;    // act[2] [B][T][H2][W2][32]
+    __half *mid;         // act[3] [B][T][H3][W3][64]: only T = 0 is written (decoder skip)
+    __half *out;         // act[4] [B][1][H4][W4][128]
+    const half8 *wf2, *wf3;
+    const float *epi2, *epi3;
+    int B;
+    int H2, W2, Hp2, Wp2;
+    int H3, W3, Hp3, Wp3, oy3, ox3;   // level 3's input = level 2's pooled output at offset (oy3, ox3) = (H2 & 1, W2 & 1)
+    int H4, W4, oy4, ox4;
+    Swz swz2, swz3;      // periodic swizzles of the ring and of level 3's band (choose_swz_periodic)
+    int ring_off, xchg_off, scr_off;   // LDS: [band3: BN_T * E3_TSZ][ring: BN_T * E23_TSZ2 (level 3's store scratch reuses it)][xchg: 4 KB]
+};
+template <bool AP2, bool AP3>
+__global__ __launch_bounds__(512, 2) void enc23_mfma(Enc23Args p) {
+    extern __shared__ __attribute__((aligned(256))) uint8_t smem[];
+    WGSPAN_BEGIN();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint8_t *const ring = smem + p.ring_off;
+    uint8_t *const xchg = smem + p.xchg_off;
+    const int TC3 = p.W3 + 2;
+    // level 3's band: halo, pad row / column and the tail of every T slice stay zero for the whole launch
+    for (int i = tid; i < BN_T * E3_TSZ / 16; i += 512) *reinterpret_cast<uint4 *>(smem + i * 16) = make_uint4(0, 0, 0, 0);
+    const int tc2 = wave & 1, nt2 = (wave >> 1) & 1, th = wave >> 2;   // level 2: tile column, N tile, T half
+    const int nt3 = wave & 3, mg3 = wave >> 2;                         // level 3: N tile, M group
+    for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+        int ll = lane;
+        asm volatile("" : "+v"(ll));
+        lds_barrier();   // the previous frame's level 3 has left the band and its scratch (= the ring)
+        const uint8_t *const src_b = reinterpret_cast<const uint8_t *>(p.in) + (size_t)b * BN_T * p.H2 * p.W2 * 64;
+        // staging through registers (a kernel with LDS-DMA makes hipcc drain the vector-memory counter in front of every LDS
+        // read, which would put each step's landing back in front of its tiles): a thread owns ONE 16-byte piece position
+        // (T slice tid >> 7, pixel, chunk) of every ring row; per step it loads that piece of the two new rows right after
+        // the step's barrier and writes them into their slots behind its tile
+        const int st_t = tid >> 7, st_i = tid & 127, st_c = st_i >> 2, st_x = st_c - 1;
+        const bool st_xin = st_x >= 0 && st_x < p.W2;
+        uint32_t st_so[2];   // source offset of the piece within its row, per row parity (the swizzle depends on it)
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            st_so[k] = (uint32_t)((min(max(st_x, 0), p.W2 - 1)) * 64 + (((st_i & 3) ^ swz_eval<4>(p.swz2, st_c, k)) << 4));
+        const uint8_t *const st_src = src_b + (size_t)st_t * p.H2 * p.W2 * 64;
+        uint8_t *const st_dst = ring + st_t * E23_TSZ2 + st_i * 16;
+        auto load_rows = [&](int r0, uint4 (&v)[2]) {    // rows r0, r0 + 1 (r0 odd): yy = row + 1 has parity k
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int rc = min(max(r0 + k, 0), p.H2 - 1);
+                v[k] = *reinterpret_cast<const uint4 *>(st_src + (size_t)rc * p.W2 * 64 + st_so[k]);
+            }
+        };
+        auto store_rows = [&](int r0, const uint4 (&v)[2]) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int row = r0 + k;
+                const bool in = st_xin && row >= 0 && row < p.H2;
+                *reinterpret_cast<uint4 *>(st_dst + ((row + 1) % E23_NSLOT) * E23_RP2) = in ? v[k] : make_uint4(0, 0, 0, 0);
+            }
+        };
+        {
+            uint4 va[2], vb[2];
+            load_rows(-1, va);
+            load_rows(1, vb);
+            store_rows(-1, va);
+            store_rows(1, vb);
+        }
+        {   // ---------------- level 2
+            const int m0 = ll & 31, kh = ll >> 5;
+            const int yl = (m0 >> 1) & 1, xl = 2 * (m0 >> 2) + (m0 & 1);
+            // the lane's part of a fragment address per tap (pixel within the ring row, chunk = K half ^ swizzle); the ring row
+            // (slot) of the tap is added per step.  yy = row + 1 of the absolute input row: its parity is the tap row's parity
+            // within a step.  (Per frame, from an opaque lane id: nothing of level 2 stays live across level 3's 240 registers.)
+            uint32_t xq2[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) {
+                const int yy = yl + tap / 3, xx = xl + 16 * tc2 + tap % 3;
+                xq2[tap] = (uint32_t)(p.ring_off + th * 2 * E23_TSZ2 + xx * 64) ^ (uint32_t)((kh ^ swz_eval<4>(p.swz2, xx, yy)) << 4);
+            }
+            half8 bf[18];
+            {
+                const half8 *wp = p.wf2 + nt2 * 18 * 64 + ll;
+                asm volatile("" : "+v"(wp));
+#pragma unroll
+                for (int ks = 0; ks < 18; ks++) bf[ks] = wp[ks * 64];
+            }
+            const int co = nt2 * 32 + (ll & 31);
+            const float e0 = p.epi2[co], e1 = p.epi2[64 + co], e2 = p.epi2[128 + co];
+            const TmixW tm = load_tmix(p.epi2 + 192, ll);
+            int s0 = 0;   // ring slot of the step's first row (input row 2s - 1)
+            for (int s = 0; s < p.Hp2; s++) {
+                lds_barrier();   // the step's rows are in the ring; every wave has left step s - 1 (its ring rows, the exchange area)
+                uint4 vn[2];
+                const bool pre = s + 1 < p.Hp2;
+                if (pre) load_rows(2 * s + 3, vn);
+                uint32_t fa[9];
+                {
+#pragma unroll
+                    for (int ty = 0; ty < 3; ty++) {
+                        int slot = s0 + ty + yl;   // per lane (written as arithmetic: a select between wave-uniform values becomes a scratch array)
+                        slot = slot >= E23_NSLOT ? slot - E23_NSLOT : slot;
+                        const uint32_t rr = (uint32_t)(slot * E23_RP2);
+#pragma unroll
+                        for (int tx = 0; tx < 3; tx++) fa[ty * 3 + tx] = xq2[ty * 3 + tx] + rr;
+                    }
+                }
+                s0 = s0 + 2 >= E23_NSLOT ? s0 + 2 - E23_NSLOT : s0 + 2;
+                // 36 products: tap x channel chunk x the wave's two T slices; A fragments through a ring of eight registers
+                constexpr int AD = 8, NS = 36;
+                auto frag = [&](int i) -> half8 {
+                    const int tap = i >> 2, kc = (i >> 1) & 1, t = i & 1;
+                    const uint8_t *a = smem + (fa[tap] ^ (uint32_t)(kc << 5));
+                    return *reinterpret_cast<const half8 *>(__builtin_assume_aligned(a + t * E23_TSZ2, 16));
+                };
+                half8 ab[AD];
+#pragma unroll
+                for (int i = 0; i < AD; i++) ab[i] = frag(i);
+                f32x16 acc[2];
+#pragma unroll
+                for (int i = 0; i < NS; i++) {
+                    const int t = i & 1;
+                    if (i < 2) {
+#pragma unroll
+                        for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
+                    }
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab[i % AD], bf[i >> 1], acc[t], 0, 0, 0);
+                    if (i + AD < NS) ab[i % AD] = frag(i + AD);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, AD, 0);
+#pragma unroll
+                for (int i = 0; i < NS; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i + AD < NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                // pooled values of windows 2g + kh (g = 0..3) for the wave's T slices, rounded to fp16 (the MLP's operand)
+                half2v hp[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+#pragma unroll
+                    for (int t = 0; t < 2; t++)
+                        hp[g][t] = (_Float16)pool4<AP2>(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3], e0, e1, e2);
+                // the partner wave (same tile, other T half) runs the MLP of windows g = 2 (1 - th), 2 (1 - th) + 1: hand it ours
+                {
+                    typedef _Float16 half4x __attribute__((ext_vector_type(4)));
+                    const half4x give = th ? half4x{hp[0][0], hp[0][1], hp[1][0], hp[1][1]} : half4x{hp[2][0], hp[2][1], hp[3][0], hp[3][1]};
+                    *reinterpret_cast<half4x *>(xchg + (wave * 64 + ll) * 8) = give;
+                }
+                if (pre) store_rows(2 * s + 3, vn);
+                lds_barrier();
+                half4 pb[2], o[2];
+                {
+                    const half4 got = *reinterpret_cast<const half4 *>(xchg + ((wave ^ 4) * 64 + ll) * 8);
+                    if (th == 0) {
+                        pb[0] = half4{hp[0][0], hp[0][1], got[0], got[1]};
+                        pb[1] = half4{hp[1][0], hp[1][1], got[2], got[3]};
+                    } else {
+                        pb[0] = half4{got[0], got[1], hp[2][0], hp[2][1]};
+                        pb[1] = half4{got[2], got[3], hp[3][0], hp[3][1]};
+                    }
+                }
+                tmix4h<2>(tm, pb, o);
+                // -> level 3's band: pixel (gy + 1, gx + 1) of every T slice, channel co, at the band's swizzle
+#pragma unroll
+                for (int gl = 0; gl < 2; gl++) {
+                    const int owx = 8 * tc2 + 2 * (2 * th + gl) + kh;
+                    if (owx < p.Wp2) {
+                        const int yy = s + p.oy3 + 1, xx = owx + p.ox3 + 1;
+                        uint8_t *d = smem + (yy * TC3 + xx) * 128 + ((((co >> 3) ^ swz_eval<8>(p.swz3, xx, yy))) << 4) + (co & 7) * 2;
+#pragma unroll
+                        for (int t = 0; t < BN_T; t++) *reinterpret_cast<_Float16 *>(d + t * E3_TSZ) = o[gl][t];
+                    }
+                }
+            }
+        }
+        lds_barrier();   // level 3's band is complete
+        {   // ---------------- level 3 (the tile loop of enc_mfma<64, 128, 2, .., E3_TSZ> on the band in LDS)
+            int l3 = lane;
+            asm volatile("" : "+v"(l3));
+            const int m0 = l3 & 31, kh = l3 >> 5;
+            const int yl = (m0 >> 1) & 1, xl = 2 * (m0 >> 2) + (m0 & 1);
+            half8 bf[36];
+            {
+                const half8 *wp = p.wf3 + nt3 * 36 * 64 + ll;
+                asm volatile("" : "+v"(wp));
+#pragma unroll
+                for (int ks = 0; ks < 36; ks++) bf[ks] = wp[ks * 64];
+            }
+            // T = 0 slice of level 2's output -> act[3] (rows / columns of the pad are zero in HBM and never written)
+            {
+                __half *const mb = p.mid + (size_t)b * BN_T * p.H3 * p.W3 * 64;
+                const int npc = p.Hp2 * p.Wp2 * 8;
+                for (int i = tid; i < npc; i += 512) {
+                    const int pix = i >> 3, j = i & 7;
+                    const int wy = pix / p.Wp2, wx = pix - wy * p.Wp2;
+                    const int yy = wy + p.oy3 + 1, xx = wx + p.ox3 + 1;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(smem + (yy * TC3 + xx) * 128 + ((j ^ swz_eval<8>(p.swz3, xx, yy)) << 4));
+                    *reinterpret_cast<uint4 *>(mb + ((size_t)(yy - 1) * p.W3 + (xx - 1)) * 64 + j * 8) = v;
+                }
+            }
+            const int co = nt3 * 32 + (ll & 31);
+            const float e0 = p.epi3[co], e1 = p.epi3[128 + co], e2 = p.epi3[256 + co];
+            const TmixW tm = load_tmix(p.epi3 + 384, ll);
+            uint32_t kq[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) {
+                const int yy = yl + tap / 3, xx = xl + tap % 3;
+                kq[tap] = (uint32_t)((yy * TC3 + xx) * 128) ^ (uint32_t)((kh ^ swz_eval<8>(p.swz3, xx, yy)) << 4);
+            }
+            const int ntc = (p.Wp3 + 7) >> 3;
+            const int ntiles = p.Hp3 * ntc;
+            int t_wy = 0, t_tc = mg3;
+            __half *const ob = p.out + (size_t)b * p.H4 * p.W4 * 128;
+            uint8_t *const scr = smem + p.scr_off + wave * 2048;
+            for (int tile = mg3; tile < ntiles; tile += 2, t_tc += 2) {
+                while (t_tc >= ntc) { t_tc -= ntc; t_wy++; }
+                const uint32_t tbase = (uint32_t)(((2 * t_wy) * TC3 + 16 * t_tc) * 128);
+                uint32_t fa[9];
+#pragma unroll
+                for (int tap = 0; tap < 9; tap++) fa[tap] = kq[tap] + tbase;
+                half4 pb4[4];
+#pragma unroll
+                for (int grp = 0; grp < 2; grp++) {
+                    f32x16 acc[2];
+#pragma unroll
+                    for (int t = 0; t < 2; t++)
+#pragma unroll
+                        for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
+#pragma unroll
+                    for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+                        for (int kc = 0; kc < 4; kc++)
+#pragma unroll
+                            for (int t = 0; t < 2; t++) {
+                                const uint8_t *ap = smem + ((fa[tap] + (uint32_t)(grp * 2 * E3_TSZ)) ^ (uint32_t)(kc << 5)) + t * E3_TSZ;
+                                const half8 a = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(ap, 16));
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[tap * 4 + kc], acc[t], 0, 0, 0);
+                            }
+#pragma unroll
+                    for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                        for (int g = 0; g < 4; g++)
+                            pb4[g][grp * 2 + tt] = (_Float16)pool4<AP3>(acc[tt][4 * g], acc[tt][4 * g + 1], acc[tt][4 * g + 2], acc[tt][4 * g + 3], e0, e1, e2);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    typedef int i32x2 __attribute__((ext_vector_type(2)));
+                    i32x2 bits = __builtin_bit_cast(i32x2, pb4[g]);
+                    asm volatile("" : "+v"(bits));
+                    pb4[g] = __builtin_bit_cast(half4, bits);
+                }
+                // epilogue: temporal MLP, T = 0 only (the decoder takes nothing else), 16-byte stores through the wave's transpose
+                half4 o4[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) tmix4h(tm, pb4[g], o4[g]);
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    _Float16 *sw = reinterpret_cast<_Float16 *>(scr + (2 * g + kh) * 64) + (ll & 31);
+                    sw[0] = o4[g][0];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int owin = 8 * t_tc + ((ll >> 2) & 7);
+                if (owin < p.Wp3 && ll < 32) {
+                    const int gy = t_wy + p.oy4, gx = owin + p.ox4;
+                    const uint32_t eo = (uint32_t)((gy * p.W4 + gx) * 128 + nt3 * 32 + 8 * (ll & 3));
+                    *reinterpret_cast<uint4 *>(ob + eo) = *reinterpret_cast<const uint4 *>(scr + ll * 16);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    WGSPAN_END(1);
+}
+
 // ------------------------------------------------------------------ decoder blocks 0..3
 // relu -> convT(4x4, s2) -> crop -> BN as ONE 2x2-tap convolution over the (Hi+1)x(Wi+1) grid:
 //   out[2u+py-cy, 2v+px-cx][co] = sum_{a,b,c} in[u-a, v-b][c] * w[py+2a][px+2b][co][c]
@@ -2239,6 +2532,38 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
     for (int i = 1; i < BN_LEVELS; i++) {
         const int H = m->lv[i].H, W = m->lv[i].W, Hp = H / 2, Wp = W / 2;
         const int cin = m->enc_c[i];
+        if (i == 2 && m->fuse_enc23 && m->enc_rowtiles && !ctx->enc_plan[2].nbands && !ctx->enc_plan[3].nbands && cin == 32 &&
+            m->enc_c[3] == 64 && m->enc_c[4] == 128) {
+            // levels 2 + 3 in one launch (enc23_mfma) when a ring row holds level 2's row, its windows make at most two tile columns
+            // and level 3's band fits the compile-time slice stride; one workgroup per frame
+            const int H3 = m->lv[3].H, W3 = m->lv[3].W, Hp3 = H3 / 2, Wp3 = W3 / 2;
+            const size_t lds = (size_t)BN_T * E3_TSZ + (size_t)BN_T * E23_TSZ2 + 4096;
+            if ((W + 2) * 64 <= E23_RP2 && Wp <= 16 && Hp >= 1 && Hp3 >= 1 && Wp3 >= 1 &&
+                (size_t)std::max(2 * Hp3 + 2, H3 + 1) * (W3 + 2) * 128 <= (size_t)E3_TSZ && lds <= 160 * 1024 - 256) {
+                Enc23Args a;
+                a.in = act[2]; a.mid = act[3]; a.out = act[4];
+                a.wf2 = (const half8 *)(prep + pr->enc[2].wfrag); a.wf3 = (const half8 *)(prep + pr->enc[3].wfrag);
+                a.epi2 = (const float *)(prep + pr->enc[2].epi); a.epi3 = (const float *)(prep + pr->enc[3].epi);
+                a.B = batch;
+                a.H2 = H; a.W2 = W; a.Hp2 = Hp; a.Wp2 = Wp;
+                a.H3 = H3; a.W3 = W3; a.Hp3 = Hp3; a.Wp3 = Wp3; a.oy3 = H & 1; a.ox3 = W & 1;
+                a.H4 = m->lv[4].H; a.W4 = m->lv[4].W; a.oy4 = H3 & 1; a.ox4 = W3 & 1;
+                a.swz2 = choose_swz_periodic(32, 30, Wp); a.swz3 = choose_swz_periodic(64, W3, Wp3);
+                a.ring_off = BN_T * E3_TSZ; a.xchg_off = a.ring_off + BN_T * E23_TSZ2; a.scr_off = a.ring_off;
+                const bool ap2 = pr->allpos[2], ap3 = pr->allpos[3];
+                int rc = ap2 ? (ap3 ? set_lds(ctx, enc23_mfma<true, true>, lds) : set_lds(ctx, enc23_mfma<true, false>, lds))
+                             : (ap3 ? set_lds(ctx, enc23_mfma<false, true>, lds) : set_lds(ctx, enc23_mfma<false, false>, lds));
+                if (rc) return rc;
+                const int grid = std::min(batch, num_cu);
+                ProfScope ps(ctx, "enc23_mfma");
+                if (ap2 && ap3) LAUNCH((enc23_mfma<true, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
+                else if (ap2) LAUNCH((enc23_mfma<true, false>), dim3(grid), dim3(512), lds, ctx->stream, a);
+                else if (ap3) LAUNCH((enc23_mfma<false, true>), dim3(grid), dim3(512), lds, ctx->stream, a);
+                else LAUNCH((enc23_mfma<false, false>), dim3(grid), dim3(512), lds, ctx->stream, a);
+                COVAHIP_CHECK_HIP(ctx, hipGetLastError());
+                break;   // level 3 ran in the same launch
+            }
+        }
         if (i == 1 && m->enc1_tile16 && cin == 16 && m->enc_c[2] == 32 && W <= E1_MAXW && !ctx->enc_plan[1].nbands) {
             // enc1_mfma: bands of at most three pool-window rows (E1_TR rows per T slice), two eight-wave workgroups per CU;
             // same planner as below: rounds x (rows + 1)

@@ -287,6 +287,36 @@ def test_row_aligned_tiles_match_general_tiles_bitwise(ctx, weights_flat, hw, mi
         np.testing.assert_array_equal(a, c)
 
 
+@pytest.mark.parametrize("hw", [(68, 120), (67, 120), (66, 116), (61, 100), (36, 64)])
+@pytest.mark.parametrize("mixed_gamma", [False, True])
+def test_fused_encoder_levels_2_3_match_separate_launches_bitwise(ctx, weights_flat, hw, mixed_gamma):
+    """Encoder levels 2 + 3 as ONE launch (enc23_mfma, round 5: level 2's input through a ring of rows, its output written
+    into level 3's LDS band, T halves of a tile on two waves) vs the two launches of enc_mfma (developer switch
+    "enc23_separate"): the same products in the same order per accumulator -- logits, masks and boxes bit for bit, both
+    gamma sign classes, both entries, grids with odd / even level-2 and level-3 sizes (pad rows and columns)."""
+    h, w = hw
+    b = 20
+    flat = _mixed_gamma_weights(91) if mixed_gamma else weights_flat
+    stack = synth.stacked_batch(b, h, w, seed=29, streams=2)
+    frames, index = synth.carrier_batch(b, h, w, seed=29, streams=2)
+    net = BlobNetInfer(ctx, flat, h, w, max_batch=b)
+    logits, mask = net.infer(stack)
+    got = net.filter_frames(frames, index, 2, max_boxes=1024, want_mask=True, want_logits=True)
+    net.set_impl("enc23_separate")
+    try:
+        logits2, mask2 = net.infer(stack)
+        got2 = net.filter_frames(frames, index, 2, max_boxes=1024, want_mask=True, want_logits=True)
+    finally:
+        net.set_impl("mfma")
+    np.testing.assert_array_equal(logits, logits2)
+    np.testing.assert_array_equal(mask, mask2)
+    for a, c in zip(got, got2):
+        np.testing.assert_array_equal(a, c)
+    # twice in a row on the same workspace (the persistent zero borders of the LDS band, the ring's reuse between frames)
+    logits3, _ = net.infer(stack)
+    np.testing.assert_array_equal(logits, logits3)
+
+
 @pytest.mark.parametrize("hw", [(68, 120), (67, 120), (45, 80), (35, 60)])
 def test_fused_decoder_blocks_match_separate_launches_bitwise(ctx, weights_flat, hw):
     """Decoder blocks 0..2 as one launch (one workgroup per frame, intermediates in LDS) vs the three launches of
