@@ -70,7 +70,17 @@ def kernel_macs_per_frame():
         out[f"dec{j}_mfma"] = hs[4 - j] * ws[4 - j] * 16 * dec_ci[j] * dec_co[j]
     out["dec3_final_mfma"] = hs[1] * ws[1] * 16 * dec_ci[3] * dec_co[3] + H_MB * W_MB * 16
     out["dec012_mfma"] = out["dec0_mfma"] + out["dec1_mfma"] + out["dec2_mfma"]      # the three blocks in one launch
+    out["enc23_mfma"] = out["enc2_mfma"] + out["enc3_mfma"]                          # levels 2 + 3 in one launch (round 5)
+    out["dec3_bboxcc_fused"] = out["dec3_final_mfma"]
     return out
+
+
+def dec3_fold_macs_per_frame():
+    """(algorithmic, executed) MACs per frame of the last decoder block + final 1x1 conv: the kernels run them FOLDED into one
+    32 -> 1 transposed conv (no non-linearity between them): 4 parities x 4 taps x 32 channels per grid position."""
+    hs, ws = level_dims()
+    alg = hs[1] * ws[1] * 16 * 32 * 16 + H_MB * W_MB * 16
+    return alg, (hs[1] + 1) * (ws[1] + 1) * 4 * 4 * 32
 
 
 def kernel_bytes_per_frame():
@@ -88,11 +98,14 @@ def kernel_bytes_per_frame():
     out["dec3_final_mfma"] = hs[1] * ws[1] * (dec_c1[3] + dec_c2[3]) * 2 + H_MB * W_MB
     # one launch for blocks 0..2: the skip inputs of the three blocks in, block 2's output out (the intermediates stay in LDS)
     out["dec012_mfma"] = sum(hs[4 - j] * ws[4 - j] * dec_c2[j] * 2 for j in range(3)) + hs[1] * ws[1] * dec_co[2] * 2
+    # levels 2 + 3 in one launch: level 2's input in; the T = 0 slice of level 2's output (decoder skip) and level 3's T = 0 output out
+    out["enc23_mfma"] = T * hs[2] * ws[2] * enc_c[2] * 2 + hs[3] * ws[3] * enc_c[3] * 2 + hs[4] * ws[4] * enc_c[4] * 2
+    out["dec3_bboxcc_fused"] = out["dec3_final_mfma"]
     return out
 
 
 PMC_KERNEL_KEYS = {"enc0p_mfma": "enc0p_mfma", "enc1_mfma": "enc1_mfma<", "enc2_mfma": "enc_mfma<32, 64",
-                   "enc3_mfma": "enc_mfma<64, 128", "dec0_mfma": "dec_mfma<0, 128", "dec1_mfma": "dec_mfma<64, 64",
+                   "enc3_mfma": "enc_mfma<64, 128", "enc23_mfma": "enc23_mfma", "dec0_mfma": "dec_mfma<0, 128", "dec1_mfma": "dec_mfma<64, 64",
                    "dec2_mfma": "dec_mfma<32, 32", "dec012_mfma": "dec012_mfma", "dec3_final_mfma": "dec_mfma<16, 16", "dec3_bboxcc_fused": "dec3cc_mfma",
                    "bboxcc_kernel": "bboxcc_kernel"}
 
@@ -322,6 +335,8 @@ def board_power_under(ctx, step, seconds=2.0, settle=0.8):
         return None
     ms = (t1 - t0) / n * 1e3
     return {"mean_w": round(sum(w) / len(w), 1), "max_w": round(max(w), 1), "cap_w": cap, "samples": len(w),
+            # at the cap = the mean within 2 % of it (the firmware holds the board there by lowering the clock)
+            "at_cap": bool(cap and sum(w) / len(w) >= 0.98 * cap),
             "ms_per_step_in_this_loop": round(ms, 4), "mj_per_step": round(sum(w) / len(w) * ms, 1)}
 
 
@@ -792,6 +807,21 @@ def main():
         # what the timed entry executes: the carrier-frame entry runs level 0's convolution once per carrier frame
         # (nfr slices) instead of once per (stack, T slice) (4 B slices)
         executed_flop = total_flop - (2.0 * hs[0] * ws[0] * 9 * 3 * 16 * (T * B - nfr) if args.entry == "frames" else 0.0)
+        # ... and the last decoder block + final conv as ONE folded 32 -> 1 transposed conv (16.8 M -> 1.1 M MAC per frame)
+        fold_alg, fold_exec = dec3_fold_macs_per_frame()
+        executed_flop -= 2.0 * (fold_alg - fold_exec) * B
+        # every kernel of a step against both roofs, from the warm one-lane per-kernel pass (HIP events: ~2 us of event
+        # overhead per launch are inside these times -- the rocprofv3 figures in profiles/ are the ones without)
+        kernels = {}
+        for k, us in sorted(per_kernel_us.items()):
+            if k not in macs:
+                continue
+            fl, by = 2.0 * macs[k] * B, kbytes[k] * B
+            kernels[k] = {"us_alone": round(us, 2), "alg_flop": fl, "frac_mfma": round(fl / (us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                          "hbm_bytes": by, "frac_hbm": round(by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+        if "dec3_bboxcc_fused" in kernels:
+            kernels["dec3_bboxcc_fused"]["executed_flop"] = 2.0 * fold_exec * B
+            kernels["dec3_bboxcc_fused"]["note"] = "alg_flop = convT 32->16 + 1x1 as written; executed folded; bboxcc runs in the same launch"
         step_s = elapsed / args.steps
         dom_flop = 2.0 * macs[dominant] * B
         ach_tflops = dom_flop / dom_s / 1e12
@@ -818,13 +848,19 @@ def main():
             "value_one_lane": round(world * B / serial_ms * 1e3, 1),
             "timed_regions_s": [round(r, 5) for r in regions],
             "timed_region": f"median of {len(regions)} barrier-to-barrier regions of {args.steps} steps each",
-            "ms_per_step_table_cached": round(elapsed_cached / args.steps * 1e3, 4),
+            "ms_per_step_one_batch": round(elapsed_cached / args.steps * 1e3, 4),
             "shader_clock_mhz_under_load": round(clock_mhz, 1),
             "blobnet_mfma_util_whole_net": round(total_flop / step_s / 1e12 / MFMA_PEAK_TFLOPS, 4),
             "blobnet_mfma_util_whole_net_executed": round(executed_flop / step_s / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "blobnet_mfma_util_whole_net_one_lane": round(total_flop / (serial_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "blobnet_mfma_util_whole_net_one_lane_executed": round(executed_flop / (serial_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
             "algorithmic_flop_per_step": total_flop,
             "executed_flop_per_step": executed_flop,
             "per_kernel_us": {k: round(v, 2) for k, v in sorted(per_kernel_us.items())},
+            "per_kernel_us_note": ("HIP events around every launch of 20 one-lane steps, warm: the event pair costs ~2 us per launch, so "
+                                   "the sum exceeds ms_per_step_one_lane; kernel times without it: profiles/r*/kernel_stats_frames_lanes1.csv (rocprofv3)"),
+            "launches_per_step": len(per_kernel_us),
+            "kernels": kernels,
         }
         line.update({k: rank0.pop(k) for k in ("stacked_entry", "carrier_frame_entry") if k in rank0})
         line.update({
@@ -854,7 +890,7 @@ def main():
                                 "note": "standalone kernel on the step's masks (in the hot path bboxcc runs inside the last "
                                         "decoder block's launch); b=256 masks are 2.09 MB: latency bound -- the byte rate is "
                                         "bboxcc_B65536_sparse_blobs"},
-            "blobnet_mfma_util_note": "BlobNet FLOP (algorithmic: SURVEY.md 8d; executed: level 0 once per carrier frame) over the "
+            "blobnet_mfma_util_note": "BlobNet FLOP (algorithmic: SURVEY.md 8d; executed: level 0 once per carrier frame, last decoder block + final conv folded) over the "
                                       "WHOLE step time (bboxcc included: it shares a launch)",
             "hip_event_ms_per_step_rank0": round(ev_ms / args.steps, 4),
             "boxes_per_frame_mean": float(counts.mean()),
@@ -890,7 +926,7 @@ def main():
                           "stack_table": ("two batches (different streams and interleaving: different carrier frames, different stack tables) alternate "
                                           "across the timed steps of every lane; every step validates its table on the host and hands it to the "
                                           "level-1 kernel by value, in its kernel arguments (blobnet.hip prepare_frames; no copy in front of the "
-                                          "kernels); ms_per_step_table_cached = the same steps on ONE batch"),
+                                          "kernels); ms_per_step_one_batch = the same steps on ONE batch"),
                           "batch_per_gpu": B, "grid_mb": [H_MB, W_MB], "timestep": T, "cc_threshold": CC_THRESHOLD,
                           "parallelism": f"{world} x independent per-GPU batches, no collective"}
         print(json.dumps(line), flush=True)

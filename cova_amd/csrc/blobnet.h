@@ -49,6 +49,7 @@ struct covahip_blobnet {
     int fuse_dec = 1;  // MFMA path: decoder blocks 0..2 as one launch (a frame's three input tiles side by side in LDS) when they fit
     int enc1_tile16 = 1;  // MFMA path: level 1 on 16-position tiles (enc1_mfma) where the row fits its fixed LDS stride
     int fuse_enc23 = 1;   // MFMA path: encoder levels 2 + 3 in one launch (enc23_mfma: level 2's output stays in LDS as level 3's band) when they fit
+                          // and the batch / geometry make it pay; 0: never, 2: whenever they fit
     int enc_rowtiles = 1; // MFMA path: levels 2 and 3 on row-aligned tiles (enc_mfma<.., TSZ>) where the geometry suits them
     int64_t macs_per_frame = 0;
 };

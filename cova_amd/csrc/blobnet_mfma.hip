@@ -1263,8 +1263,7 @@ __global__ __launch_bounds__(512, 2) void enc23_mfma(Enc23Args p) {
     uint8_t *const ring = smem + p.ring_off;
     uint8_t *const xchg = smem + p.xchg_off;
     const int TC3 = p.W3 + 2;
-    // level 3's band: halo, pad row / column and the tail of every T slice stay zero for the whole launch
-    for (int i = tid; i < BN_T * E3_TSZ / 16; i += 512) *reinterpret_cast<uint4 *>(smem + i * 16) = make_uint4(0, 0, 0, 0);
+    bool first = true;
     const int tc2 = wave & 1, nt2 = (wave >> 1) & 1, th = wave >> 2;   // level 2: tile column, N tile, T half
     const int nt3 = wave & 3, mg3 = wave >> 2;                         // level 3: N tile, M group
     for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
@@ -1303,6 +1302,12 @@ __global__ __launch_bounds__(512, 2) void enc23_mfma(Enc23Args p) {
             uint4 va[2], vb[2];
             load_rows(-1, va);
             load_rows(1, vb);
+            if (first) {
+                // level 3's band: halo, pad row / column and the tail of every T slice stay zero for the whole launch (written
+                // while the first rows are on their way)
+                for (int i = tid; i < BN_T * E3_TSZ / 16; i += 512) *reinterpret_cast<uint4 *>(smem + i * 16) = make_uint4(0, 0, 0, 0);
+                first = false;
+            }
             store_rows(-1, va);
             store_rows(1, vb);
         }
@@ -1413,19 +1418,19 @@ __global__ __launch_bounds__(512, 2) void enc23_mfma(Enc23Args p) {
                 }
             }
         }
-        lds_barrier();   // level 3's band is complete
         {   // ---------------- level 3 (the tile loop of enc_mfma<64, 128, 2, .., E3_TSZ> on the band in LDS)
             int l3 = lane;
             asm volatile("" : "+v"(l3));
             const int m0 = l3 & 31, kh = l3 >> 5;
             const int yl = (m0 >> 1) & 1, xl = 2 * (m0 >> 2) + (m0 & 1);
-            half8 bf[36];
+            half8 bf[36];   // requested in front of the barrier that completes the band
             {
                 const half8 *wp = p.wf3 + nt3 * 36 * 64 + ll;
                 asm volatile("" : "+v"(wp));
 #pragma unroll
                 for (int ks = 0; ks < 36; ks++) bf[ks] = wp[ks * 64];
             }
+            lds_barrier();   // level 3's band is complete
             // T = 0 slice of level 2's output -> act[3] (rows / columns of the pad are zero in HBM and never written)
             {
                 __half *const mb = p.mid + (size_t)b * BN_T * p.H3 * p.W3 * 64;
@@ -2538,7 +2543,12 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
             // and level 3's band fits the compile-time slice stride; one workgroup per frame
             const int H3 = m->lv[3].H, W3 = m->lv[3].W, Hp3 = H3 / 2, Wp3 = W3 / 2;
             const size_t lds = (size_t)BN_T * E3_TSZ + (size_t)BN_T * E23_TSZ2 + 4096;
-            if ((W + 2) * 64 <= E23_RP2 && Wp <= 16 && Hp >= 1 && Hp3 >= 1 && Wp3 >= 1 &&
+            // ... and when it pays: one workgroup per frame wants about a frame per CU (a batch of 32 leaves seven CUs in eight idle
+            // where the two launches spread a frame's bands over them: 62 -> 76 us per step at b = 32), and row-aligned tiles want rows
+            // that fill their tile columns (45 x 80: 10 of 16 and 5 of 8 windows, 3 % slower than the two launches at b = 512).
+            // fuse_enc23 == 2 (developer switch "enc23_force", the tests) takes it whenever it fits
+            const bool pays = 4 * batch >= 3 * num_cu && 20 * Wp >= 17 * 8 * ((Wp + 7) / 8) && 20 * Wp3 >= 17 * 8 * ((Wp3 + 7) / 8);
+            if ((pays || m->fuse_enc23 == 2) && (W + 2) * 64 <= E23_RP2 && Wp <= 16 && Hp >= 1 && Hp3 >= 1 && Wp3 >= 1 &&
                 (size_t)std::max(2 * Hp3 + 2, H3 + 1) * (W3 + 2) * 128 <= (size_t)E3_TSZ && lds <= 160 * 1024 - 256) {
                 Enc23Args a;
                 a.in = act[2]; a.mid = act[3]; a.out = act[4];

@@ -300,6 +300,7 @@ def test_fused_encoder_levels_2_3_match_separate_launches_bitwise(ctx, weights_f
     stack = synth.stacked_batch(b, h, w, seed=29, streams=2)
     frames, index = synth.carrier_batch(b, h, w, seed=29, streams=2)
     net = BlobNetInfer(ctx, flat, h, w, max_batch=b)
+    net.set_impl("enc23_force")    # (a batch of 20 would take the two launches by default)
     logits, mask = net.infer(stack)
     got = net.filter_frames(frames, index, 2, max_boxes=1024, want_mask=True, want_logits=True)
     net.set_impl("enc23_separate")
@@ -313,7 +314,11 @@ def test_fused_encoder_levels_2_3_match_separate_launches_bitwise(ctx, weights_f
     for a, c in zip(got, got2):
         np.testing.assert_array_equal(a, c)
     # twice in a row on the same workspace (the persistent zero borders of the LDS band, the ring's reuse between frames)
-    logits3, _ = net.infer(stack)
+    net.set_impl("enc23_force")
+    try:
+        logits3, _ = net.infer(stack)
+    finally:
+        net.set_impl("mfma")
     np.testing.assert_array_equal(logits, logits3)
 
 
@@ -338,6 +343,23 @@ def test_fused_decoder_blocks_match_separate_launches_bitwise(ctx, weights_flat,
     np.testing.assert_array_equal(counts, counts2)
     for i in range(b):
         np.testing.assert_array_equal(boxes[i, :counts[i]], boxes2[i, :counts[i]])
+
+
+def test_fused_encoder_levels_2_3_more_frames_than_workgroups(ctx, weights_flat):
+    """enc23_mfma is persistent over frames (grid = min(batch, CUs)): 600 frames on 256 CUs take two to three frames per
+    workgroup -- the band's borders stay zero, the ring and the store scratch are reused -- and give the bits of the two
+    launches; 600 >= 3/4 of the CUs, so this is also the default chain at 68 x 120."""
+    h, w, b = 68, 120, 600
+    frames, index = synth.carrier_batch(b, h, w, seed=31, streams=6)
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=b)
+    got = net.filter_frames(frames, index, 1, max_boxes=1024, want_mask=True, want_logits=True)
+    net.set_impl("enc23_separate")
+    try:
+        got2 = net.filter_frames(frames, index, 1, max_boxes=1024, want_mask=True, want_logits=True)
+    finally:
+        net.set_impl("mfma")
+    for a, c in zip(got, got2):
+        np.testing.assert_array_equal(a, c)
 
 
 def test_whole_path_on_a_4k_grid(ctx, weights_flat):

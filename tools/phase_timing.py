@@ -29,6 +29,7 @@ d_boxes, d_counts, d_mask = ctx.malloc(B * 256 * 20), ctx.malloc(B * 4), ctx.mal
 lib = ctypes.CDLL(L.LIB_PATH)
 out = (ctypes.c_ulonglong * 80)()
 names = ["bookkeeping", "barrier (previous item)", "DMA issue", "band landing", "temporal MLP in place", "skip slice out", "tiles: matrix part", "tiles: epilogue", "weights into registers (kernel start)"]
+E23_NAMES = ["frame start: barrier, first six rows", "level 2: barrier A (+ weights at step 0)", "level 2: products, pooling", "level 2: barrier B", "level 2: next rows into the ring", "level 2: temporal MLP, band writes", "between the levels: weights, barrier, T = 0 out", "level 3: products + pooling", "level 3: epilogue"]
 E1V_NAMES = ["bookkeeping, addresses, loads issued", "barrier (previous item)", "loads landing", "temporal MLP, LDS writes, skip stores", "barrier (band complete)", "weights landing", "tiles: matrix part", "tiles: epilogue", "-"]
 steps = 20
 for _ in range(3):
@@ -40,8 +41,12 @@ for _ in range(steps):
 ctx.sync()
 lib.covahip_dev_phase_read(out, 1)
 v = np.array(list(out), dtype=np.float64)
-for base, label in ((0, "enc1t (PRE)"), (16, "enc2"), (32, "enc3"), (48, "dec012"), (64, "dec3cc")):
+FUSED23 = os.environ.get("QB_IMPL") not in ("enc23_separate", "enc_general_tiles")
+NWG[16] = 256 if FUSED23 else 512
+for base, label in ((0, "enc1t (PRE)"), (16, "enc23" if FUSED23 else "enc2"), (32, "enc3"), (48, "dec012"), (64, "dec3cc")):
+    if v[base:base + 9].sum() == 0:
+        continue
     tot = v[base:base + 9].sum()
     print(f"{label}: {tot / steps / 100:.0f} us of workgroup time per launch (all workgroups)")
-    for i, n in enumerate(DEC_NAMES if base == 48 else TAIL_NAMES if base == 64 else E1V_NAMES if base == 0 and not os.environ.get('QB_IMPL') else names):
+    for i, n in enumerate(E23_NAMES if base == 16 and FUSED23 else DEC_NAMES if base == 48 else TAIL_NAMES if base == 64 else E1V_NAMES if base == 0 and not os.environ.get('QB_IMPL') else names):
         print(f"   {n:40s} {100 * v[base + i] / tot:5.1f} %   {v[base + i] / steps / 100 / NWG[base]:7.2f} us per workgroup ({NWG[base]} of them)")
