@@ -532,8 +532,7 @@ def main():
             port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-        sys.exit(subprocess.run(cmd, env=env).returncode)
+        sys.exit(subprocess.run(cmd, env=dict(os.environ)).returncode)
     if env_world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch one rank per GPU "
                  f"(python -m torch.distributed.run --nproc-per-node {args.gpus} ...) or let --gpus start them")
@@ -560,10 +559,10 @@ def main():
         if not args.no_cpu_baseline:
             pre["cpu_tracking"] = cpu_tracking_baseline()
 
-    from cova_amd.multigpu import Group
-    # torch.distributed (RCCL) only when WORLD_SIZE > 1: rendezvous/barrier/MAX (gloo in a rehearsal: two ranks cannot open
-    # one GPU as two RCCL devices)
-    grp = Group("gloo" if args.rehearse_on_one_gpu else None)
+    from cova_amd.multigpu import Group, pin_to_gpu, streams_of_rank
+    # torch.distributed only when WORLD_SIZE > 1, and only as the job's control plane: rendezvous, barrier, MAX over ranks, the
+    # gather of the per-rank lines -- gloo on CPU tensors.  RCCL is never initialised: the path has no exchange step.
+    grp = Group()
     rank, local_rank, world = grp.rank, grp.local_rank, grp.world
     if world != args.gpus:
         sys.exit(f"bench.py: world size {world} != --gpus {args.gpus}")
@@ -578,6 +577,14 @@ def main():
         n_dev = C.c_int(0)
         L.lib().covahip_device_count(C.byref(n_dev))
         dev = local_rank % max(1, n_dev.value)
+    # rank r = GPU r + the cores of that GPU's NUMA node: the per-stream host work (decoder threads, cova elements) of the
+    # streams a rank owns runs next to the GPU it feeds.  Ranks whose GPUs share a node split its cores.
+    pin = {"pinned": False}
+    if world > 1:
+        from cova_amd.multigpu import gpu_numa
+        nodes = grp.gather(gpu_numa(dev)[0])
+        same = [r for r in range(world) if nodes[r] == nodes[rank]]
+        pin = pin_to_gpu(dev, len(same), same.index(rank))
     ctx = Context(dev)
     ctx.set_lanes(1)         # the extra legs and the per-kernel pass run one step after the other
     B = args.batch
@@ -790,6 +797,17 @@ def main():
         rank0["frames_per_s_pcie_inclusive_pipelined_carrier_frames"] = pipelined_host_rate(net, frames, index, args.steps)
         ctx.set_lanes(1)
 
+    # ---- one object per rank (stderr, and gathered into the aggregate line): what it owns and what it measured on its own clock
+    n_streams = 8 * world
+    mine = {"rank": rank, "local_rank": local_rank, "device": dev, "streams": streams_of_rank(n_streams, rank, world),
+            "frames_per_step": B, "ms_per_step_own_clock": round(ev_ms / args.steps, 4),
+            "frames_per_s_own_clock": round(B * args.steps / (ev_ms * 1e-3), 1),
+            "ms_per_step_one_lane": round(serial_ms, 4), "numa_node": pin.get("numa_node"), "cpus": pin.get("cpus"),
+            "pinned": pin.get("pinned"), "input_seed": seed}
+    if world > 1:
+        print(json.dumps({"bench_rank": mine}), file=sys.stderr, flush=True)
+    all_ranks = grp.gather(mine)
+
     if rank == 0:
         macs = kernel_macs_per_frame()
         kbytes = kernel_bytes_per_frame()
@@ -843,7 +861,9 @@ def main():
             "dtype": "f16",
             "data": "synthetic",
             "lanes": NL,
-            **({"rehearsal": f"{world} ranks shared the GPUs present on this box: not a scaling result"} if args.rehearse_on_one_gpu else {}),
+            **({"rehearsal": f"{world} ranks shared the GPUs present on this box: NOT a scaling result"} if args.rehearse_on_one_gpu else {}),
+            **({"ranks": all_ranks, "control_plane": "gloo on CPU tensors (rendezvous, barrier, MAX over ranks, gather of these objects); "
+                                                      "no RCCL communicator exists"} if world > 1 else {}),
             "ms_per_step_one_lane": round(serial_ms, 4),
             "value_one_lane": round(world * B / serial_ms * 1e3, 1),
             "timed_regions_s": [round(r, 5) for r in regions],

@@ -72,6 +72,7 @@ PROTOTYPES = {
     "covahip_strerror": (C.c_char_p, [C.c_int]),
     "covahip_version": (C.c_char_p, []),
     "covahip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "covahip_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "covahip_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "covahip_ctx_destroy": (None, [_P]),
     "covahip_ctx_sync": (C.c_int, [_P]),

@@ -35,6 +35,15 @@ int covahip_device_count(int *count) {
     return COVAHIP_OK;
 }
 
+int covahip_device_pci_bus_id(int device_id, char *out, int out_len) {
+    if (!out || out_len < 13) return COVAHIP_ERR_INVALID_ARG;
+    if (hipDeviceGetPCIBusId(out, out_len, device_id) != hipSuccess) {
+        out[0] = 0;
+        return COVAHIP_ERR_NO_DEVICE;
+    }
+    return COVAHIP_OK;
+}
+
 int covahip_ctx_create(int device_id, covahip_ctx **out) {
     if (!out) return COVAHIP_ERR_INVALID_ARG;
     *out = nullptr;

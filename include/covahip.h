@@ -52,6 +52,10 @@ enum { COVAHIP_MEM_HOST = 0, COVAHIP_MEM_DEVICE = 1 };
 typedef struct covahip_ctx covahip_ctx;
 
 int covahip_device_count(int *count);
+/* PCI address ("0000:c1:00.0") of HIP device `device_id` into out (>= 13 bytes): what a host process needs to find the
+ * device's NUMA node (/sys/bus/pci/devices/<address>/numa_node, local_cpulist) and pin its per-stream threads next to the GPU
+ * it feeds -- one process per GPU, as the reference runs one pipeline per GoP range (gst-gopsplit/gstgopsplit.cpp:556-603). */
+int covahip_device_pci_bus_id(int device_id, char *out, int out_len);
 /* Creates a context on GPU `device_id` with its own HIP stream.
  * (The reference pins its engines with gpu-id, config/blobnet/amsterdam_b128.txt:6,
  *  gst-plugins/gst-maskcopy/gstmaskcopy.cpp:247.) */

@@ -53,9 +53,11 @@ def main():
     elapsed = time.perf_counter() - t0
     tmax = grp.max(elapsed)
     total_streams = grp.sum(float(len(mine)))
+    gathered = grp.gather(mine)
     with open(os.path.join(out_dir, f"rank{grp.rank}.json"), "w") as f:
         json.dump({"rank": grp.rank, "world": grp.world, "streams": mine, "results": results,
-                   "elapsed": elapsed, "tmax": tmax, "total_streams": total_streams}, f)
+                   "elapsed": elapsed, "tmax": tmax, "total_streams": total_streams, "gathered": gathered,
+                   "backend": grp.backend}, f)
     grp.close()
 
 

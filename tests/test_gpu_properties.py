@@ -1,5 +1,7 @@
 """Size-independent properties of the HIP path at BASELINE sizes (b=256, 68x120), where running the
 oracle on everything would take too long for a test: conservation laws and invariances."""
+import os
+
 import numpy as np
 import pytest
 
@@ -123,3 +125,40 @@ def test_kernel_chains_agree_over_many_geometries(ctx):
         for i in range(3):
             np.testing.assert_array_equal(b1[i, :c1[i]], b2[i, :c1[i]], err_msg=f"{h}x{w}")
             np.testing.assert_array_equal(fb[i, :c1[i]], b1[i, :c1[i]], err_msg=f"{h}x{w}")
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsed_on_this_gpu():
+    """The N > 1 path of bench.py on real hardware, every round: two ranks started by bench.py itself as a
+    child process (before anything in it touches the GPU), gloo control plane, both on this box's GPU.  Checks what an 8-GPU
+    node will rely on -- world size, disjoint stream sets, distinct inputs, per-rank pinning report, a finite aggregate -- and
+    that the line says it is NOT a scaling result."""
+    import json
+    import math
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "5",
+                        "--warmup", "2", "--min-warmup-s", "0.05", "--no-extra-legs", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE aggregate line on stdout"
+    line = lines[0]
+    assert line["n_gpus"] == 2 and "NOT a scaling result" in line["rehearsal"]
+    assert math.isfinite(line["value"]) and line["value"] > 0 and line["scaling"] == "weak"
+    assert "no RCCL" in line["control_plane"]
+    ranks = line["ranks"]
+    assert [x["rank"] for x in ranks] == [0, 1]
+    s0, s1 = set(ranks[0]["streams"]), set(ranks[1]["streams"])
+    assert s0 and s1 and not (s0 & s1) and s0 | s1 == set(range(16))          # stream s -> rank s mod 2
+    assert ranks[0]["input_seed"] != ranks[1]["input_seed"]
+    for x in ranks:
+        assert x["frames_per_s_own_clock"] > 0 and x["cpus"]
+    if all(x["pinned"] for x in ranks) and len(ranks[0]["cpus"]) + len(ranks[1]["cpus"]) > 2:
+        assert not (set(ranks[0]["cpus"]) & set(ranks[1]["cpus"])), "two ranks on one NUMA node split its cores"
+    # the aggregate is both ranks' frames over the slowest rank's region
+    assert abs(line["value"] - 2 * line["config"]["batch_per_gpu"] * line["steps"] / (line["ms_per_step"] * 1e-3 * line["steps"])) / line["value"] < 1e-3
+    per_rank = [json.loads(l)["bench_rank"] for l in r.stderr.splitlines() if l.startswith('{"bench_rank"')]
+    assert sorted(x["rank"] for x in per_rank) == [0, 1]
