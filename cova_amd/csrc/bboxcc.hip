@@ -64,7 +64,7 @@ __global__ __launch_bounds__(CC_THREADS) void bboxcc_kernel(const uint8_t *__res
         one(blockIdx.x);
         return;
     }
-    const int n = *n_list;
+    const int n = min(*n_list, stat_batch);   // (list mode: stat_batch = the batch = the list's capacity)
     for (int k = blockIdx.x; k < n; k += gridDim.x) {
         one(list[k]);
         __syncthreads();   // the next frame reuses the LDS region
@@ -112,19 +112,27 @@ __global__ __launch_bounds__(WV_WAVES * 64, LIST ? 1 : 8) void bboxcc_wave_kerne
         const int n = ccwave::frame_wave(masks + (size_t)frame * g.H * g.W, sm, g, area_thresh, boxes + (size_t)frame * max_boxes,
                                          counts + frame, max_boxes, lane);
         if (lane == 0) {
-            if (n > g.cap) ovf_list[atomicAdd(ovf_n, 1)] = frame;   // more runs than the LDS region holds
+            if (n > g.cap) {   // more runs than the LDS region holds
+                // (the index is clamped to the list's capacity: a counter set that was NOT zero at the start of the call -- a failed
+                // call before this one, a replayed graph capture of a step -- must not turn into a write behind the list)
+                const int k = atomicAdd(ovf_n, 1);
+                if (k < batch) ovf_list[k] = frame;
+            }
             // statistics for the next call's plan, SAMPLED: one frame in sixteen -- an atomic per frame on one address cost more
             // than the rest of the kernel when most frames had many runs (52 k same-address atomics = 0.5 ms)
             if (n_big && (frame & 15) == 0 && n > base_cap)   // [0]: 128 < n <= 192, [1]: 192 < n <= 256, [2]: n > 256
                 atomicAdd(n_big + (n > 2 * base_cap ? 2 : 2 * n > 3 * base_cap ? 1 : 0), 1);
         }
     } else {
-        const int nl = *n_list;
+        const int nl = min(*n_list, batch);
         for (int k = blockIdx.x * WV_WAVES + wave; k < nl; k += gridDim.x * WV_WAVES) {
             const int frame = list[k];
             const int n = ccwave::frame_wave(masks + (size_t)frame * g.H * g.W, sm, g, area_thresh, boxes + (size_t)frame * max_boxes,
                                              counts + frame, max_boxes, lane);
-            if (lane == 0 && n > g.cap) ovf_list[atomicAdd(ovf_n, 1)] = frame;
+            if (lane == 0 && n > g.cap) {
+                const int k2 = atomicAdd(ovf_n, 1);
+                if (k2 < batch) ovf_list[k2] = frame;
+            }
             ccwave::wave_fence();   // the next frame reuses this wave's LDS region
         }
     }
@@ -223,7 +231,9 @@ int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, in
                 ln.cc_stat = ln.cc_stat_ring;
             }
         }
-        const unsigned set = can_overflow ? (ln.cc_stat_turn++ & 1) : 0;
+        // (the turn advances only once pass 1 -- which zeroes the OTHER set for the next call -- has been enqueued: a call that
+        // fails before that leaves the sets as they were)
+        const unsigned set = can_overflow ? (ln.cc_stat_turn & 1) : 0;
         int32_t *cnt = ovf ? ovf + 8 * set : nullptr, *cnt_next = ovf ? ovf + 8 * (set ^ 1) : nullptr;
         int32_t *n1 = cnt, *n2 = cnt ? cnt + 1 : nullptr, *n_big = cnt ? cnt + 2 : nullptr;
         int32_t *list1 = ovf ? ovf + 16 : nullptr, *list2 = ovf ? ovf + 16 + batch : nullptr;
@@ -241,6 +251,7 @@ int covahip_bboxcc_launch(covahip_ctx *ctx, const uint8_t *d_mask, int batch, in
                                d_mask, wg, batch, area_thresh, d_boxes, d_counts, max_boxes, (const int32_t *)nullptr,
                                (const int32_t *)nullptr, list1, n1, WAVE_CAP, n_big, cnt_next);
             COVAHIP_CHECK_HIP(ctx, hipGetLastError());
+            if (can_overflow) ln.cc_stat_turn++;
         }
         if (second_now) {
             const size_t wlds2 = (size_t)WV_WAVES * wg2.wave_bytes;

@@ -54,6 +54,15 @@ struct covahip_blobnet {
     int64_t macs_per_frame = 0;
 };
 
+// Whether encoder level 1 runs on enc1_mfma (16x16x32 tiles, fixed LDS row: grids of at most BN_E1_MAXW level-1 pixels) or on
+// the round-1..3 kernel.  ONE predicate for both translation units: blobnet.hip hands the stack table over by value only to
+// enc1_mfma, and blobnet_mfma.hip must then launch exactly that kernel.
+constexpr int BN_E1_MAXW = 62;
+inline bool bn_level1_on_enc1(const covahip_ctx *ctx, const covahip_blobnet *m) {
+    return m->enc1_tile16 && m->enc_c[1] == 16 && m->enc_c[2] == 32 && m->lv[1].W <= BN_E1_MAXW && m->lv[1].H >= 2 &&
+           !ctx->enc_plan[1].nbands;
+}
+
 // blobnet_mfma.hip
 int blobnet_prepare_mfma(covahip_ctx *ctx, covahip_blobnet *m, const float *h_weights);
 void blobnet_release_mfma(covahip_ctx *ctx, covahip_blobnet *m);

@@ -89,8 +89,7 @@ static int prepare_frames(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws,
         }
     // small batches: the table travels in the level-1 kernel's arguments (blobnet_mfma.hip); the device copy below is for
     // larger ones and for the round-1..3 level-1 kernel
-    const bool by_value = batch <= BN_KTAB_STACKS && n_frames <= 65535 && m->enc1_tile16 && !ctx->enc_plan[1].nbands &&
-                          m->lv[1].W <= 62;
+    const bool by_value = batch <= BN_KTAB_STACKS && n_frames <= 65535 && bn_level1_on_enc1(ctx, m);
     if (by_value) {
         ws.last_table = std::move(table);      // (kept alive until the launch has copied it)
         ws.last_n_frames = -1;                 // the device table, if any, is stale
@@ -396,37 +395,53 @@ int covahip_dev_graph_probe(covahip_ctx *ctx, const uint8_t *d_frames, int n_fra
     covahip_blobnet *m = ctx->blobnet;
     COVAHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     if (int rc = covahip_primary_op(ctx)) return rc;
-    hipEvent_t e0, e1;
-    COVAHIP_CHECK_HIP(ctx, hipEventCreate(&e0));
-    COVAHIP_CHECK_HIP(ctx, hipEventCreate(&e1));
-    for (int i = 0; i < 3; i++)
-        if (int rc = filter_placed(ctx, m, d_frames, n_frames, stack_index, batch, area_thresh, d_boxes, d_counts, max_boxes, nullptr, d_mask)) return rc;
-    COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    COVAHIP_CHECK_HIP(ctx, hipEventRecord(e0, ctx->stream));
-    for (int i = 0; i < iters; i++)
-        if (int rc = filter_placed(ctx, m, d_frames, n_frames, stack_index, batch, area_thresh, d_boxes, d_counts, max_boxes, nullptr, d_mask)) return rc;
-    COVAHIP_CHECK_HIP(ctx, hipEventRecord(e1, ctx->stream));
-    COVAHIP_CHECK_HIP(ctx, hipEventSynchronize(e1));
-    COVAHIP_CHECK_HIP(ctx, hipEventElapsedTime(ms_direct, e0, e1));
-    hipGraph_t graph;
-    hipGraphExec_t exec;
-    COVAHIP_CHECK_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
-    const int crc = filter_placed(ctx, m, d_frames, n_frames, stack_index, batch, area_thresh, d_boxes, d_counts, max_boxes, nullptr, d_mask);
-    COVAHIP_CHECK_HIP(ctx, hipStreamEndCapture(ctx->stream, &graph));
-    if (crc) return crc;
-    COVAHIP_CHECK_HIP(ctx, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-    for (int i = 0; i < 3; i++) COVAHIP_CHECK_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
-    COVAHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    COVAHIP_CHECK_HIP(ctx, hipEventRecord(e0, ctx->stream));
-    for (int i = 0; i < iters; i++) COVAHIP_CHECK_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
-    COVAHIP_CHECK_HIP(ctx, hipEventRecord(e1, ctx->stream));
-    COVAHIP_CHECK_HIP(ctx, hipEventSynchronize(e1));
-    COVAHIP_CHECK_HIP(ctx, hipEventElapsedTime(ms_graph, e0, e1));
-    (void)hipGraphExecDestroy(exec);
-    (void)hipGraphDestroy(graph);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    return COVAHIP_OK;
+    // a captured step must not contain the standalone bboxcc launches: their alternating counter sets are chosen at capture time,
+    // a replay would keep adding to ONE set -- the probe is for the fused tail only
+    if (!m->fuse_tail) return COVAHIP_ERR_UNSUPPORTED;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int rc = COVAHIP_OK;
+    // every exit goes through `done`: events, graph and exec are destroyed, and a capture that was begun is always ended
+    auto hip_ok = [&](hipError_t e, const char *what) {
+        if (e == hipSuccess || rc) return e == hipSuccess;
+        ctx->last_hip_error = std::string(what) + ": " + hipGetErrorString(e);
+        rc = COVAHIP_ERR_HIP;
+        return false;
+    };
+    auto run = [&](int n) {
+        for (int i = 0; i < n && !rc; i++)
+            rc = filter_placed(ctx, m, d_frames, n_frames, stack_index, batch, area_thresh, d_boxes, d_counts, max_boxes, nullptr, d_mask);
+    };
+    bool capturing = false;
+    do {
+        if (!hip_ok(hipEventCreate(&e0), "hipEventCreate") || !hip_ok(hipEventCreate(&e1), "hipEventCreate")) break;
+        run(3);
+        if (rc || !hip_ok(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize")) break;
+        if (!hip_ok(hipEventRecord(e0, ctx->stream), "hipEventRecord")) break;
+        run(iters);
+        if (rc || !hip_ok(hipEventRecord(e1, ctx->stream), "hipEventRecord") || !hip_ok(hipEventSynchronize(e1), "hipEventSynchronize") ||
+            !hip_ok(hipEventElapsedTime(ms_direct, e0, e1), "hipEventElapsedTime"))
+            break;
+        if (!hip_ok(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed), "hipStreamBeginCapture")) break;
+        capturing = true;
+        run(1);
+        capturing = false;
+        const hipError_t ee = hipStreamEndCapture(ctx->stream, &graph);   // always: the stream must leave capture mode
+        if (rc || !hip_ok(ee, "hipStreamEndCapture")) break;
+        if (!hip_ok(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0), "hipGraphInstantiate")) break;
+        for (int i = 0; i < 3 && !rc; i++) hip_ok(hipGraphLaunch(exec, ctx->stream), "hipGraphLaunch");
+        if (rc || !hip_ok(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize") || !hip_ok(hipEventRecord(e0, ctx->stream), "hipEventRecord")) break;
+        for (int i = 0; i < iters && !rc; i++) hip_ok(hipGraphLaunch(exec, ctx->stream), "hipGraphLaunch");
+        if (rc || !hip_ok(hipEventRecord(e1, ctx->stream), "hipEventRecord") || !hip_ok(hipEventSynchronize(e1), "hipEventSynchronize")) break;
+        hip_ok(hipEventElapsedTime(ms_graph, e0, e1), "hipEventElapsedTime");
+    } while (false);
+    if (capturing) (void)hipStreamEndCapture(ctx->stream, &graph);
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return rc;
 }
 
 int covahip_blobnet_forward(covahip_ctx *ctx, const uint8_t *rgba_stack, int batch, float *logits, uint8_t *mask,

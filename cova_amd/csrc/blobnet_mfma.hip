@@ -937,8 +937,9 @@ constexpr int E2_TSZ = 16384, E3_TSZ = 26112;
 constexpr int E1_RS = 2176;              // bytes per band row: 66 pixels x 32 B + 64 B, == 128 mod 256
 constexpr int E1_TR = 8;                 // band rows per T slice (three pool-window rows + halo)
 constexpr int E1_TSZ = E1_RS * E1_TR;    // bytes per T slice
-constexpr int E1_MAXW = 62;              // 8 rows x 2 (W + 2) pieces <= 2 pieces per thread; (W + 2) * 32 + 32 <= E1_RS (the
+constexpr int E1_MAXW = BN_E1_MAXW;      // (62) 8 rows x 2 (W + 2) pieces <= 2 pieces per thread; (W + 2) * 32 + 32 <= E1_RS (the
                                          // zero-weight tap of the last K step reads one pixel past the row)
+static_assert(8 * 2 * (E1_MAXW + 2) <= 2 * 512 && (E1_MAXW + 2) * 32 + 32 <= E1_RS, "enc1_mfma's staging / row limits");
 struct Enc1Args {
     const __half *in;    // P [F][H][W][16]: pooled level-0 values per carrier frame (enc0p_mfma)
     __half *out;         // [B][T][Ho][Wo][32]
@@ -2574,7 +2575,7 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
                 break;   // level 3 ran in the same launch
             }
         }
-        if (i == 1 && m->enc1_tile16 && cin == 16 && m->enc_c[2] == 32 && W <= E1_MAXW && !ctx->enc_plan[1].nbands) {
+        if (i == 1 && bn_level1_on_enc1(ctx, m)) {   // (the predicate blobnet.hip's prepare_frames uses for the table by value)
             // enc1_mfma: bands of at most three pool-window rows (E1_TR rows per T slice), two eight-wave workgroups per CU;
             // same planner as below: rounds x (rows + 1)
             const long long slots = 2LL * num_cu;
@@ -2678,6 +2679,8 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
         a.pidx = d_index; a.skip = act[1]; a.tm_pre = (const float *)(prep + pr->enc[0].epi) + 48;
         int rc = COVAHIP_OK;
         if (i == 1) {
+            // (a null table means "stack b = frames 4b .. 4b+3" to this kernel: a carrier-frame call must bring its table)
+            if (by_frames && !d_index && !dry) return COVAHIP_ERR_INVALID_ARG;
             // the round-1..3 level-1 kernel: grids wider than enc1_mfma's LDS row, developer band plans, set_impl(5)
             rc = pr->allpos[i] ? set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true, true, true>, lds) : set_lds(ctx, enc_mfma<16, 32, 2, 4, 8, true, false, true>, lds);
             if (rc) return rc;

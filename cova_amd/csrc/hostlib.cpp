@@ -605,11 +605,15 @@ struct Sort {  // sort/src/lib.rs:14-23
         // each class stay in the problem: same optimum value, same surviving edges, and the solver's work drops from
         // n_dets^2 x trackers to about n_dets^3 (at the experiment's maxage 60 / minhits 30 a stream carries 100 - 250
         // trackers, nearly all of them idle: 50 -> 3 us per frame at 11 detections x 256 trackers).
+        // Only with iou_threshold > 0: at a threshold <= 0 (the element property allows it) an edge of IoU 0 does pass
+        // the filter, the reference then matches and updates idle trackers, and WHICH idle tracker stays in the problem is no
+        // longer immaterial -- the full problem is solved.
         std::vector<size_t> &keep = keep_;
         keep.clear();
         size_t idle[2] = {0, 0};
+        const bool prune = iou_threshold > (P)0;
         for (size_t i = 0; i < np; i++)
-            if (ov_[i] || idle[trackers[i]->active ? 0 : 1]++ < nd) keep.push_back(i);
+            if (!prune || ov_[i] || idle[trackers[i]->active ? 0 : 1]++ < nd) keep.push_back(i);
         if (keep.size() < np) {
             const size_t nk = keep.size();
             red_.resize(nk * nd);

@@ -418,14 +418,17 @@ static gboolean bf_try_reserve(GstBlobNetFilter *s, BfPad *p, GstBuffer *buf, ui
 /* One carrier frame of one stream.  The streaming threads of the N decoder branches take their slot positions without a
  * lock and copy their 32 KB into the pinned slot in parallel; the element's mutex is for the rest: loading the model,
  * submitting a batch, waiting for a free slot. */
-static void bf_pack_into(GstBuffer *buf, uint16_t *dst, gsize frame_bytes) {
+/* FALSE: the buffer could not be mapped.  The slot position is already reserved (the batch's bookkeeping must complete), so it
+ * is zeroed -- and the caller reports the failure: a warning on the bus and GST_FLOW_ERROR upstream, never a silent empty frame. */
+static gboolean bf_pack_into(GstBuffer *buf, uint16_t *dst, gsize frame_bytes) {
     GstMapInfo mi;
     if (gst_buffer_map(buf, &mi, GST_MAP_READ)) {
         covahip_carrier_pack(mi.data, frame_bytes / 4, dst);
         gst_buffer_unmap(buf, &mi);
-    } else {
-        memset(dst, 0, frame_bytes / 2);
+        return TRUE;
     }
+    memset(dst, 0, frame_bytes / 2);
+    return FALSE;
 }
 
 static GstFlowReturn bf_chain(GstPad *pad, GstObject *parent, GstBuffer *buf) {
@@ -478,19 +481,27 @@ static GstFlowReturn bf_chain(GstPad *pad, GstObject *parent, GstBuffer *buf) {
 
     /* metapreprocess copies these bytes (imp.rs:311-312); here they go into the slot as two-byte records (covahip_carrier_pack:
      * what BlobNet keeps of them), so that the host-to-device copy -- the bound of this element -- moves half the bytes */
-    bf_pack_into(buf, (uint16_t *)(pf + (gsize)pos * (s->frame_bytes / 2)), s->frame_bytes);
+    gboolean mapped = bf_pack_into(buf, (uint16_t *)(pf + (gsize)pos * (s->frame_bytes / 2)), s->frame_bytes);
     for (int k = 0; k < BF_TIMESTEP - 1; k++)
         if (need[k]) {
-            bf_pack_into(need[k], (uint16_t *)(pf + (gsize)need_pos[k] * (s->frame_bytes / 2)), s->frame_bytes);
+            mapped &= bf_pack_into(need[k], (uint16_t *)(pf + (gsize)need_pos[k] * (s->frame_bytes / 2)), s->frame_bytes);
             gst_buffer_unref(need[k]);
         }
     __atomic_fetch_add(&s->done, (guint64)taken, __ATOMIC_RELEASE);
+    if (!mapped) {
+        GST_ELEMENT_WARNING(s, RESOURCE, READ, ("a carrier frame of pad %s could not be mapped for reading", GST_PAD_NAME(pad)),
+                            ("its slot was zeroed; the stream gets GST_FLOW_ERROR"));
+        ret = GST_FLOW_ERROR;
+    }
 
     if (full) {   /* the frame that completed the batch submits it, unless a later arrival has done so already */
         const gint64 tf0 = g_get_monotonic_time();
         g_mutex_lock(&s->lock);
         bf_wait_idle(s);
-        if (BF_ST_STACKS(bf_state(s)) >= (int)s->batch_size) ret = bf_flush(s);
+        if (BF_ST_STACKS(bf_state(s)) >= (int)s->batch_size) {
+            const GstFlowReturn fr = bf_flush(s);
+            if (ret == GST_FLOW_OK) ret = fr;
+        }
         g_mutex_unlock(&s->lock);
         g_atomic_int_add(&s->chain_flush_us, (gint)(g_get_monotonic_time() - tf0));
     }

@@ -159,6 +159,51 @@ def test_sequence_matches_numpy_restatement(params):
     assert n_dead_total + len(rfin) >= 1
 
 
+def test_zero_iou_threshold_solves_the_full_problem():
+    """at iou_threshold <= 0 an edge of IoU 0 passes the filter (cost 1 <= 1 - 0), so a detection that overlaps
+    nothing is MATCHED to an idle tracker instead of starting a new one (lib.rs:108-131) -- the port's idle-tracker pruning must
+    not run there.  One active idle tracker + one inactive idle one: the optimum is unique (cost 1 vs 2), so the numpy
+    restatement (scipy) and the port must agree on which tracker takes the detection."""
+    for iou in (0.0, -0.25):
+        s = E._SortHandle(10, 2, iou)
+        r = R.Sort(10, 2, iou)
+        seq = [[(10, 10, 6, 6)], [(10.5, 10, 6, 6)], [(11, 10, 6, 6)],          # tracker 0 becomes active
+               [(11.5, 10, 6, 6), (60, 40, 5, 5)],                              # tracker 1 is born (inactive)
+               [(90, 5, 4, 4)],                                                 # overlaps neither: goes to the ACTIVE idle tracker
+               [(90.5, 5, 4, 4), (30, 30, 3, 3), (31, 50, 3, 3)]]               # more detections than trackers
+        for i, dets in enumerate(seq):
+            pts = i * 33_333_333
+            dead, lens = s.update(_bb(dets), pts)
+            rdead = r.update([R.Bbox(*d) for d in dets], pts)
+            assert [len(t.history) for t in rdead] == list(lens)
+            assert s.num_trackers() == len(r.trackers), (iou, i)
+            for j, t in enumerate(r.trackers):
+                info = s.tracker_info(j)
+                assert (info["id"], info["active"], info["hit_streaks"], info["time_since_update"]) == \
+                    (t.id, t.active, t.hit_streaks, t.time_since_update), (iou, i, j)
+            if i == 4:
+                assert s.num_trackers() == 2 and s.tracker_info(0)["hit_streaks"] == 4   # matched at IoU 0: no tracker was born
+        assert s.num_trackers() == 4        # (an edge of cost exactly 2.0 -- inactive tracker, IoU 0 -- is dropped by the `!= 2.0` filter)
+
+
+def test_duplicate_detections_match_numpy_restatement():
+    """Two identical detections on one tracker, and a duplicate pair that overlaps nothing: one of a pair matches / both start
+    trackers, the same way in the port (pruned problem, iou_threshold > 0) and in the restatement."""
+    s = E._SortHandle(10, 2, 0.1)
+    r = R.Sort(10, 2, 0.1)
+    seq = [[(10, 10, 6, 6)], [(10.2, 10, 6, 6)], [(10.4, 10, 6, 6), (10.4, 10, 6, 6)],
+           [(10.6, 10, 6, 6), (50, 50, 4, 4), (50, 50, 4, 4)], [(10.8, 10, 6, 6), (50, 50, 4, 4)]]
+    for i, dets in enumerate(seq):
+        pts = i * 33_333_333
+        dead, lens = s.update(_bb(dets), pts)
+        rdead = r.update([R.Bbox(*d) for d in dets], pts)
+        assert [len(t.history) for t in rdead] == list(lens)
+        assert s.num_trackers() == len(r.trackers), i
+        got = sorted((s.tracker_info(j)["hit_streaks"], s.tracker_info(j)["time_since_update"]) for j in range(s.num_trackers()))
+        exp = sorted((t.hit_streaks, t.time_since_update) for t in r.trackers)
+        assert got == exp, i
+
+
 def test_updates_after_finalize_match_numpy_restatement():
     """finalize() (lib.rs:207-213) takes the active trackers out and keeps the others: the updates that follow run on the
     reordered set (the port keeps its prediction arrays in tracker order and histories partly unwritten -- both must survive it)."""
