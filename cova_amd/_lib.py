@@ -21,7 +21,11 @@ AU_DELTA_UNIT, AU_DISCONT, AU_DROPPABLE = 1, 2, 4
 class CovahipError(RuntimeError):
     def __init__(self, status: int, where: str, detail: str = ""):
         self.status = status
-        msg = f"{where}: {lib().covahip_strerror(status).decode()} (status {status})"
+        try:
+            text = lib().covahip_strerror(status).decode()
+        except AttributeError:            # the sanitizer build of the host units (COVAHIP_HOST_SAN_LIB) has no covahip_strerror
+            text = "error"
+        msg = f"{where}: {text} (status {status})"
         if detail:
             msg += f" [{detail}]"
         super().__init__(msg)
@@ -182,6 +186,18 @@ def lib() -> C.CDLL:
     """Loads libcovahip.so; raises (no fallback) when it has not been built."""
     global _lib
     if _lib is None:
+        san = os.environ.get("COVAHIP_HOST_SAN_LIB")
+        if san:
+            # TEST HOOK (tests/test_sanitize_host.py): the CPU-only ASan / UBSan build of the HIP-free translation units.  It has
+            # no GPU entry point at all -- those names stay unbound and any use of one raises AttributeError.
+            L = C.CDLL(san)
+            for name, (res, args) in list(PROTOTYPES.items()) + list(DEV_PROTOTYPES.items()):
+                fn = getattr(L, name, None)
+                if fn is not None:
+                    fn.restype = res
+                    fn.argtypes = args
+            _lib = L
+            return _lib
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

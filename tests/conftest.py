@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
+    config.addinivalue_line("markers", "sanitize: CPU-only ASan / UBSan leg of the host C-ABI (tests/test_sanitize_host.py)")
 
 
 def _have_gpu() -> bool:
