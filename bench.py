@@ -817,7 +817,12 @@ def main():
         macs["enc0p_mfma"] = hs[0] * ws[0] * 9 * 3 * 16 * nfr / B
         kbytes["enc0p_mfma"] = (hs[0] * ws[0] * 4 + hs[1] * ws[1] * 16 * 2) * nfr / B
         macs["enc1_mfma"] += hs[1] * ws[1] * 16 * 32            # + level 0's temporal MLP (applied while staging)
-        kbytes["enc1_mfma"] += hs[1] * ws[1] * 16 * 2           # + the T = 0 skip slice
+        # + the level-0 skip connection: as fp32 partial logits, four per grid position of the last block (round 5; the level-1 kernel
+        # runs the skip half of the folded last block, (H1 + 1)(W1 + 1) x 4 taps x 16 channels x 4 parities MAC, counted as executed
+        # work of this kernel, not as algorithmic FLOP -- those stay with the last block)
+        part_bytes = (hs[1] + 1) * (ws[1] + 1) * 16
+        kbytes["enc1_mfma"] += part_bytes
+        kbytes["dec3_bboxcc_fused"] = kbytes["dec3_final_mfma"] = hs[1] * ws[1] * 16 * 2 + part_bytes + H_MB * W_MB
         dom_s = dom_ms / dom_n * 1e-3
         cc_s = cc_ms * 1e-3
         cc_gbs = B * H_MB * W_MB / cc_s / 1e9

@@ -24,6 +24,9 @@ struct BnWorkspace {
     // carrier-frame path: pooled level-0 values per carrier frame, [frames][H_1][W_1][16] (pad row / column zero)
     __half *pbuf = nullptr;
     size_t pbuf_frames = 0;
+    // the level-0 skip connection's share of the logits (round 5): fp32 [B][H_1 + 1][W_1 + 1][4], written by the level-1 kernel, added by the last
+    // decoder block -- the skip tensor itself (act[1]) is then neither written nor read
+    float *part = nullptr;
     // stack -> frame index table of the call in flight
     int32_t *d_index = nullptr;
     int32_t *h_index = nullptr;       // pinned host copy it is uploaded from
@@ -48,6 +51,7 @@ struct covahip_blobnet {
     int fuse_tail = 1;  // MFMA path, with bboxcc requested: last decoder block + bboxcc in one launch
     int fuse_dec = 1;  // MFMA path: decoder blocks 0..2 as one launch (a frame's three input tiles side by side in LDS) when they fit
     int enc1_tile16 = 1;  // MFMA path: level 1 on 16-position tiles (enc1_mfma) where the row fits its fixed LDS stride
+    int tail_part = 1;    // MFMA path: the last decoder block's skip half computed by the level-1 kernel as partial logits (enc1_mfma only)
     int fuse_enc23 = 1;   // MFMA path: encoder levels 2 + 3 in one launch (enc23_mfma: level 2's output stays in LDS as level 3's band) when they fit
                           // and the batch / geometry make it pay; 0: never, 2: whenever they fit
     int enc_rowtiles = 1; // MFMA path: levels 2 and 3 on row-aligned tiles (enc_mfma<.., TSZ>) where the geometry suits them

@@ -28,6 +28,7 @@ static void free_model(covahip_ctx *ctx, covahip_blobnet *m) {
         for (int j = 0; j < BN_LEVELS; j++)
             if (ws.dact[j]) hipFree(ws.dact[j]);
         if (ws.pbuf) hipFree(ws.pbuf);
+        if (ws.part) hipFree(ws.part);
         if (ws.d_index) hipFree(ws.d_index);
         if (ws.h_index) hipHostFree(ws.h_index);
         if (ws.ev_index) hipEventDestroy(ws.ev_index);
@@ -169,6 +170,7 @@ static int alloc_workspace(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws
         const size_t n = (size_t)m->max_batch * out.H * out.W * m->dec_co[j];
         COVAHIP_CHECK_HIP(ctx, hipMalloc((void **)&ws.dact[j], n * sizeof(__half)));
     }
+    COVAHIP_CHECK_HIP(ctx, hipMalloc((void **)&ws.part, (size_t)m->max_batch * (m->lv[1].H + 1) * (m->lv[1].W + 1) * 4 * sizeof(float)));
     ws.ready = true;
     return COVAHIP_OK;
 }
@@ -277,11 +279,12 @@ int covahip_blobnet_set_enc_plan(covahip_ctx *ctx, int level, int nbands, int nb
 
 int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl) {
     if (!ctx || !ctx->blobnet) return COVAHIP_ERR_NOT_LOADED;
-    if (impl != 1 && (impl < 4 || impl > 8)) return COVAHIP_ERR_INVALID_ARG;
+    if (impl != 1 && (impl < 4 || impl > 9)) return COVAHIP_ERR_INVALID_ARG;
     ctx->blobnet->fuse_dec = impl != 4;
     ctx->blobnet->enc1_tile16 = impl != 5;
     ctx->blobnet->enc_rowtiles = impl != 6;
     ctx->blobnet->fuse_enc23 = impl == 7 ? 0 : impl == 8 ? 2 : 1;
+    ctx->blobnet->tail_part = impl != 9;
     return COVAHIP_OK;
 }
 

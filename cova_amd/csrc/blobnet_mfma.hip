@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -64,6 +65,8 @@ struct Prepared {
     size_t enc1w;    // level 1 again, in the fragment order of enc1_mfma: [2 N tiles][5 K steps][64] x half8
     size_t final_w;  // B fragments of the folded (convT 32->16) x (1x1 16->1) last block: [KSTEPS][64] x half8
     size_t final_epi;  // folded bias (fp32)
+    size_t final_w_up;   // the same fold restricted to the "up" half of the last block's input (channels 0..15): [4][64] x half8
+    size_t tail_w;       // ... and to the skip half (channels 16..31) as A fragments of v_mfma_f32_16x16x32_f16 for enc1_mfma: [2][64] x half8
     size_t zero;     // 256 zero bytes (LDS-DMA source for halo chunks)
     bool allpos[BN_LEVELS];  // all BN scales of encoder level i are >= 0
     size_t total;
@@ -286,6 +289,7 @@ struct DecArgs {
     Swz swz;             // LDS pixel swizzle of this launch (choose_swz)
     int scr_off;         // blocks 0..2: byte offset of the per-wave store transpose scratch (2 KB per wave)
     int mask_off;        // last block: byte offset of the band's mask rows in LDS
+    const float *part;   // last block without a skip input (C2 == 0): the skip half's share of the logits, fp32 [B][Hi + 1][Wi + 1][4 parities] (Enc1Args::part)
 };
 
 #ifdef PHASE_TIMING
@@ -956,6 +960,17 @@ struct Enc1Args {
     // the stack table BY VALUE (use_ktab): frames of stack b = ktab[4b .. 4b+3]; read from the kernel-argument segment with
     // scalar loads.  A table that changes from call to call then costs no copy in front of the kernels.
     int use_ktab;
+    // the level-0 skip connection's share of the LOGITS (round 5): the last decoder block is linear in its concatenated input
+    // (convT of concat(up, skip) = convT_up(up) + convT_skip(skip), decoder.py:122-134, no non-linearity up to the final 1x1
+    // conv), and its skip half is exactly the T = 0 slice this kernel has just computed and holds in LDS.  part != null: the
+    // kernel runs that half (folded with the final conv: 16 channels x 4 taps -> 4 output parities per grid position) on its
+    // band and writes fp32 partial logits -- four per grid position of the transposed convolution (its 2 x 2 output pixels), laid
+    // out [B][H + 1][W + 1][4] exactly as the last block's own tiles walk them: 34 KB per frame instead of the 65 KB skip slice,
+    // which then is neither written here nor read by the decoder tail (33 MB per step at b = 256).  One unconditional 16-byte
+    // store per position (a first form wrote [Hd][Wd] pixels: sixteen masked 4-byte stores per tile, 500 instructions per item).
+    float *part;
+    const half8 *wtail;  // [2 K steps][64 lanes]: A fragments of the folded skip half (prep_tail)
+    uint32_t mGW;        // magic of W + 1 (grid positions per row of the transposed convolution)
     uint16_t ktab[BN_KTAB_STACKS * BN_T];
 };
 // Per-lane constants live in a small LDS table behind the scratch instead of registers (hipcc keeps every loop-invariant
@@ -963,7 +978,8 @@ struct Enc1Args {
 //   [0, 384)    e0[32], e1[32], e2[32]                      (pool4)
 //   [384, 448)  this level's temporal MLP: rows lane % 4 of W1^T and W2^T as fp16 (TmixW::a1, a2), 16 B per lane % 4
 //   [448, 512)  the same for the level below
-constexpr int E1_CONST = 512;
+//   [512, 2560) the folded skip half of the last decoder block (Enc1Args::wtail): 2 K steps x 64 lanes x 16 B
+constexpr int E1_CONST = 2560;
 #ifndef E1_ABL
 #define E1_ABL 0   // developer builds (tools/ablate_enc1.sh): 1 no temporal MLP, 3 no tile epilogue, 4 no tiles, 5 no staging
 #endif
@@ -978,6 +994,7 @@ __global__ __launch_bounds__(512, 4) void enc1_mfma(Enc1Args p) {
     for (int i = tid; i < BN_T * E1_TSZ / 16; i += WGS) *reinterpret_cast<uint4 *>(smem + i * 16) = make_uint4(0, 0, 0, 0);
     uint8_t *const cst = smem + p.scr_off + NWV * 1024;
     if (tid < 96) reinterpret_cast<float *>(cst)[tid] = p.epi[tid];
+    if (p.part && tid >= 256 && tid < 384) reinterpret_cast<half8 *>(cst + 512)[tid - 256] = p.wtail[tid - 256];
     if (tid >= 128 && tid < 136) {
         const int i = tid & 3;
         const float *tmw = (tid & 4) ? p.tm_pre : p.epi + 96;
@@ -1092,7 +1109,7 @@ __global__ __launch_bounds__(512, 4) void enc1_mfma(Enc1Args p) {
 #pragma unroll
                     for (int t = 0; t < BN_T; t++) *reinterpret_cast<half8 *>(smem + t * E1_TSZ + dst[k]) = o[t];
                 }
-                if (own[k]) *reinterpret_cast<half8 *>(reinterpret_cast<uint8_t *>(p.skip) + (size_t)b * BN_T * plane + eoff[k]) = o[0];
+                if (own[k] && !p.part) *reinterpret_cast<half8 *>(reinterpret_cast<uint8_t *>(p.skip) + (size_t)b * BN_T * plane + eoff[k]) = o[0];
             } else {
                 if (have[k]) {
 #pragma unroll
@@ -1123,6 +1140,64 @@ __global__ __launch_bounds__(512, 4) void enc1_mfma(Enc1Args p) {
         const uint32_t tstride = (uint32_t)(p.Ho * p.Wo * 32);
         __half *const ob = p.out + (size_t)b * BN_T * tstride;
         uint8_t *const scr = smem + p.scr_off + wave * 1024;
+        // ---- the skip half of the last decoder block on this band's T = 0 slice (see Enc1Args::part), IN FRONT of the tile loop:
+        // behind it the phase's first LDS read sat behind `s_waitcnt vmcnt(0)` = the acknowledgement of the tile epilogues' stores
+        // (2.2 us per item, measured with the phase clock); here the only outstanding vector-memory operations are the weight
+        // fragments the tile loop waits for anyway.: grid rows u = ya .. yb - 1
+        // (the last band: + the row behind the image) x W + 1 columns, tiles of 16 positions, transposed (A = weights, B =
+        // activations: a lane < 16 ends up with the four parities of ITS position = a 2 x 2 block of output pixels).
+        // out[2u + py - cy][2v + px - cx] += sum_{a, b, c} skip[u - a][v - b][c] * w[py + 2a][px + 2b][c]
+        if (p.part) {
+            const int GW = p.W + 1;
+            const int ub = (band == p.nbands - 1) ? p.H + 1 : yb;
+            const int npos = (ub - ya) * GW;
+            const int nptiles = (npos + 15) / 16;
+            f32x4 *const pb = reinterpret_cast<f32x4 *>(p.part) + (size_t)b * (p.H + 1) * GW;
+            // a wave's tiles go through the phases together (addresses and LDS reads of all of them, then the products, then the
+            // stores): one LDS latency and one product latency per item instead of one per tile.  A band of E1_TR rows has at most
+            // 7 grid rows x 63 columns = 28 tiles: three per wave and a fourth for the first few waves (wave-uniform branch).  The
+            // phase is paid in issued instructions (four waves share a SIMD's issue port): ~25 per tile.
+            static_assert(((E1_TR - 1) * (E1_MAXW + 1) + 15) / 16 <= 4 * MG, "partial-logit tiles per wave");
+            const half8 wa0 = *reinterpret_cast<const half8 *>(cst + 512 + ll * 16), wa1 = *reinterpret_cast<const half8 *>(cst + 1536 + ll * 16);
+            // lane part of the fragment address: lane group kg = 2 * bb + channel half reads pixel column v + 1 - bb
+            const int lpart = (1 - (kg >> 1)) * 32 + (kg & 1) * 16 + (1 - y0) * E1_RS;
+            auto ptiles = [&](auto npt_tag, int first) {
+                constexpr int NPT = decltype(npt_tag)::value;
+                half8 b0[NPT], b1[NPT];
+                int pidx[NPT];
+#pragma unroll
+                for (int k = 0; k < NPT; k++) {
+                    const int q = (first + k * MG) * 16 + m;
+                    const int qc = min(q, npos - 1);
+                    const int ul = fdiv(qc, p.mGW), pv = qc - ul * GW;
+                    pidx[k] = q < npos ? ya * GW + q : -1;     // -1: a lane without a position
+                    // taps (a, bb): K step = a; input pixel (u - a, v - bb) = band row u - a - y0 + 1, column v - bb + 1 (the halo
+                    // columns / rows of the band hold zeros).  A row behind the image that the band does not hold (odd H: the row
+                    // of u = H) is read from the band's first halo pixel instead, which is zero in every row
+                    const int u = ya + ul;
+                    const int o1 = (u - 1) * E1_RS + pv * 32 + lpart;            // row u - 1 (a = 1)
+                    const int o0 = u >= p.H ? 0 : o1 + E1_RS;                    // row u (a = 0)
+                    b0[k] = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(smem + o0, 16));
+                    b1[k] = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(smem + o1, 16));
+                }
+                f32x4 pacc[NPT];
+#pragma unroll
+                for (int k = 0; k < NPT; k++) {
+                    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                    pacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa0, b0[k], z4, 0, 0, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < NPT; k++) pacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa1, b1[k], pacc[k], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < NPT; k++)
+                    if (kg == 0 && pidx[k] >= 0) pb[pidx[k]] = pacc[k];   // registers 0..3 of a lane < 16 = parities (py, px) = (r >> 1, r & 1)
+            };
+            if (wave + 2 * MG < nptiles) ptiles(std::integral_constant<int, 3>{}, wave);
+            else if (wave + MG < nptiles) ptiles(std::integral_constant<int, 2>{}, wave);
+            else if (wave < nptiles) ptiles(std::integral_constant<int, 1>{}, wave);
+            if (wave + 3 * MG < nptiles) ptiles(std::integral_constant<int, 1>{}, wave + 3 * MG);
+            PHASE_MARK(8);   // partial logits of the band
+        }
         for (int tile = wave; tile < (E1_ABL == 4 ? 0 : ntiles); tile += MG) {
             const int win = min(tile * 4 + (m >> 2), nwin - 1);
             const int wy = fdiv(win, p.mWp), wx = win - wy * p.Wp;
@@ -1623,11 +1698,14 @@ __global__ __launch_bounds__(((FINAL ? 1 : 4 * COUT / 32) > 4 ? 4 * COUT / 32 : 
                 const int u = u0 + ul;
                 // rows 0..3 = parities (py,px) = (r>>1, r&1): only the kh == 0 half holds them
                 if (kh == 0) {
+                    f32x4 pl = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (C2 == 0) pl = reinterpret_cast<const f32x4 *>(p.part)[((size_t)b * GH + u) * GW + v];
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int Y = 2 * u + (r >> 1) - p.cy, X = 2 * v + (r & 1) - p.cx;
                         if (Y >= 0 && Y < p.Hd && X >= 0 && X < p.Wd) {
-                            const float l = acc[r] + fbias;
+                            float l = acc[r] + fbias;
+                            if constexpr (C2 == 0) l += pl[r];
                             if (p.logits) p.logits[((size_t)b * p.Hd + Y) * p.Wd + X] = l;
                             mrows[(Y - Yb) * p.Wd + X] = l > 0.f ? 1 : 0;   // band mask, assembled in LDS
                         }
@@ -1962,13 +2040,17 @@ struct Dec3ccArgs {
     int area_thresh, max_boxes;
     int tile_bytes;            // one band buffer; two of them at LDS offsets 0 and tile_bytes
     int mfull_off, cc_off;     // LDS offsets of the frame's mask bytes and of bboxcc's region
+    int part_off;              // PART: LDS offset of the frame's partial logits (fp32 [Hd][Wd], DecArgs::part)
 };
 
 // WV: the run-based bboxcc body (bboxcc_wave.h) instead of the block-based one (bboxcc_body.h); one body per instantiation, so
 // that the kernel's single register allocation of 128 VGPRs (16 waves per CU) holds the tile loop and ONE bboxcc.
-template <bool WV>
+// PART (round 5): the block's input is its "up" half alone (16 channels, half the tile, half the products, the whole frame in
+// one buffer); the skip half's share of every logit comes as fp32 partial logits from the level-1 kernel (Enc1Args::part),
+// lands in LDS beside the tile and is added in the epilogue.
+template <bool WV, bool PART>
 __global__ __launch_bounds__(ccbody::CC_THREADS) void dec3cc_mfma(Dec3ccArgs q) {
-    constexpr int C1 = 16, C2 = 16, C = 32, NW = ccbody::CC_THREADS / 64;
+    constexpr int C1 = 16, C2 = PART ? 0 : 16, C = C1 + C2, NW = ccbody::CC_THREADS / 64;
     constexpr int KC = C / 16, KSTEPS = 4 * KC, CPP = C / 8, PS = C * 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const DecArgs &p = q.d;
@@ -2004,7 +2086,7 @@ __global__ __launch_bounds__(ccbody::CC_THREADS) void dec3cc_mfma(Dec3ccArgs q) 
                     const void *src = p.zero;
                     if (y >= 0 && y < p.Hi && x >= 0 && x < p.Wi) {
                         const size_t pix = (size_t)y * p.Wi + x;
-                        src = cb < C1 ? (const void *)(su + pix * C1 + cb) : (const void *)(ss + pix * C2 + (cb - C1));
+                        src = (PART || cb < C1) ? (const void *)(su + pix * C1 + cb) : (const void *)(ss + pix * C2 + (cb - C1));
                     }
                     glds16(src, buf + s0 * 16);
                 }
@@ -2012,6 +2094,12 @@ __global__ __launch_bounds__(ccbody::CC_THREADS) void dec3cc_mfma(Dec3ccArgs q) 
         };
         lds_barrier();   // the previous frame's bboxcc is done with the band buffers it reuses
         PHASE_MARK(0);
+        if constexpr (PART) {   // the frame's partial logits: one 16-byte piece per grid position
+            const uint8_t *ps = reinterpret_cast<const uint8_t *>(p.part) + (size_t)b * GH * GW * 16;
+            const int nch = GH * GW;
+            for (int s0 = wave * 64; s0 < nch; s0 += NW * 64)
+                if (s0 + lane < nch) glds16(ps + (size_t)(s0 + lane) * 16, smem + q.part_off + s0 * 16);
+        }
         stage(0, smem);
         PHASE_MARK(1);   // requesting band 0 (+ weights)
         for (int band = 0; band < p.nbands; band++) {
@@ -2046,11 +2134,14 @@ __global__ __launch_bounds__(ccbody::CC_THREADS) void dec3cc_mfma(Dec3ccArgs q) 
                     }
                 if (qi < npos && kh == 0) {   // rows 0..3 = the four output parities of position (u, v)
                     const int u = u0 + ul;
+                    f32x4 pl = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (PART) pl = reinterpret_cast<const f32x4 *>(smem + q.part_off)[u * GW + v];
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int Y = 2 * u + (r >> 1) - p.cy, X = 2 * v + (r & 1) - p.cx;
                         if (Y >= 0 && Y < p.Hd && X >= 0 && X < p.Wd) {
-                            const float l = acc[r] + fbias;
+                            float l = acc[r] + fbias;
+                            if constexpr (PART) l += pl[r];
                             if (p.logits) p.logits[((size_t)b * p.Hd + Y) * p.Wd + X] = l;
                             mfull[Y * p.Wd + X] = l > 0.f ? 1 : 0;
                         }
@@ -2191,26 +2282,41 @@ void prep_dec(int cin, int cout, const float *k, const float *bias, const float 
 
 // last block folded with the final 1x1 conv: logit = sum_c fk[c]*(convT_c(x) + b_c) + fb.
 // Rows 0..3 of the single 32-row tile are the four parities, the rest are zero.
+// folded weight of (parity n, tap (a, bb), input channel c): sum over the 16 intermediate channels
+float final_fold(int cin, int cout, const float *k, const float *fk, int n, int a, int bb, int c) {
+    const int ky = (n >> 1) + 2 * a, kx = (n & 1) + 2 * bb;
+    double sacc = 0.0;
+    for (int o = 0; o < cout; o++) sacc += (double)fk[o] * k[(((size_t)ky * 4 + kx) * cout + o) * cin + c];
+    return (float)sacc;
+}
+// cwin input channels starting at c0 (the whole concatenated input, or its "up" half alone)
 void prep_final(int cin, int cout, const float *k, const float *bias, const float *fk, const float *fb,
-                _Float16 *wfrag, float *epi) {
-    const int KC = cin / 16, KSTEPS = 4 * KC;
+                _Float16 *wfrag, float *epi, int c0 = 0, int cwin = 0) {
+    if (!cwin) cwin = cin;
+    const int KC = cwin / 16, KSTEPS = 4 * KC;
     for (int ks = 0; ks < KSTEPS; ks++)
         for (int l = 0; l < 64; l++)
             for (int j = 0; j < 8; j++) {
                 const int tap = ks / KC, kc = ks % KC, a = tap >> 1, bb = tap & 1;
-                const int c = kc * 16 + 8 * (l >> 5) + j, n = l & 31;
-                float w = 0.f;
-                if (n < 4) {
-                    const int ky = (n >> 1) + 2 * a, kx = (n & 1) + 2 * bb;
-                    double sacc = 0.0;
-                    for (int o = 0; o < cout; o++) sacc += (double)fk[o] * k[(((size_t)ky * 4 + kx) * cout + o) * cin + c];
-                    w = (float)sacc;
-                }
-                wfrag[((size_t)ks * 64 + l) * 8 + j] = f2h(w);
+                const int c = c0 + kc * 16 + 8 * (l >> 5) + j, n = l & 31;
+                wfrag[((size_t)ks * 64 + l) * 8 + j] = f2h(n < 4 ? final_fold(cin, cout, k, fk, n, a, bb, c) : 0.f);
             }
-    double bsum = fb[0];
-    for (int o = 0; o < cout; o++) bsum += (double)fk[o] * bias[o];
-    epi[0] = (float)bsum;
+    if (epi) {
+        double bsum = fb[0];
+        for (int o = 0; o < cout; o++) bsum += (double)fk[o] * bias[o];
+        epi[0] = (float)bsum;
+    }
+}
+// The skip half of the same fold for the level-1 kernel (enc1_mfma's partial logits): A fragments of v_mfma_f32_16x16x32_f16,
+// A[i][k] in lane 16 * (k / 8) + i; row i < 4 = output parity, one K step = the two taps (a, bb = 0 | 1) x 16 skip channels:
+// k = 16 * bb + (channel), K step s = a.
+void prep_tail(int cin, int cout, const float *k, const float *fk, int c0, _Float16 *wfrag) {
+    for (int s = 0; s < 2; s++)
+        for (int l = 0; l < 64; l++)
+            for (int j = 0; j < 8; j++) {
+                const int i = l & 15, kg = l >> 4, bb = kg >> 1, c = c0 + 8 * (kg & 1) + j;
+                wfrag[((size_t)s * 64 + l) * 8 + j] = f2h(i < 4 ? final_fold(cin, cout, k, fk, i, s, bb, c) : 0.f);
+            }
 }
 
 // ------------------------------------------------------------------ LDS bank-conflict model (host)
@@ -2442,6 +2548,8 @@ int blobnet_prepare_mfma(covahip_ctx *ctx, covahip_blobnet *m, const float *w) {
     pr->enc1w = off; off = align256(off + (size_t)2 * 5 * 64 * 16);
     pr->final_w = off; off = align256(off + (size_t)(4 * m->dec_ci[3] / 16) * 64 * 16);
     pr->final_epi = off; off = align256(off + 16 * sizeof(float));
+    pr->final_w_up = off; off = align256(off + (size_t)4 * 64 * 16);
+    pr->tail_w = off; off = align256(off + (size_t)2 * 64 * 16);
     pr->zero = off; off = align256(off + 256);
     pr->total = off;
 
@@ -2464,6 +2572,10 @@ int blobnet_prepare_mfma(covahip_ctx *ctx, covahip_blobnet *m, const float *w) {
                  (_Float16 *)(host.data() + pr->dec[j].wfrag), (float *)(host.data() + pr->dec[j].epi));
     prep_final(m->dec_ci[3], m->dec_co[3], hd[3].k, hd[3].b, fk, fb, (_Float16 *)(host.data() + pr->final_w),
                (float *)(host.data() + pr->final_epi));
+    if (m->dec_ci[3] == 32) {   // the last block's input = concat(up 16, skip 16): decoder.py:122-134
+        prep_final(32, m->dec_co[3], hd[3].k, hd[3].b, fk, fb, (_Float16 *)(host.data() + pr->final_w_up), nullptr, 0, 16);
+        prep_tail(32, m->dec_co[3], hd[3].k, fk, 16, (_Float16 *)(host.data() + pr->tail_w));
+    }
     COVAHIP_CHECK_HIP(ctx, hipMalloc(&m->d_prepared, off));
     COVAHIP_CHECK_HIP(ctx, hipMemcpy(m->d_prepared, host.data(), off, hipMemcpyHostToDevice));
     m->prepared_bytes = off;
@@ -2496,6 +2608,7 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
     const uint8_t *const d_frames = by_frames ? inp.frames : inp.stack;
     const int n_frames = by_frames ? inp.n_frames : batch * BN_T;
     const int32_t *const d_index = by_frames ? inp.index : nullptr;
+    bool part_written = false;   // the level-1 kernel wrote partial logits instead of the level-0 skip tensor
     if ((size_t)n_frames > ws.pbuf_frames && !dry) return COVAHIP_ERR_INVALID_ARG;   // (the caller sizes P: blobnet.hip)
     {
         const int H = m->lv[0].H, W = m->lv[0].W, Hp = H / 2, Wp = W / 2;
@@ -2599,6 +2712,11 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
                 const int grid = std::min(batch * nbands, 2 * num_cu);
                 a.plan = make_plan(grid, num_cu, 2, batch, nbands, Hp);
                 a.pidx = d_index; a.skip = act[1]; a.tm_pre = (const float *)(prep + pr->enc[0].epi) + 48;
+                // the level-0 skip connection as partial logits instead of a tensor (Enc1Args::part)
+                part_written = m->tail_part && ws.part && m->dec_ci[3] == 32 && m->dec_co[3] == 16 && m->enc_c[1] == 16;
+                a.part = part_written ? ws.part : nullptr;
+                a.wtail = (const half8 *)(prep + pr->tail_w);
+                a.mGW = magic(W + 1);
                 a.use_ktab = 0;
                 if (by_frames && inp.h_index && batch <= BN_KTAB_STACKS) {
                     a.use_ktab = 1;
@@ -2606,7 +2724,7 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
                 } else if (by_frames && !d_index && !dry) {
                     return COVAHIP_ERR_INVALID_ARG;
                 }
-                const size_t lds = (size_t)BN_T * E1_TSZ + 8 * 1024 + E1_CONST;
+                const size_t lds = (size_t)BN_T * E1_TSZ + 8 * 1024 + E1_CONST;   // (twice this fits a CU's 160 KB)
                 int rc = pr->allpos[1] ? set_lds(ctx, enc1_mfma<true>, lds) : set_lds(ctx, enc1_mfma<false>, lds);
                 if (rc) return rc;
                 ProfScope ps(ctx, "enc1_mfma");
@@ -2752,24 +2870,27 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
     for (int j = first_dec; j < BN_LEVELS; j++) {
         const BnLevelGeom in = m->lv[BN_LEVELS - j], out = m->lv[BN_LEVELS - 1 - j];
         const bool last = j == BN_LEVELS - 1;
+        const bool half = last && part_written;                 // the last block on its "up" half + partial logits
+        const int ci_j = half ? m->dec_ci[j] / 2 : m->dec_ci[j];
         DecArgs a;
         a.up = j == 0 ? nullptr : dact[j - 1];
         a.skip = act[BN_LEVELS - j];
         a.out = last ? nullptr : dact[j];
         a.logits = last ? d_logits : nullptr;
         a.mask = last ? d_mask : nullptr;
-        a.wfrag = (const half8 *)(prep + (last ? pr->final_w : pr->dec[j].wfrag));
+        a.wfrag = (const half8 *)(prep + (half ? pr->final_w_up : last ? pr->final_w : pr->dec[j].wfrag));
+        a.part = half ? ws.part : nullptr;
         a.epi = (const float *)(prep + (last ? pr->final_epi : pr->dec[j].epi));
         a.B = batch; a.Hi = in.H; a.Wi = in.W; a.Hd = out.H; a.Wd = out.W; a.cy = m->dec_cy[j]; a.cx = m->dec_cx[j];
         a.Ts = j == 0 ? 1 : BN_T;
         const int GH = in.H + 1;
-        const size_t row_bytes = (size_t)(in.W + 2) * m->dec_ci[j] * 2;
+        const size_t row_bytes = (size_t)(in.W + 2) * ci_j * 2;
         // band planner.  A workgroup keeps its M-tile's weight fragments in registers, so the weights
         // cross the L2 -> CU path once per workgroup: block 0 (256 KB of fragments per workgroup) runs
         // one workgroup per CU over whole frames.  The lighter blocks are bound by the latency of
         // stage -> barrier -> compute, which only other workgroups on the CU can hide: bands of at most
         // ~30 KB of LDS so that four to five of them are resident per CU.
-        const size_t wbytes = (size_t)(last ? 1 : 4 * m->dec_co[j] / 32) * (4 * m->dec_ci[j] / 16) * 1024;
+        const size_t wbytes = (size_t)(last ? 1 : 4 * m->dec_co[j] / 32) * (4 * ci_j / 16) * 1024;
         const bool heavy = wbytes >= 192 * 1024 && (size_t)(GH + 1) * row_bytes <= 72 * 1024;
         int nbands = 1;
         if (!heavy)
@@ -2777,8 +2898,8 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
                                    (long long)batch * nbands < 2LL * num_cu))
                 nbands++;
         a.nbands = nbands; a.mNb = magic(nbands); a.mGW = magic(in.W + 1);
-        a.mRC = magic((in.W + 2) * (m->dec_ci[j] / 8)); a.zero = prep + pr->zero;
-        a.swz = choose_swz(false, m->dec_ci[j], in.W, 0, (GH + nbands - 1) / nbands);
+        a.mRC = magic((in.W + 2) * (ci_j / 8)); a.zero = prep + pr->zero;
+        a.swz = choose_swz(false, ci_j, in.W, 0, (GH + nbands - 1) / nbands);
         const size_t tile_bytes = (((size_t)((GH + nbands - 1) / nbands) + 1) * row_bytes + 15) & ~(size_t)15;
         const size_t mask_bytes = last ? ((((size_t)2 * ((GH + nbands - 1) / nbands) * out.W) + 15) & ~(size_t)15) : 0;
         const size_t scr_bytes = last ? 0 : (size_t)std::max(4, 4 * m->dec_co[j] / 32) * 2048;   // one 2 KB transpose scratch per wave
@@ -2814,12 +2935,13 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
                        if (t.use_wv) cc_bytes = (size_t)t.wg.wave_bytes;
                        if (!cc_bytes) return false;
                        const size_t mfull = ((size_t)out.H * out.W + 15) & ~(size_t)15;
+                       const size_t partb = half ? (size_t)GH * (in.W + 1) * 16 : 0;   // partial logits beside the mask
                        int best_nb = 0;
                        long long best_cost = -1;
                        for (int nb = 1; nb <= GH; nb++) {
                            const size_t tb = (((size_t)((GH + nb - 1) / nb) + 1) * row_bytes + 15) & ~(size_t)15;
                            const size_t nbuf = nb == 1 ? 1 : 2;   // the whole frame in one buffer when it fits
-                           if (std::max(nbuf * tb, cc_bytes) + mfull > 160 * 1024 - 512) continue;
+                           if (std::max(nbuf * tb, cc_bytes) + mfull + partb > 160 * 1024 - 512) continue;
                            long long rounds = 0;   // tiles of 32 positions over 16 waves, band by band
                            for (int k = 0; k < nb; k++) {
                                const int nu = (k + 1) * GH / nb - k * GH / nb;
@@ -2832,19 +2954,33 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
                        const size_t tb = (((size_t)((GH + best_nb - 1) / best_nb) + 1) * row_bytes + 15) & ~(size_t)15;
                        t.d = a;
                        t.d.nbands = best_nb; t.d.mNb = magic(best_nb);
-                       t.d.swz = choose_swz(false, m->dec_ci[j], in.W, 0, (GH + best_nb - 1) / best_nb);
+                       t.d.swz = choose_swz(false, ci_j, in.W, 0, (GH + best_nb - 1) / best_nb);
                        t.boxes = cc->boxes; t.counts = cc->counts;
                        t.area_thresh = cc->area_thresh; t.max_boxes = cc->max_boxes;
                        t.tile_bytes = (int)tb; t.cc_off = 0;
                        t.mfull_off = (int)std::max((best_nb == 1 ? 1 : 2) * tb, cc_bytes);
-                       const size_t tl = (size_t)t.mfull_off + mfull;
-                       if (t.use_wv ? set_lds(ctx, dec3cc_mfma<true>, tl) : set_lds(ctx, dec3cc_mfma<false>, tl)) return false;
+                       t.part_off = (int)((size_t)t.mfull_off + mfull);
+                       const size_t tl = (size_t)t.part_off + partb;
+                       const dim3 grid3(std::min(batch, 2 * num_cu)), wg3(ccbody::CC_THREADS);
+                       if (half) {
+                           if (t.use_wv ? set_lds(ctx, dec3cc_mfma<true, true>, tl) : set_lds(ctx, dec3cc_mfma<false, true>, tl)) return false;
+                           ProfScope ps(ctx, "dec3_bboxcc_fused");
+                           if (t.use_wv) LAUNCH((dec3cc_mfma<true, true>), grid3, wg3, tl, ctx->stream, t);
+                           else LAUNCH((dec3cc_mfma<false, true>), grid3, wg3, tl, ctx->stream, t);
+                           return true;
+                       }
+                       if (t.use_wv ? set_lds(ctx, dec3cc_mfma<true, false>, tl) : set_lds(ctx, dec3cc_mfma<false, false>, tl)) return false;
                        ProfScope ps(ctx, "dec3_bboxcc_fused");
-                       if (t.use_wv) LAUNCH(dec3cc_mfma<true>, dim3(std::min(batch, 2 * num_cu)), dim3(ccbody::CC_THREADS), tl, ctx->stream, t);
-                       else LAUNCH(dec3cc_mfma<false>, dim3(std::min(batch, 2 * num_cu)), dim3(ccbody::CC_THREADS), tl, ctx->stream, t);
+                       if (t.use_wv) LAUNCH((dec3cc_mfma<true, false>), grid3, wg3, tl, ctx->stream, t);
+                       else LAUNCH((dec3cc_mfma<false, false>), grid3, wg3, tl, ctx->stream, t);
                        return true;
                    }()) {
             if (cc_done) *cc_done = true;
+        } else if (half) {
+            rc = set_lds(ctx, dec_mfma<16, 0, 16, true>, lds);
+            if (rc) return rc;
+            ProfScope ps(ctx, "dec3_final_mfma");
+            LAUNCH((dec_mfma<16, 0, 16, true>), dim3(grid), dim3(256), lds, ctx->stream, a);
         } else {
             rc = set_lds(ctx, dec_mfma<16, 16, 16, true>, lds);
             if (rc) return rc;

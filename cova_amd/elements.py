@@ -181,8 +181,10 @@ class BlobNetInfer:
         ("dec_separate"); "enc1_legacy": encoder level 1 on the 32x32x16 kernel instead of the sixteen-channel-wave one;
         "enc_general_tiles": encoder levels 2 and 3 on the general tile form instead of the row-aligned one;
         "enc23_separate" / "enc23_force": encoder levels 2 + 3 always as two launches / as one launch (enc23_mfma) whenever it
-        fits (the default takes the single launch when the batch fills the chip and the rows fill their tile columns)."""
-        L.check(self._lib.covahip_blobnet_set_impl(self.ctx.handle, {"mfma": 1, "dec_separate": 4, "enc1_legacy": 5, "enc_general_tiles": 6, "enc23_separate": 7, "enc23_force": 8}[impl]), "set_impl")
+        fits (the default takes the single launch when the batch fills the chip and the rows fill their tile columns);
+        "tail_skip_tensor": the last decoder block reads the level-0 skip tensor (rounds 1-4) instead of the partial logits the
+        level-1 kernel computes from it (round 5 default; another summation order, not another value)."""
+        L.check(self._lib.covahip_blobnet_set_impl(self.ctx.handle, {"mfma": 1, "dec_separate": 4, "enc1_legacy": 5, "enc_general_tiles": 6, "enc23_separate": 7, "enc23_force": 8, "tail_skip_tensor": 9}[impl]), "set_impl")
 
     @property
     def macs_per_frame(self) -> int:

@@ -345,6 +345,41 @@ def test_fused_decoder_blocks_match_separate_launches_bitwise(ctx, weights_flat,
         np.testing.assert_array_equal(boxes[i, :counts[i]], boxes2[i, :counts[i]])
 
 
+@pytest.mark.parametrize("hw", [(68, 120), (67, 120), (45, 80), (35, 60), (61, 100)])
+@pytest.mark.parametrize("mixed_gamma", [False, True])
+def test_tail_partial_logits_match_the_skip_tensor_form(ctx, weights_flat, hw, mixed_gamma):
+    """Round 5: the last decoder block is linear in concat(up, skip) (decoder.py:122-134 -> final 1x1 conv, blobnet.py:44-48, no
+    non-linearity between them), so the level-1 kernel computes the skip half's share of every logit from the T = 0 slice it
+    holds in LDS and the fused tail adds those fp32 partial logits to its "up" half -- the level-0 skip TENSOR never crosses
+    HBM.  Against the round-1..4 form (developer switch "tail_skip_tensor": the tail reads the tensor): the same fp16 operands
+    and fp32 products, only the order of the fp32 additions differs -> logits equal to a few ulp of the largest term, masks
+    equal wherever the logit is not within that distance of zero; both entries, odd / even grids (crop offsets, the grid row
+    behind an odd image), infer() and filter() identical to each other in both forms."""
+    h, w = hw
+    b = 12
+    flat = _mixed_gamma_weights(57) if mixed_gamma else weights_flat
+    stack = synth.stacked_batch(b, h, w, seed=41, streams=2)
+    frames, index = synth.carrier_batch(b, h, w, seed=41, streams=2)
+    net = BlobNetInfer(ctx, flat, h, w, max_batch=b)
+    logits, mask = net.infer(stack)
+    got = net.filter_frames(frames, index, 1, max_boxes=2048, want_mask=True, want_logits=True)
+    np.testing.assert_array_equal(got[3], logits)          # carrier-frame entry + fused tail == stacked entry + stand-alone last block
+    np.testing.assert_array_equal(got[2], mask)
+    net.set_impl("tail_skip_tensor")
+    try:
+        logits2, mask2 = net.infer(stack)
+        got2 = net.filter_frames(frames, index, 1, max_boxes=2048, want_mask=True, want_logits=True)
+    finally:
+        net.set_impl("mfma")
+    np.testing.assert_array_equal(got2[3], logits2)
+    scale = float(np.abs(logits2).max())
+    err = np.abs(logits - logits2)
+    assert err.max() <= 4e-6 * scale + 1e-6, (err.max(), scale)
+    differ = mask != mask2
+    assert (np.abs(logits2)[differ] <= 4e-6 * scale + 1e-6).all()
+    assert differ.mean() < 1e-3
+
+
 def test_fused_encoder_levels_2_3_more_frames_than_workgroups(ctx, weights_flat):
     """enc23_mfma is persistent over frames (grid = min(batch, CUs)): 600 frames on 256 CUs take two to three frames per
     workgroup -- the band's borders stay zero, the ring and the store scratch are reused -- and give the bits of the two

@@ -30,7 +30,7 @@ lib = ctypes.CDLL(L.LIB_PATH)
 out = (ctypes.c_ulonglong * 80)()
 names = ["bookkeeping", "barrier (previous item)", "DMA issue", "band landing", "temporal MLP in place", "skip slice out", "tiles: matrix part", "tiles: epilogue", "weights into registers (kernel start)"]
 E23_NAMES = ["frame start: barrier, first six rows", "level 2: barrier A (+ weights at step 0)", "level 2: products, pooling", "level 2: barrier B", "level 2: next rows into the ring", "level 2: temporal MLP, band writes", "between the levels: weights, barrier, T = 0 out", "level 3: products + pooling", "level 3: epilogue"]
-E1V_NAMES = ["bookkeeping, addresses, loads issued", "barrier (previous item)", "loads landing", "temporal MLP, LDS writes, skip stores", "barrier (band complete)", "weights landing", "tiles: matrix part", "tiles: epilogue", "-"]
+E1V_NAMES = ["bookkeeping, addresses, loads issued", "barrier (previous item)", "loads landing", "temporal MLP, LDS writes, skip stores", "barrier (band complete)", "weights landing", "tiles: matrix part", "tiles: epilogue", "partial logits (tail skip half)"]
 steps = 20
 for _ in range(3):
     net.filter_frames_device(d_frames, frames.shape[0], index, B, 1, d_boxes, d_counts, 256, d_mask)
