@@ -489,12 +489,12 @@ def pipelined_host_rate(net, frames, index, steps):
     return res
 
 
-def element_rate(script="element_bench.sh", args=("20000", "8", str(CC_THRESHOLD))):
+def element_rate(script="element_bench.sh", args=("20000", "8", str(CC_THRESHOLD)), env=None):
     """frames/s through the GStreamer elements (tools/element_bench.sh: the batching element alone; tools/chain_bench.sh: the
     batching element + one cova element per stream = BASELINE config 4); a child process with its own ctx."""
     try:
         r = subprocess.run(["bash", os.path.join(ROOT, "tools", script), *args],
-                           capture_output=True, text=True, timeout=180)
+                           capture_output=True, text=True, timeout=180, env=dict(os.environ, **(env or {})))
         for line in r.stdout.splitlines():
             if line.startswith("{"):
                 return json.loads(line)
@@ -545,7 +545,13 @@ def main():
             pre["through_gstreamer_elements"] = element_rate()
             # BASELINE config 4: metapreprocess -> BlobNet -> bboxcc -> cova (embedded SORT + GoP filter) per stream, the
             # experiment's tracker parameters, blob-like weights (a few boxes per frame, as a trained BlobNet gives)
-            chain = element_rate("chain_bench.sh", ("60000", "16"))
+            # (round 5: the streams hand `blobnetfilter` packed two-byte records -- caps application/x-cova-records, what
+            # `h264entropydec records=true` emits -- instead of I420-sized carrier frames; the I420 form is measured beside it)
+            chain = element_rate("chain_bench.sh", ("60000", "16"), env={"CHAINBENCH_RECORDS": "1"})
+            chain_i420 = element_rate("chain_bench.sh", ("60000", "16"), env={"CHAINBENCH_RECORDS": "0"})
+            if "frames_per_s_full_chain" in chain:
+                chain["input"] = "application/x-cova-records (packed two-byte records per macroblock)"
+                chain["frames_per_s_full_chain_i420_carrier_frames"] = chain_i420.get("frames_per_s_full_chain")
             if "frames_per_s_full_chain" in chain:
                 t_cova = chain["seconds"] * min(16, effective_cores()) / max(1, chain["frames_in"])
                 chain["limiter"] = ("host: every core of the box's share is busy (the per-stream cova elements -- SORT with the "

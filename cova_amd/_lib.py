@@ -105,6 +105,7 @@ PROTOTYPES = {
     "covahip_pipe_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "covahip_pipe_destroy": (None, [_P]),
     "covahip_pipe_set_packed": (C.c_int, [_P, C.c_int]),
+    "covahip_pipe_set_blocking_wait": (C.c_int, [_P, C.c_int]),
     "covahip_pipe_acquire": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(_P)]),
     "covahip_pipe_submit": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "covahip_pipe_wait": (C.c_int, [_P, C.c_int]),

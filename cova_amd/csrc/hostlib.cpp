@@ -889,6 +889,14 @@ constexpr uint64_t SECOND = 1000000000ull;
 struct covahip_gopfilter {
     covahip_gopfilter_cfg cfg;
     std::list<Gop> bufs;
+    // The reference walks ALL buffered GoPs on every mask buffer (imp.rs:135-315).  Its encoded branch runs ahead of the mask branch
+    // through an unbounded queue (pipeline.py:237-253), so hundreds of GoPs can be waiting: 23 - 28 % of the chain's CPU samples
+    // sat in these walks with 1,200 GoPs buffered per stream.  While the GoPs' pts ranges are in order -- every GoP opened so far
+    // started at or behind the largest pts of the one before it, which is what a stream of closed GoPs gives -- a walk may stop at
+    // the first GoP that lies wholly on the far side of the range it looks for: the same GoPs are visited in the same order, the
+    // rest would have been skipped by the reference's own tests.  `ordered` turns false for good on the first GoP that breaks the
+    // rule (and on any pts that lowers a GoP's minimum below its predecessor's maximum); the full walks run from then on.
+    bool ordered = true;
     Sort *sort = nullptr;
     bool have_range_start = false;
     uint64_t range_start = 0;
@@ -970,7 +978,10 @@ void covahip_gopfilter_free(covahip_gopfilter *g) { delete g; }
 int covahip_gopfilter_push_enc(covahip_gopfilter *g, uint64_t id, uint64_t pts, uint32_t flags) {
     if (!g) return COVAHIP_ERR_INVALID_ARG;
     if (!(flags & COVAHIP_AU_DELTA_UNIT)) {  // imp.rs:327-347: key frame opens a GoP
-        if (!g->bufs.empty()) g->bufs.back().finalized = true;
+        if (!g->bufs.empty()) {
+            g->bufs.back().finalized = true;
+            if (pts < g->bufs.back().max) g->ordered = false;
+        }
         Gop gop;
         gop.min = gop.max = pts;
         gop.finalized = false;
@@ -979,8 +990,10 @@ int covahip_gopfilter_push_enc(covahip_gopfilter *g, uint64_t id, uint64_t pts, 
     } else {  // imp.rs:348-358
         if (g->bufs.empty()) return COVAHIP_ERR_BAD_DATA;  // reference: unwrap() panic
         Gop &back = g->bufs.back();
-        if (pts < back.min) back.min = pts;
-        else if (pts > back.max) back.max = pts;
+        if (pts < back.min) {
+            back.min = pts;
+            if (g->bufs.size() > 1 && pts < std::prev(g->bufs.end(), 2)->max) g->ordered = false;
+        } else if (pts > back.max) back.max = pts;
         back.in.push_back(Au{id, pts, flags});
     }
     return COVAHIP_OK;
@@ -1018,6 +1031,7 @@ int covahip_gopfilter_push_boxes(covahip_gopfilter *g, const covahip_bbox *boxes
         uint64_t dd = 0, di = 0;
         for (auto it = g->bufs.rbegin(); it != g->bufs.rend(); ++it) {
             Gop &gop = *it;
+            if (g->ordered && gop.max < min_track_pts) break;   // newest first: every older GoP ends even earlier
             if (!(min_track_pts <= gop.max && gop.min <= max_track_pts)) continue;
             bool already = false;
             for (const Au &a : gop.out)
@@ -1050,6 +1064,7 @@ int covahip_gopfilter_push_boxes(covahip_gopfilter *g, const covahip_bbox *boxes
         if (track_inferenced < (size_t)g->cfg.beta) {  // imp.rs:200-246
             for (auto it = g->bufs.rbegin(); it != g->bufs.rend(); ++it) {
                 Gop &gop = *it;
+                if (g->ordered && gop.max < min_track_pts) break;
                 if (!(min_track_pts <= gop.max && gop.min <= max_track_pts)) continue;
                 if (gop.out.empty()) continue;
                 const size_t extra_decode = std::min(gop.in.size(), (size_t)g->cfg.alpha);
@@ -1095,6 +1110,7 @@ int covahip_gopfilter_push_boxes(covahip_gopfilter *g, const covahip_bbox *boxes
     const uint64_t droppable_pts = pts >= gop_pts ? pts - gop_pts : 0;
     for (auto it = g->bufs.begin(); it != g->bufs.end();) {
         Gop &gop = *it;
+        if (g->ordered && gop.max > droppable_pts) break;   // oldest first: every newer GoP ends even later
         if (!(gop.finalized && gop.max <= droppable_pts)) {
             ++it;
             continue;

@@ -175,6 +175,24 @@ int covahip_pipe_set_packed(covahip_pipe *p, int on) {
     return COVAHIP_OK;
 }
 
+// hipEventSynchronize spins on the completion signal by default: a collector thread that waits for the GPU most of the time
+// then burns a whole core doing so (13 - 16 % of the chain's CPU samples sat in the HSA runtime, tools/prof_resolve.py).  With
+// blocking waits the slot's "results are in host memory" event is created with hipEventBlockingSync and the waiting thread
+// sleeps until the completion interrupt; several slots are in flight, so the wake-up latency is not on the critical path.
+int covahip_pipe_set_blocking_wait(covahip_pipe *p, int on) {
+    if (!p) return COVAHIP_ERR_INVALID_ARG;
+    for (const Slot &s : p->slots)
+        if (s.state != 0) return COVAHIP_ERR_INVALID_ARG;   // not with slots acquired or in flight
+    if (hipSetDevice(p->ctx->device) != hipSuccess) return COVAHIP_ERR_HIP;
+    for (Slot &s : p->slots) {
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming | (on ? hipEventBlockingSync : 0)) != hipSuccess) return COVAHIP_ERR_HIP;
+        if (s.ev_out) hipEventDestroy(s.ev_out);
+        s.ev_out = ev;
+    }
+    return COVAHIP_OK;
+}
+
 int covahip_pipe_acquire(covahip_pipe *p, int *slot, uint8_t **frames, int32_t **stack_index) {
     if (!p || !slot || !frames || !stack_index) return COVAHIP_ERR_INVALID_ARG;
     for (int k = 0; k < p->n_slots; k++) {

@@ -8,6 +8,7 @@
  *        'M' bbox buffer for cova.sink_mask, 'e' EOS on sink_enc, 'm' EOS on sink_mask.
  * Output records: 'B' (pts, flags = GstBufferFlags, payload) and for cova 'L' (start of a BufferList).
  */
+#define _GNU_SOURCE
 #include <gst/check/gstharness.h>
 #include <gst/gst.h>
 #include <stdint.h>
@@ -364,6 +365,63 @@ static int run_muxbench(const char *desc, int n_pads, int w_px, int h_px, int fr
     return 0;
 }
 
+/* CHAINBENCH_PROF=1: a sampling profile of the whole process without tools the image lacks (no perf / gdb here): ITIMER_PROF
+ * delivers SIGPROF to whichever thread is burning CPU, the handler notes the interrupted program counter, and at the end the
+ * samples are attributed to the nearest preceding dynamic symbol (dladdr) -- where the host cores of the chain go, by function. */
+#define _PROF_MAX 400000
+#include <dlfcn.h>
+#include <signal.h>
+#include <sys/time.h>
+#include <ucontext.h>
+static void *prof_pc[_PROF_MAX];
+static volatile gint prof_n;
+static void prof_handler(int sig, siginfo_t *si, void *uc_) {
+    ucontext_t *uc = uc_;
+    const gint k = g_atomic_int_add(&prof_n, 1);
+    if (k < _PROF_MAX) prof_pc[k] = (void *)uc->uc_mcontext.gregs[REG_RIP];
+}
+static void prof_start(void) {
+    struct sigaction sa;
+    struct itimerval it = {{0, 500}, {0, 500}};   /* 2 kHz of CPU time */
+    memset(&sa, 0, sizeof sa);
+    sa.sa_sigaction = prof_handler;
+    sa.sa_flags = SA_SIGINFO | SA_RESTART;
+    sigaction(SIGPROF, &sa, NULL);
+    setitimer(ITIMER_PROF, &it, NULL);
+}
+static void prof_report(void) {
+    struct itimerval off = {{0, 0}, {0, 0}};
+    struct { const char *name; const char *lib; int n; } acc[512];
+    int na = 0, n = MIN(prof_n, _PROF_MAX);
+    setitimer(ITIMER_PROF, &off, NULL);
+    for (int i = 0; i < n; i++) {
+        Dl_info di;
+        const char *nm = "?", *lb = "?";
+        if (dladdr(prof_pc[i], &di)) { nm = di.dli_sname ? di.dli_sname : "(static)"; lb = di.dli_fname ? di.dli_fname : "?"; }
+        int k = 0;
+        for (; k < na; k++) if (!strcmp(acc[k].name, nm) && !strcmp(acc[k].lib, lb)) break;
+        if (k == na && na < 512) { acc[na].name = nm; acc[na].lib = lb; acc[na].n = 0; na++; }
+        if (k < 512) acc[k].n++;
+    }
+    if (getenv("CHAINBENCH_PROF_RAW")) {   /* "library offset" per sample: resolved offline with nm (tools/prof_resolve.py) */
+        FILE *f = fopen(getenv("CHAINBENCH_PROF_RAW"), "w");
+        for (int i = 0; f && i < n; i++) {
+            Dl_info di;
+            if (dladdr(prof_pc[i], &di) && di.dli_fname) fprintf(f, "%s %lx\n", di.dli_fname, (unsigned long)((char *)prof_pc[i] - (char *)di.dli_fbase));
+            else fprintf(f, "? %lx\n", (unsigned long)prof_pc[i]);
+        }
+        if (f) fclose(f);
+    }
+    fprintf(stderr, "profile: %d samples\n", n);
+    for (int r = 0; r < 40; r++) {
+        int best = -1;
+        for (int k = 0; k < na; k++) if (acc[k].n > 0 && (best < 0 || acc[k].n > acc[best].n)) best = k;
+        if (best < 0) break;
+        const char *b = strrchr(acc[best].lib, '/');
+        fprintf(stderr, "  %5.1f %%  %-48s %s\n", 100.0 * acc[best].n / n, acc[best].name, b ? b + 1 : acc[best].lib);
+        acc[best].n = 0;
+    }
+}
 /* CPU seconds per thread name of this process (/proc/self/task): where the host time of a bench run went */
 #include <dirent.h>
 static void print_thread_cpu(const char *tag) {
@@ -394,6 +452,25 @@ static void print_thread_cpu(const char *tag) {
     fprintf(stderr, "cpu seconds by thread name (%s):", tag);
     for (int k = 0; k < na; k++) fprintf(stderr, " %s x%d %.2f;", acc[k].name, acc[k].n, acc[k].sec);
     fprintf(stderr, "\n");
+}
+/* CHAINBENCH_RECORDS=1: the feeders hand over packed two-byte records (caps application/x-cova-records: what `h264entropydec
+ * records=true` emits) instead of four-byte carrier regions -- the buffers of a feed are replaced by their packed form */
+static void pack_feed(GstBuffer **bufs, int n, int wmb, int hmb) {
+    for (int k = 0; k < n; k++) {
+        GstMapInfo mi, mo;
+        GstBuffer *nb = gst_buffer_new_allocate(NULL, (gsize)wmb * hmb * 2, NULL);
+        gst_buffer_map(bufs[k], &mi, GST_MAP_READ);
+        gst_buffer_map(nb, &mo, GST_MAP_WRITE);
+        /* covahip_carrier_pack's format (include/covahip.h), written out here: the driver does not link the library */
+        for (gsize q = 0; q < (gsize)wmb * hmb; q++) {
+            const guint8 *r = mi.data + 4 * q;
+            ((uint16_t *)mo.data)[q] = (uint16_t)(MIN(r[0], 6) | MIN(r[1], 6) << 3 | MIN(r[2], 6) << 6);
+        }
+        gst_buffer_unmap(nb, &mo);
+        gst_buffer_unmap(bufs[k], &mi);
+        gst_buffer_unref(bufs[k]);
+        bufs[k] = nb;
+    }
 }
 /* ---- chainbench: BASELINE config 4 as a throughput number.  N streams -> blobnetfilter (metapreprocess + nvstreammux + nvinfer +
  * nvstreamdemux + maskcopy + bboxcc stand-in) -> per stream a `cova` element (embedded SORT + GoP frame filter) whose sink_enc gets
@@ -478,7 +555,9 @@ static int run_chainbench(const char *desc, const char *cova_props, int n_pads, 
     enc_feed_t encs[64];
     static chain_out_t outs[64];
     GThread *th[64], *eth[64];
-    gchar *caps = g_strdup_printf("video/x-raw,format=I420,width=%d,height=%d,framerate=30/1", w_px, h_px);
+    const int records = getenv("CHAINBENCH_RECORDS") && atoi(getenv("CHAINBENCH_RECORDS"));
+    gchar *caps = records ? g_strdup_printf("application/x-cova-records,width-mbs=%d,height-mbs=%d,framerate=30/1", w_px / 16, h_px / 16)
+                          : g_strdup_printf("video/x-raw,format=I420,width=%d,height=%d,framerate=30/1", w_px, h_px);
     gchar *cdesc = g_strdup_printf("cova %s", cova_props);
     guint64 batches = 0;
     const int cycle = 256;
@@ -495,6 +574,7 @@ static int run_chainbench(const char *desc, const char *cova_props, int n_pads, 
         feeds[i].n_bufs = cycle;
         feeds[i].bufs = g_new(GstBuffer *, cycle);
         chain_make_frames(feeds[i].bufs, cycle, w_px / 16, h_px / 16, 1000u + (unsigned)i);
+        if (records) pack_feed(feeds[i].bufs, cycle, w_px / 16, h_px / 16);
         encs[i].src = gst_pad_new("enc", GST_PAD_SRC);
         gst_pad_set_element_private(tsink, &outs[i]);
         gst_pad_set_chain_function(tsink, chainb_chain);
@@ -525,11 +605,13 @@ static int run_chainbench(const char *desc, const char *cova_props, int n_pads, 
         for (int i = 0; i < n_pads; i++) g_thread_join(eth[i]);
         for (int i = 0; i < n_pads; i++) { feeds[i].first = first; feeds[i].n_frames = n; feeds[i].eos = phase; }
         if (phase) t0 = g_get_monotonic_time();
+        if (phase && getenv("CHAINBENCH_PROF")) prof_start();
         for (int i = 0; i < n_pads; i++) th[i] = g_thread_new("feed", bench_feeder, &feeds[i]);
         for (int i = 0; i < n_pads; i++) g_thread_join(th[i]);
         if (phase) t1 = g_get_monotonic_time(); else g_usleep(300000);
     }
     g_usleep(200000);   /* the last batches drain through the pusher threads */
+    if (getenv("CHAINBENCH_PROF")) prof_report();
     if (getenv("CHAINBENCH_CPU")) {
         print_thread_cpu("live threads at the end");
         fprintf(stderr, "cpu seconds of the carrier-frame feeders (both phases): %.2f; wall seconds of the timed phase %.3f\n", feeder_cpu_us * 1e-6, (t1 - t0) * 1e-6);

@@ -43,6 +43,7 @@ typedef struct {
     gint hist_pos[BF_TIMESTEP - 1];  /* their position in the slot being filled, -1 = not copied into it yet */
     guint n_seen;
     gboolean eos, caps_sent;
+    gboolean records;                 /* sink caps application/x-cova-records: buffers are packed two-byte records already */
     gint src_ret;                     /* last GstFlowReturn of a push on src that was neither OK nor NOT_LINKED (atomic) */
 } BfPad;
 
@@ -138,6 +139,8 @@ static gboolean bf_ensure_model(GstBlobNetFilter *s) {   /* lock held */
     g_free(blob);
     if (rc == COVAHIP_OK) rc = covahip_pipe_create(s->ctx, (int)s->batch_size, BF_TIMESTEP * (int)s->batch_size, (int)s->max_boxes, BF_SLOTS, 0, &s->pipe);
     if (rc == COVAHIP_OK) rc = covahip_pipe_set_packed(s->pipe, 1);
+    /* the collector sleeps while it waits for the GPU instead of spinning on the completion signal (BLOBNETFILTER_SPIN=1: the old way) */
+    if (rc == COVAHIP_OK && !g_getenv("BLOBNETFILTER_SPIN")) rc = covahip_pipe_set_blocking_wait(s->pipe, 1);
     if (rc == COVAHIP_OK) rc = covahip_pipe_acquire(s->pipe, &s->slot, &s->pf, &s->pi);
     if (rc != COVAHIP_OK) {
         GST_ELEMENT_ERROR(s, LIBRARY, INIT, ("covahip: %s (%s)", covahip_strerror(rc), covahip_last_hip_error(s->ctx)), (NULL));
@@ -420,10 +423,14 @@ static gboolean bf_try_reserve(GstBlobNetFilter *s, BfPad *p, GstBuffer *buf, ui
  * submitting a batch, waiting for a free slot. */
 /* FALSE: the buffer could not be mapped.  The slot position is already reserved (the batch's bookkeeping must complete), so it
  * is zeroed -- and the caller reports the failure: a warning on the bus and GST_FLOW_ERROR upstream, never a silent empty frame. */
-static gboolean bf_pack_into(GstBuffer *buf, uint16_t *dst, gsize frame_bytes) {
+static gboolean bf_pack_into(GstBuffer *buf, uint16_t *dst, gsize frame_bytes, gboolean records) {
     GstMapInfo mi;
     if (gst_buffer_map(buf, &mi, GST_MAP_READ)) {
-        covahip_carrier_pack(mi.data, frame_bytes / 4, dst);
+        /* application/x-cova-records (round 5): the producer -- h264entropydec records=true, or any front end that writes
+         * covahip_carrier_pack's form -- hands over the two-byte records themselves: a 16 KB copy at 1080p instead of reading a
+         * 32 KB carrier region and packing it (the feeders' 6.4 us per frame of the round-4 chain) */
+        if (records) memcpy(dst, mi.data, frame_bytes / 2);
+        else covahip_carrier_pack(mi.data, frame_bytes / 4, dst);
         gst_buffer_unmap(buf, &mi);
         return TRUE;
     }
@@ -444,7 +451,7 @@ static GstFlowReturn bf_chain(GstPad *pad, GstObject *parent, GstBuffer *buf) {
         const gint own = g_atomic_int_get(&p->src_ret);
         if (own == GST_FLOW_EOS || own == GST_FLOW_FLUSHING) { gst_buffer_unref(buf); return (GstFlowReturn)own; }
     }
-    if (gst_buffer_get_size(buf) < s->frame_bytes || !s->frame_bytes) {
+    if (gst_buffer_get_size(buf) < (p->records ? s->frame_bytes / 2 : s->frame_bytes) || !s->frame_bytes) {
         GST_ELEMENT_ERROR(s, STREAM, FORMAT, ("carrier frame of %" G_GSIZE_FORMAT " bytes, need %" G_GSIZE_FORMAT " (caps set?)",
                                               gst_buffer_get_size(buf), s->frame_bytes), (NULL));
         gst_buffer_unref(buf);
@@ -481,10 +488,10 @@ static GstFlowReturn bf_chain(GstPad *pad, GstObject *parent, GstBuffer *buf) {
 
     /* metapreprocess copies these bytes (imp.rs:311-312); here they go into the slot as two-byte records (covahip_carrier_pack:
      * what BlobNet keeps of them), so that the host-to-device copy -- the bound of this element -- moves half the bytes */
-    gboolean mapped = bf_pack_into(buf, (uint16_t *)(pf + (gsize)pos * (s->frame_bytes / 2)), s->frame_bytes);
+    gboolean mapped = bf_pack_into(buf, (uint16_t *)(pf + (gsize)pos * (s->frame_bytes / 2)), s->frame_bytes, p->records);
     for (int k = 0; k < BF_TIMESTEP - 1; k++)
         if (need[k]) {
-            mapped &= bf_pack_into(need[k], (uint16_t *)(pf + (gsize)need_pos[k] * (s->frame_bytes / 2)), s->frame_bytes);
+            mapped &= bf_pack_into(need[k], (uint16_t *)(pf + (gsize)need_pos[k] * (s->frame_bytes / 2)), s->frame_bytes, p->records);
             gst_buffer_unref(need[k]);
         }
     __atomic_fetch_add(&s->done, (guint64)taken, __ATOMIC_RELEASE);
@@ -537,11 +544,24 @@ static gboolean bf_sink_event(GstPad *pad, GstObject *parent, GstEvent *ev) {
         GstCaps *caps, *out;
         GstVideoInfo vi;
         gboolean ok;
+        gint w = 0, h = 0;
         gst_event_parse_caps(ev, &caps);
-        if (!gst_video_info_from_caps(&vi, caps)) { gst_event_unref(ev); return FALSE; }
+        if (gst_structure_has_name(gst_caps_get_structure(caps, 0), "application/x-cova-records")) {
+            /* packed records: the grid itself is in the caps */
+            const GstStructure *st = gst_caps_get_structure(caps, 0);
+            if (!gst_structure_get_int(st, "width-mbs", &w) || !gst_structure_get_int(st, "height-mbs", &h) || w <= 0 || h <= 0) {
+                gst_event_unref(ev);
+                return FALSE;
+            }
+            p->records = TRUE;
+        } else {
+            if (!gst_video_info_from_caps(&vi, caps)) { gst_event_unref(ev); return FALSE; }
+            /* metapreprocess' caps arithmetic (imp.rs:262-268): macroblock grid = picture / 16 */
+            w = GST_VIDEO_INFO_WIDTH(&vi) / 16; h = GST_VIDEO_INFO_HEIGHT(&vi) / 16;
+            p->records = FALSE;
+        }
         g_mutex_lock(&s->lock);
-        {   /* metapreprocess' caps arithmetic (imp.rs:262-268): macroblock grid = picture / 16 */
-            const gint w = GST_VIDEO_INFO_WIDTH(&vi) / 16, h = GST_VIDEO_INFO_HEIGHT(&vi) / 16;
+        {
             ok = (s->w_mb == 0 && s->h_mb == 0) || (s->w_mb == w && s->h_mb == h);
             if (ok) { s->w_mb = w; s->h_mb = h; s->frame_bytes = (gsize)w * h * 4; }
         }
@@ -763,7 +783,8 @@ static void gst_blobnetfilter_class_init(GstBlobNetFilterClass *k) {
         "Batches the carrier frames of N streams and runs stacking + BlobNet + connected components on MI355X "
         "(replaces metapreprocess ! nvstreammux ! nvinfer ! nvstreamdemux ! maskcopy ! bboxcc)", "covahip");
     gst_element_class_add_pad_template(e, gst_pad_template_new("sink_%u", GST_PAD_SINK, GST_PAD_REQUEST,
-        gst_caps_from_string("video/x-raw, format=(string)I420, width=(int)[16,2147483647], height=(int)[16,2147483647]")));
+        gst_caps_from_string("video/x-raw, format=(string)I420, width=(int)[16,2147483647], height=(int)[16,2147483647]; "
+                             "application/x-cova-records, width-mbs=(int)[1,2147483647], height-mbs=(int)[1,2147483647]")));
     gst_element_class_add_pad_template(e, gst_pad_template_new("src_%u", GST_PAD_SRC, GST_PAD_SOMETIMES,
         gst_caps_from_string("bbox, width=(int)[0,2147483647], height=(int)[0,2147483647]")));
 }

@@ -11,6 +11,10 @@
  *         the smallest picture order count leaves; every frame keeps the timestamps of its access unit
  *   property max-threads: accepted for launch-line compatibility with avdec_h264, ignored (one streaming thread per element,
  *         as the reference configures it)
+ *   property records (round 5): FALSE (default) = the drop-in form above.  TRUE = src caps application/x-cova-records,
+ *         width-mbs, height-mbs: a frame is its macroblocks' PACKED two-byte records (covahip_carrier_pack: everything BlobNet
+ *         keeps of a record) and nothing else -- 16 KB per 1080p picture instead of a zero-filled 3 MB I420 frame; `blobnetfilter`
+ *         takes them as they are.  Same results: the records are the same, the padding was never read.
  */
 #include <gst/gst.h>
 #include <string.h>
@@ -29,6 +33,8 @@ typedef struct {
     gsize rec_bytes, frame_bytes;
     GArray *held;          /* EdHeld, unsorted; at most max_num_reorder_frames (or num_ref_frames + 1) + 1 entries */
     guint max_threads;
+    gboolean records;      /* property: packed two-byte records out instead of the I420 carrier frame */
+    guint8 *scratch;       /* records = TRUE: the four-byte records of the picture being decoded */
     gint fps_n, fps_d;
 } GstEntropyDec;
 typedef struct { GstElementClass parent_class; } GstEntropyDecClass;
@@ -37,7 +43,7 @@ G_DEFINE_TYPE(GstEntropyDec, gst_entropydec, GST_TYPE_ELEMENT)
 static GstStaticPadTemplate ed_sink_t = GST_STATIC_PAD_TEMPLATE("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
     GST_STATIC_CAPS("video/x-h264, stream-format=(string)avc, alignment=(string)au"));
 static GstStaticPadTemplate ed_src_t = GST_STATIC_PAD_TEMPLATE("src", GST_PAD_SRC, GST_PAD_ALWAYS,
-    GST_STATIC_CAPS("video/x-raw, format=(string)I420"));
+    GST_STATIC_CAPS("video/x-raw, format=(string)I420; application/x-cova-records"));
 
 static GstFlowReturn ed_pop(GstEntropyDec *s, gboolean all) {
     GstFlowReturn ret = GST_FLOW_OK;
@@ -71,7 +77,7 @@ static GstFlowReturn ed_chain(GstPad *pad, GstObject *parent, GstBuffer *buf) {
         gst_buffer_unref(buf);
         return GST_FLOW_NOT_NEGOTIATED;
     }
-    GstBuffer *ob = gst_buffer_new_allocate(NULL, s->frame_bytes, NULL);
+    GstBuffer *ob = gst_buffer_new_allocate(NULL, s->records ? s->rec_bytes / 2 : s->frame_bytes, NULL);
     if (!ob || !gst_buffer_map(buf, &in, GST_MAP_READ)) {
         if (ob) gst_buffer_unref(ob);
         gst_buffer_unref(buf);
@@ -85,8 +91,13 @@ static GstFlowReturn ed_chain(GstPad *pad, GstObject *parent, GstBuffer *buf) {
         GST_ELEMENT_ERROR(s, RESOURCE, FAILED, ("cannot map the output frame"), (NULL));
         return GST_FLOW_ERROR;
     }
-    rc = covahip_h264_decode_au(s->h, in.data, in.size, out.data, out.size, &hdr, &key);
-    if (rc == COVAHIP_OK) memset(out.data + s->rec_bytes, 0, out.size - s->rec_bytes);
+    if (s->records) {
+        rc = covahip_h264_decode_au(s->h, in.data, in.size, s->scratch, s->rec_bytes, &hdr, &key);
+        if (rc == COVAHIP_OK) covahip_carrier_pack(s->scratch, s->rec_bytes / 4, (uint16_t *)out.data);
+    } else {
+        rc = covahip_h264_decode_au(s->h, in.data, in.size, out.data, out.size, &hdr, &key);
+        if (rc == COVAHIP_OK) memset(out.data + s->rec_bytes, 0, out.size - s->rec_bytes);
+    }
     gst_buffer_unmap(ob, &out);
     gst_buffer_unmap(buf, &in);
     if (rc != COVAHIP_OK) {
@@ -144,8 +155,14 @@ static gboolean ed_sink_event(GstPad *pad, GstObject *parent, GstEvent *ev) {
         }
         s->rec_bytes = (gsize)s->info.width_mbs * s->info.height_mbs * 4;
         s->frame_bytes = (gsize)s->info.width_mbs * 16 * s->info.height_mbs * 16 * 3 / 2;
-        out = gst_caps_new_simple("video/x-raw", "format", G_TYPE_STRING, "I420", "width", G_TYPE_INT, s->info.width_mbs * 16, "height",
-                                  G_TYPE_INT, s->info.height_mbs * 16, "framerate", GST_TYPE_FRACTION, s->fps_n, s->fps_d, NULL);
+        g_free(s->scratch);
+        s->scratch = s->records ? g_malloc0(s->rec_bytes) : NULL;
+        if (s->records)
+            out = gst_caps_new_simple("application/x-cova-records", "width-mbs", G_TYPE_INT, s->info.width_mbs, "height-mbs", G_TYPE_INT,
+                                      s->info.height_mbs, "framerate", GST_TYPE_FRACTION, s->fps_n, s->fps_d, NULL);
+        else
+            out = gst_caps_new_simple("video/x-raw", "format", G_TYPE_STRING, "I420", "width", G_TYPE_INT, s->info.width_mbs * 16, "height",
+                                      G_TYPE_INT, s->info.height_mbs * 16, "framerate", GST_TYPE_FRACTION, s->fps_n, s->fps_d, NULL);
         ok = gst_pad_push_event(s->src, gst_event_new_caps(out));
         gst_caps_unref(out);
         return ok;
@@ -162,18 +179,21 @@ static gboolean ed_sink_event(GstPad *pad, GstObject *parent, GstEvent *ev) {
     return gst_pad_event_default(pad, parent, ev);
 }
 
-enum { ED_PROP_0, ED_PROP_MAX_THREADS };
+enum { ED_PROP_0, ED_PROP_MAX_THREADS, ED_PROP_RECORDS };
 static void ed_set_property(GObject *o, guint id, const GValue *v, GParamSpec *ps) {
     if (id == ED_PROP_MAX_THREADS) ((GstEntropyDec *)o)->max_threads = g_value_get_uint(v);
+    else if (id == ED_PROP_RECORDS) ((GstEntropyDec *)o)->records = g_value_get_boolean(v);
 }
 static void ed_get_property(GObject *o, guint id, GValue *v, GParamSpec *ps) {
     if (id == ED_PROP_MAX_THREADS) g_value_set_uint(v, ((GstEntropyDec *)o)->max_threads);
+    else if (id == ED_PROP_RECORDS) g_value_set_boolean(v, ((GstEntropyDec *)o)->records);
 }
 static void ed_finalize(GObject *o) {
     GstEntropyDec *s = (GstEntropyDec *)o;
     ed_drop_all(s);
     g_array_free(s->held, TRUE);
     if (s->h) covahip_h264_close(s->h);
+    g_free(s->scratch);
     G_OBJECT_CLASS(gst_entropydec_parent_class)->finalize(o);
 }
 static GstStateChangeReturn ed_change_state(GstElement *e, GstStateChange tr) {
@@ -191,6 +211,10 @@ static void gst_entropydec_class_init(GstEntropyDecClass *k) {
     g_object_class_install_property(g, ED_PROP_MAX_THREADS,
         g_param_spec_uint("max-threads", "Max threads", "accepted for compatibility with avdec_h264 (pipeline.py:91-92); ignored", 0, 64, 1,
                           G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+    g_object_class_install_property(g, ED_PROP_RECORDS,
+        g_param_spec_boolean("records", "Records", "TRUE: packed two-byte macroblock records (application/x-cova-records) instead of "
+                             "the I420-sized carrier frame; set before the caps arrive", FALSE,
+                             G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS | GST_PARAM_MUTABLE_READY));
     gst_element_class_set_static_metadata(e, "H.264 entropy decoder", "Codec/Decoder/Video",
         "H.264 access units -> per-macroblock records in the first bytes of an I420-sized frame (no reconstruction)", "covahip");
     gst_element_class_add_static_pad_template(e, &ed_sink_t);

@@ -69,7 +69,7 @@ def test_inspect_lists_reference_elements_and_properties(tmp_path):
             "blobnetinfer": ["model-weights-file", "gpu-id"], "bboxsink": ["location"],
             "blobnetfilter": ["model-weights-file", "gpu-id", "batch-size", "batched-push-timeout", "cc-threshold"],
             "maskcopy": ["unique-id", "gpu-id", "timestep"],
-            "tfrecordsink": ["location", "gt", "gop"], "h264entropydec": ["max-threads"]}
+            "tfrecordsink": ["location", "gt", "gop"], "h264entropydec": ["max-threads", "records"]}
     for el, props in want.items():
         r = subprocess.run([insp, el], env=_env(tmp_path), capture_output=True, text=True, timeout=60)
         assert r.returncode == 0, r.stdout + r.stderr
@@ -266,11 +266,14 @@ def test_tfrecordsink_element(tmp_path, gop):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batch_size,timeout_us,pause", [(64, 0, False), (32, 0, False), (64, 20000, True)])
-def test_blobnetfilter_batching_element(tmp_path, weights_flat, batch_size, timeout_us, pause):
+@pytest.mark.parametrize("batch_size,timeout_us,pause,records", [(64, 0, False, False), (32, 0, False, False), (64, 20000, True, False),
+                                                                 (64, 0, False, True), (32, 0, False, True)])
+def test_blobnetfilter_batching_element(tmp_path, weights_flat, batch_size, timeout_us, pause, records):
     """blobnetfilter (N request pads; stands for metapreprocess ! nvstreammux ! nvinfer ! nvstreamdemux ! maskcopy ! bboxcc):
     8 streams x 64 carrier frames -> per stream, per frame from the fourth on, the bincode boxes of the C-ABI path on the
-    stacks metapreprocess would have built, with the frame's PTS; batches are formed across the streams."""
+    stacks metapreprocess would have built, with the frame's PTS; batches are formed across the streams.
+    records (round 5): the sink caps are application/x-cova-records and every buffer is the frame's packed two-byte records
+    (what `h264entropydec records=true` emits) -- byte for byte the same payloads as from the I420 carrier frames."""
     from cova_amd import synth, weights as W
     from cova_amd.elements import BlobNetInfer, Context
     h, w, n_streams, n = 45, 80, 8, 64
@@ -280,13 +283,15 @@ def test_blobnetfilter_batching_element(tmp_path, weights_flat, batch_size, time
     recs = []
     for i in range(n):
         for s in range(n_streams):
-            recs.append(("B", i * CLK, s << 8, carriers[s][i].tobytes()))
+            recs.append(("B", i * CLK, s << 8, E.pack_frames(carriers[s][i]).tobytes() if records else carriers[s][i].tobytes()))
         if pause and i == 12:
             recs.append(("s", 150, 0, b""))                  # 150 ms without input: the open batch (16 stacks) leaves by timeout
     recs += [("e", 0, s << 8, b"") for s in range(n_streams)]
     _write(tmp_path / "in.rec", recs)
     info = _run(["mux", f"blobnetfilter model-weights-file={wpath} batch-size={batch_size} batched-push-timeout={timeout_us} "
-                 f"cc-threshold=4 max-boxes=512", str(n_streams), f"video/x-raw,format=I420,width={w * 16},height={h * 16},framerate=30/1",
+                 f"cc-threshold=4 max-boxes=512", str(n_streams),
+                 f"application/x-cova-records,width-mbs={w},height-mbs={h},framerate=30/1" if records else
+                 f"video/x-raw,format=I420,width={w * 16},height={h * 16},framerate=30/1",
                  str(tmp_path / "in.rec"), str(tmp_path / "out.rec")], tmp_path)
     n_out = n_streams * (n - 3)
     assert info["buffers"] == n_out and info["eos"] == n_streams
@@ -391,6 +396,15 @@ def test_config_1_through_the_elements_entropy_decoder_metapreprocess_tfrecordsi
         stack = np.frombuffer(payload, np.uint8).reshape(4 * 45, 80, 4)
         for j in range(4):
             np.testing.assert_array_equal(stack[j * 45:(j + 1) * 45], rec[order[cur - j]])
+    # round 5: records=true -> application/x-cova-records, a frame = the packed two-byte records of its picture (16 KB at 1080p
+    # instead of a zero-filled 3 MB I420 frame), in the same output order with the same timestamps
+    info = _run(["harness", "h264entropydec records=true", caps, str(tmp_path / "in.rec"), str(tmp_path / "rec.rec")], tmp_path)
+    assert "application/x-cova-records" in info["out_caps"] and "width-mbs=(int)80" in info["out_caps"] and "height-mbs=(int)45" in info["out_caps"]
+    routs = _read(tmp_path / "rec.rec")
+    assert len(routs) == n_au
+    for k, (kind, pts, flags, payload) in enumerate(routs):
+        assert pts == order[k] * CLK and len(payload) == 45 * 80 * 2
+        np.testing.assert_array_equal(np.frombuffer(payload, np.uint16).reshape(45, 80), E.pack_frames(rec[order[k]]))
     lib.covahip_h264_close(h)
     # the same chain into the sink: one Example per emitted frame
     out = tmp_path / "out.tfrecord"

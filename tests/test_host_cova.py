@@ -68,6 +68,49 @@ def test_counters_and_forwarded_aus_match_restatement(cfg):
     assert c.dropped + c.decoded_dependency + c.decoded_inference <= n
 
 
+@pytest.mark.parametrize("reorder", ["b_frames", "overlapping_gops", "far_ahead"])
+def test_gop_walks_stop_early_only_while_the_gops_are_in_order(reorder):
+    """Round 5: the port stops its walks over the buffered GoPs at the first one wholly outside the range it looks for -- exact
+    only while the GoPs' pts ranges are in order, which it tracks.  Against the restatement (which walks everything, as the
+    reference does, imp.rs:135-315): B-frame reordering inside closed GoPs (in order), GoPs whose leading pictures reach back
+    below the previous GoP's last pts (NOT in order: the port must fall back to the full walks), and an encoded branch that
+    is a thousand frames ahead (many buffered GoPs, the case the early exit is for)."""
+    n, gop = 1500, 50
+    objects = [(10, 120, 5, 5, 0.4, 0.2, 6, 6), (200, 420, 60, 30, -0.3, 0.0, 8, 5), (300, 330, 20, 20, 0, 0, 4, 4),
+               (500, 800, 10, 40, 0.2, -0.1, 7, 7), (900, 1400, 30, 10, 0.05, 0.05, 5, 5)]
+    dets = _timeline(n, gop, objects)
+    kw = dict(sort_maxage=10, sort_minhits=5, sort_iou=0.1, alpha=4, beta=2)
+    c = E.Cova(**kw)
+    r = R.GopFilter(**kw)
+
+    def enc_pts(i):                      # decode order -> presentation time
+        k = i % gop
+        if reorder == "overlapping_gops" and k in (1, 2) and i >= gop:
+            return (i - 6) * CLK         # leading pictures of an open GoP: presented before the previous GoP's last pictures
+        if k and k % 3 == 0 and k + 1 < gop:
+            return (i + 1) * CLK         # a P picture decoded before the B picture that precedes it in output order
+        if k and k % 3 == 1 and k > 1:
+            return (i - 1) * CLK
+        return i * CLK
+    lead = 1000 if reorder == "far_ahead" else 120
+    forwarded = []
+    for i in range(n + lead):
+        if i < n:
+            c.sink_enc_chain(i, enc_pts(i), delta_unit=(i % gop != 0))
+            r.push_enc(i, enc_pts(i), 0 if i % gop == 0 else R.DELTA_UNIT)
+        j = i - lead
+        if 0 <= j < n:
+            forwarded.extend(c.sink_mask_chain(E.serialize_vec(_bb(dets[j])), j * CLK))
+            r.push_boxes([R.Bbox(*d) for d in dets[j]], j * CLK)
+    assert c.eos("sink_enc") is None
+    forwarded.extend(c.eos("sink_mask"))
+    r.eos()
+    assert (c.dropped, c.decoded_dependency, c.decoded_inference) == (r.dropped, r.decoded_dependency, r.decoded_inference)
+    exp = [b for lst in r.pushed for b in lst]
+    assert [(int(a["id"]), int(a["pts"]), int(a["flags"])) for a in forwarded] == [tuple(b) for b in exp]
+    assert len(exp) > 15
+
+
 def test_key_frame_gets_discont_and_dependencies_droppable():
     c = E.Cova(sort_maxage=10, sort_minhits=5)
     for i in range(600):
