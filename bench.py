@@ -511,7 +511,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--entry", choices=["frames", "stack"], default="frames",
                     help="entry point of the timed step: carrier frames + stack table (default) or pre-stacked tensors")
-    ap.add_argument("--lanes", type=int, default=2,
+    ap.add_argument("--lanes", type=int, default=3,
                     help="batches in flight per GPU (covahip_ctx_set_lanes): 1 = one step after the other on one stream")
     ap.add_argument("--min-warmup-s", type=float, default=0.3, help="warm up for at least this long on top of --warmup steps")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",

@@ -27,6 +27,21 @@
 
 #include "bboxcc_body.h"
 
+#ifdef PHASE_TIMING
+// developer build (tools/build_phase_lib.sh): s_memrealtime ticks per phase of frame_wg, thread 0 of every workgroup, summed
+__device__ unsigned long long g_ccph[8];
+#define CCWG_MARK(i)                                                        \
+    do {                                                                    \
+        if (tid == 0) {                                                     \
+            const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+            atomicAdd(&g_ccph[i], now_ - cc_last_);                         \
+            cc_last_ = now_;                                                \
+        }                                                                   \
+    } while (0)
+#else
+#define CCWG_MARK(i) do { } while (0)
+#endif
+
 namespace ccwave {
 
 struct WvGeom {
@@ -236,6 +251,9 @@ __device__ __forceinline__ void frame_wg(const uint8_t *m, uint8_t *sm, const Wv
     uint32_t *s_area = lab + g.cap, *s_minx = s_area + g.cap, *s_maxx = s_minx + g.cap, *s_miny = s_maxx + g.cap,
              *s_maxy = s_miny + g.cap;
     __shared__ uint32_t wave_tot[NWV];
+#ifdef PHASE_TIMING
+    unsigned long long cc_last_ = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- A
     for (int i = tid; i < g.rows_bytes / 4; i += NTH) rows[i] = 0;
@@ -254,6 +272,7 @@ __device__ __forceinline__ void frame_wg(const uint8_t *m, uint8_t *sm, const Wv
         if (o) atomicOr(rw + 2, o << sh);
     }
     __syncthreads();
+    CCWG_MARK(0);   // A: bit planes
     // ---- B (every wave for itself)
     uint64_t a = 0, b = 0, c = 0, d = 0, ue = 0, uo = 0;
     if (lane < g.BH) {
@@ -282,6 +301,7 @@ __device__ __forceinline__ void frame_wg(const uint8_t *m, uint8_t *sm, const Wv
     if (lane == 0) { S_up = 0; J_up = 0; base_up = 0; }
     for (int i = tid; i < n; i += NTH) lab[i] = (uint32_t)i;
     __syncthreads();
+    CCWG_MARK(1);   // B: row masks, prefix sums
     // ---- C: wave w takes the runs w, w + NWV, ... of every block row (lane = block row): the runs of a row are spread
     // evenly over the waves, a dense row costs ceil(runs / NWV) passes instead of one pass per run
     for (int k = wave; __any(k < nr); k += NWV) {
@@ -313,6 +333,7 @@ __device__ __forceinline__ void frame_wg(const uint8_t *m, uint8_t *sm, const Wv
         }
     }
     __syncthreads();
+    CCWG_MARK(2);   // C: runs, unions
     // ---- D
     for (int i = tid; i < n; i += NTH) {
         const uint32_t root = ccbody::uf_find(lab, (uint32_t)i);
@@ -326,6 +347,7 @@ __device__ __forceinline__ void frame_wg(const uint8_t *m, uint8_t *sm, const Wv
         }
     }
     __syncthreads();
+    CCWG_MARK(3);   // D: statistics to the roots
     // ---- E: ordered compaction, `per` consecutive runs per thread
     const int per = (n + NTH - 1) / NTH;
     const int i0 = tid * per;
@@ -367,6 +389,7 @@ __device__ __forceinline__ void frame_wg(const uint8_t *m, uint8_t *sm, const Wv
     }
     if (tid == 0) *count_out = (int32_t)total;
     __syncthreads();   // wave_tot and the frame's LDS region are free for the next frame
+    CCWG_MARK(4);   // E: compaction, box stores
 }
 
 }  // namespace ccwave

@@ -1548,7 +1548,7 @@ __global__ __launch_bounds__(512, 2) void enc23_mfma(Enc23Args p) {
 #pragma unroll
                         for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
 #pragma unroll
-                    for (int tap = 0; tap < 9; tap++)
+                    for (int tap = 0; tap < 9; tap++) {
 #pragma unroll
                         for (int kc = 0; kc < 4; kc++)
 #pragma unroll
@@ -1557,6 +1557,7 @@ __global__ __launch_bounds__(512, 2) void enc23_mfma(Enc23Args p) {
                                 const half8 a = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(ap, 16));
                                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[tap * 4 + kc], acc[t], 0, 0, 0);
                             }
+                    }
 #pragma unroll
                     for (int tt = 0; tt < 2; tt++)
 #pragma unroll
@@ -3003,6 +3004,14 @@ extern "C" int covahip_dev_itemspan_read(unsigned long long *out, int kid) {
 }
 #endif
 #ifdef PHASE_TIMING
+extern "C" int covahip_dev_ccphase_read(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ccph), sizeof(g_ccph)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_ccph), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
 extern "C" int covahip_dev_phase_read(unsigned long long *out64, int reset) {
     if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase), sizeof(g_phase)) != hipSuccess) return 1;
     if (reset) {

@@ -374,11 +374,13 @@ static int run_muxbench(const char *desc, int n_pads, int w_px, int h_px, int fr
 #include <sys/time.h>
 #include <ucontext.h>
 static void *prof_pc[_PROF_MAX];
+static int prof_tid[_PROF_MAX];
 static volatile gint prof_n;
+#include <sys/syscall.h>
 static void prof_handler(int sig, siginfo_t *si, void *uc_) {
     ucontext_t *uc = uc_;
     const gint k = g_atomic_int_add(&prof_n, 1);
-    if (k < _PROF_MAX) prof_pc[k] = (void *)uc->uc_mcontext.gregs[REG_RIP];
+    if (k < _PROF_MAX) { prof_pc[k] = (void *)uc->uc_mcontext.gregs[REG_RIP]; prof_tid[k] = (int)syscall(SYS_gettid); }
 }
 static void prof_start(void) {
     struct sigaction sa;
@@ -407,8 +409,13 @@ static void prof_report(void) {
         FILE *f = fopen(getenv("CHAINBENCH_PROF_RAW"), "w");
         for (int i = 0; f && i < n; i++) {
             Dl_info di;
-            if (dladdr(prof_pc[i], &di) && di.dli_fname) fprintf(f, "%s %lx\n", di.dli_fname, (unsigned long)((char *)prof_pc[i] - (char *)di.dli_fbase));
-            else fprintf(f, "? %lx\n", (unsigned long)prof_pc[i]);
+            char comm[64] = "?", path[64];
+            FILE *cf;
+            snprintf(path, sizeof path, "/proc/self/task/%d/comm", prof_tid[i]);   /* (a thread that has exited by now stays "?") */
+            if ((cf = fopen(path, "r"))) { if (fgets(comm, sizeof comm, cf)) comm[strcspn(comm, "\n")] = 0; fclose(cf); }
+            for (char *c = comm; *c; c++) if (*c == ' ') *c = '_';
+            if (dladdr(prof_pc[i], &di) && di.dli_fname) fprintf(f, "%s %lx %s\n", di.dli_fname, (unsigned long)((char *)prof_pc[i] - (char *)di.dli_fbase), comm);
+            else fprintf(f, "? %lx %s\n", (unsigned long)prof_pc[i], comm);
         }
         if (f) fclose(f);
     }

@@ -36,6 +36,8 @@ for _ in range(3):
     net.filter_frames_device(d_frames, frames.shape[0], index, B, 1, d_boxes, d_counts, 256, d_mask)
 ctx.sync()
 lib.covahip_dev_phase_read(out, 1)
+cc = (ctypes.c_ulonglong * 8)()
+lib.covahip_dev_ccphase_read(cc, 1)
 for _ in range(steps):
     net.filter_frames_device(d_frames, frames.shape[0], index, B, 1, d_boxes, d_counts, 256, d_mask)
 ctx.sync()
@@ -50,3 +52,9 @@ for base, label in ((0, "enc1t (PRE)"), (16, "enc23" if FUSED23 else "enc2"), (3
     print(f"{label}: {tot / steps / 100:.0f} us of workgroup time per launch (all workgroups)")
     for i, n in enumerate(E23_NAMES if base == 16 and FUSED23 else DEC_NAMES if base == 48 else TAIL_NAMES if base == 64 else E1V_NAMES if base == 0 and not os.environ.get('QB_IMPL') else names):
         print(f"   {n:40s} {100 * v[base + i] / tot:5.1f} %   {v[base + i] / steps / 100 / NWG[base]:7.2f} us per workgroup ({NWG[base]} of them)")
+lib.covahip_dev_ccphase_read(cc, 1)
+ccv = np.array(list(cc), dtype=np.float64)
+if ccv.sum() > 0:
+    print("bboxcc inside the fused tail (frame_wg, thread 0 of every workgroup):")
+    for i, nme in enumerate(["A: bit planes", "B: row masks, prefix sums", "C: runs, unions", "D: statistics to the roots", "E: compaction, box stores"]):
+        print(f"   {nme:40s} {ccv[i] / steps / 100 / 256:7.2f} us per workgroup")

@@ -29,17 +29,22 @@ def table(path):
 
 cnt = collections.Counter()
 n = 0
+by_thread = collections.Counter()
 for line in open(sys.argv[1]):
-    lib, off = line.split()
+    parts = line.split()
+    lib, off = parts[0], parts[1]
+    thread = parts[2] if len(parts) > 2 else "?"
+    by_thread[thread] += 1
     n += 1
     base = os.path.basename(lib)
     path = LOCAL.get(base) if base in LOCAL and os.path.exists(LOCAL[base]) else (os.path.realpath(lib) if os.path.exists(lib) else None)
     if path and not os.environ.get("PROF_LOCAL_ONLY"):      # (the build container and the GPU boxes run the same image: system libraries resolve too)
         t = table(path) or [(0, "*")]
         i = bisect.bisect_right(t, (int(off, 16), "￿")) - 1
-        cnt[(base, t[i][1][:70] if i >= 0 else "?")] += 1
+        cnt[(thread, base, t[i][1][:70] if i >= 0 else "?")] += 1
     else:
-        cnt[(base, "*")] += 1
+        cnt[(thread, base, "*")] += 1
 print(f"{n} samples")
-for (lib, fn), c in cnt.most_common(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
-    print(f"  {100.0 * c / n:5.1f} %  {lib:24s} {fn}")
+print("by thread name:", ", ".join(f"{t} {100.0 * c / n:.1f} %" for t, c in by_thread.most_common()))
+for (thread, lib, fn), c in cnt.most_common(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
+    print(f"  {100.0 * c / n:5.1f} %  {thread:16s} {lib:24s} {fn}")
