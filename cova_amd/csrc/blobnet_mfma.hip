@@ -66,7 +66,8 @@ struct Prepared {
     size_t final_w;  // B fragments of the folded (convT 32->16) x (1x1 16->1) last block: [KSTEPS][64] x half8
     size_t final_epi;  // folded bias (fp32)
     size_t final_w_up;   // the same fold restricted to the "up" half of the last block's input (channels 0..15): [4][64] x half8
-    size_t tail_w;       // ... and to the skip half (channels 16..31) as A fragments of v_mfma_f32_16x16x32_f16 for enc1_mfma: [2][64] x half8
+    size_t tail_w;       // ... and to the skip half (channels 16..31) as fragments of v_mfma_f32_16x16x32_f16 for enc1_mfma, in the K-step
+                         // order of its main convolution: [2][64] x half8
     size_t zero;     // 256 zero bytes (LDS-DMA source for halo chunks)
     bool allpos[BN_LEVELS];  // all BN scales of encoder level i are >= 0
     size_t total;
@@ -970,7 +971,7 @@ struct Enc1Args {
     // store per position (a first form wrote [Hd][Wd] pixels: sixteen masked 4-byte stores per tile, 500 instructions per item).
     float *part;
     const half8 *wtail;  // [2 K steps][64 lanes]: A fragments of the folded skip half (prep_tail)
-    uint32_t mGW;        // magic of W + 1 (grid positions per row of the transposed convolution)
+    uint32_t mXe;        // magic of 2 * Wp (columns of the grid rows the edge pass walks)
     uint16_t ktab[BN_KTAB_STACKS * BN_T];
 };
 // Per-lane constants live in a small LDS table behind the scratch instead of registers (hipcc keeps every loop-invariant
@@ -1135,6 +1136,7 @@ __global__ __launch_bounds__(512, 4) void enc1_mfma(Enc1Args p) {
         PHASE_MARK(5);   // weights landing
 #endif
         const int m = ll & 15, kg = ll >> 4;
+        const bool ride = p.part != nullptr;
         const int nwin = (rows / 2) * p.Wp;
         const int ntiles = (nwin + 3) / 4;
         const uint32_t tstride = (uint32_t)(p.Ho * p.Wo * 32);
@@ -1147,56 +1149,51 @@ __global__ __launch_bounds__(512, 4) void enc1_mfma(Enc1Args p) {
         // (the last band: + the row behind the image) x W + 1 columns, tiles of 16 positions, transposed (A = weights, B =
         // activations: a lane < 16 ends up with the four parities of ITS position = a 2 x 2 block of output pixels).
         // out[2u + py - cy][2v + px - cx] += sum_{a, b, c} skip[u - a][v - b][c] * w[py + 2a][px + 2b][c]
+        // Partial logits (see Enc1Args::part).  The grid positions (u, v) = (y, x) that ARE positions of the main convolution ride on
+        // its tiles: K steps 0 and 1 of a tile's T = 0 slice hold exactly the four taps (u - a, v - bb) the folded skip half needs
+        // (rows y - 1, y; columns x - 1, x), so two more products per tile -- weights as the B operand, the fragments the tile has in
+        // registers anyway -- give four parities x sixteen positions.  What no tile covers is done here, IN FRONT of the tile loop:
+        // the grid column(s) behind the last pooled column and, in the last band, the grid row(s) behind the last pooled row -- 6 of a
+        // band's 366 positions, 65 in the last band.  (Behind the tile loop the phase's first LDS read sat behind `s_waitcnt
+        // vmcnt(0)` = the acknowledgement of the tile epilogues' stores, 2.2 us per item; here the only outstanding vector-memory
+        // operations are the weight fragments the tile loop waits for anyway.  The first form of this pass covered EVERY position:
+        // ~85 instructions per wave and item on an issue port that is 88 % busy, +2.0 us per launch.)
+        const int GW = p.W + 1;
+        f32x4 *const pb4 = reinterpret_cast<f32x4 *>(p.part) + (size_t)b * (p.H + 1) * GW;
         if (p.part) {
-            const int GW = p.W + 1;
             const int ub = (band == p.nbands - 1) ? p.H + 1 : yb;
-            const int npos = (ub - ya) * GW;
+            const int xe = 2 * p.Wp, ce = GW - xe;                  // edge columns xe .. W (one of them: W is even)
+            const int ne1 = (ub - ya) * ce;                          // ... of every grid row of the band
+            const int ne2 = max(0, ub - (y0 + rows)) * xe;           // + the grid rows behind the last pooled row, columns 0 .. xe - 1
+            const int npos = ne1 + ne2;
             const int nptiles = (npos + 15) / 16;
-            f32x4 *const pb = reinterpret_cast<f32x4 *>(p.part) + (size_t)b * (p.H + 1) * GW;
-            // a wave's tiles go through the phases together (addresses and LDS reads of all of them, then the products, then the
-            // stores): one LDS latency and one product latency per item instead of one per tile.  A band of E1_TR rows has at most
-            // 7 grid rows x 63 columns = 28 tiles: three per wave and a fourth for the first few waves (wave-uniform branch).  The
-            // phase is paid in issued instructions (four waves share a SIMD's issue port): ~25 per tile.
-            static_assert(((E1_TR - 1) * (E1_MAXW + 1) + 15) / 16 <= 4 * MG, "partial-logit tiles per wave");
-            const half8 wa0 = *reinterpret_cast<const half8 *>(cst + 512 + ll * 16), wa1 = *reinterpret_cast<const half8 *>(cst + 1536 + ll * 16);
-            // lane part of the fragment address: lane group kg = 2 * bb + channel half reads pixel column v + 1 - bb
-            const int lpart = (1 - (kg >> 1)) * 32 + (kg & 1) * 16 + (1 - y0) * E1_RS;
-            auto ptiles = [&](auto npt_tag, int first) {
-                constexpr int NPT = decltype(npt_tag)::value;
-                half8 b0[NPT], b1[NPT];
-                int pidx[NPT];
-#pragma unroll
-                for (int k = 0; k < NPT; k++) {
-                    const int q = (first + k * MG) * 16 + m;
+            if (wave < nptiles) {
+                const half8 w0 = *reinterpret_cast<const half8 *>(cst + 512 + ll * 16), w1 = *reinterpret_cast<const half8 *>(cst + 1536 + ll * 16);
+                for (int pt = wave; pt < nptiles; pt += MG) {
+                    const int q = pt * 16 + m;
                     const int qc = min(q, npos - 1);
-                    const int ul = fdiv(qc, p.mGW), pv = qc - ul * GW;
-                    pidx[k] = q < npos ? ya * GW + q : -1;     // -1: a lane without a position
-                    // taps (a, bb): K step = a; input pixel (u - a, v - bb) = band row u - a - y0 + 1, column v - bb + 1 (the halo
-                    // columns / rows of the band hold zeros).  A row behind the image that the band does not hold (odd H: the row
-                    // of u = H) is read from the band's first halo pixel instead, which is zero in every row
-                    const int u = ya + ul;
-                    const int o1 = (u - 1) * E1_RS + pv * 32 + lpart;            // row u - 1 (a = 1)
-                    const int o0 = u >= p.H ? 0 : o1 + E1_RS;                    // row u (a = 0)
-                    b0[k] = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(smem + o0, 16));
-                    b1[k] = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(smem + o1, 16));
-                }
-                f32x4 pacc[NPT];
-#pragma unroll
-                for (int k = 0; k < NPT; k++) {
+                    int u, v;
+                    if (qc < ne1) {
+                        const int ul = ce == 1 ? qc : qc >> 1;
+                        u = ya + ul; v = xe + (qc - ul * ce);
+                    } else {
+                        const int q2 = qc - ne1, ul = fdiv(q2, p.mXe);
+                        u = y0 + rows + ul; v = q2 - ul * xe;
+                    }
+                    // K step 0 = input row u - 1 (band row u - y0), K step 1 = row u; lane group kg: column v - 1 + (kg >> 1) (band
+                    // column v + (kg >> 1)), channel half kg & 1.  A row behind the image that the band does not hold (odd H: the
+                    // row of u = H) is read from the band's first halo pixel instead, which is zero
+                    const int o1 = (u - y0) * E1_RS + (v + (kg >> 1)) * 32 + (kg & 1) * 16;
+                    const int o0 = u >= p.H ? 0 : o1 + E1_RS;
+                    const half8 b1 = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(smem + o1, 16));
+                    const half8 b0 = *reinterpret_cast<const half8 *>(__builtin_assume_aligned(smem + o0, 16));
                     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                    pacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa0, b0[k], z4, 0, 0, 0);
+                    f32x4 pe = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, b1, z4, 0, 0, 0);       // weights as A: a lane < 16 gets the four
+                    pe = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, b0, pe, 0, 0, 0);             // parities of ITS position
+                    if (kg == 0 && q < npos) pb4[u * GW + v] = pe;
                 }
-#pragma unroll
-                for (int k = 0; k < NPT; k++) pacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa1, b1[k], pacc[k], 0, 0, 0);
-#pragma unroll
-                for (int k = 0; k < NPT; k++)
-                    if (kg == 0 && pidx[k] >= 0) pb[pidx[k]] = pacc[k];   // registers 0..3 of a lane < 16 = parities (py, px) = (r >> 1, r & 1)
-            };
-            if (wave + 2 * MG < nptiles) ptiles(std::integral_constant<int, 3>{}, wave);
-            else if (wave + MG < nptiles) ptiles(std::integral_constant<int, 2>{}, wave);
-            else if (wave < nptiles) ptiles(std::integral_constant<int, 1>{}, wave);
-            if (wave + 3 * MG < nptiles) ptiles(std::integral_constant<int, 1>{}, wave + 3 * MG);
-            PHASE_MARK(8);   // partial logits of the band
+            }
+            PHASE_MARK(8);   // partial logits: the positions no tile covers
         }
         for (int tile = wave; tile < (E1_ABL == 4 ? 0 : ntiles); tile += MG) {
             const int win = min(tile * 4 + (m >> 2), nwin - 1);
@@ -1223,12 +1220,16 @@ __global__ __launch_bounds__(512, 4) void enc1_mfma(Enc1Args p) {
             f32x4 acc[2][2];
             f32x4 pooled[2];
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            f32x4 pride = z4;        // partial logits of the tile's sixteen positions, parity = lane & 15 (< 4)
 #pragma unroll
             for (int k = 0; k < 20; k++) {
                 const int s = (k % 10) >> 1, tp = k & 1;
 #pragma unroll
                 for (int nt = 0; nt < 2; nt++)
                     acc[nt][tp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ab[k % AD], bf[nt][s], s == 0 ? z4 : acc[nt][tp], 0, 0, 0);
+                if ((k == 0 || k == 2) && ride)   // T = 0, K steps 0 and 1: the fragment in ab[] is the one the folded skip half needs
+                    pride = __builtin_amdgcn_mfma_f32_16x16x32_f16(ab[k % AD], *reinterpret_cast<const half8 *>(cst + 512 + (k >> 1) * 1024 + ll * 16),
+                                                                   pride, 0, 0, 0);
                 if (k + AD < 20) ab[k % AD] = frag(k + AD);
 #if E1_ABL == 3
                 if (s == 4) asm volatile("" :: "v"(acc[0][tp]), "v"(acc[1][tp]));
@@ -1285,6 +1286,11 @@ __global__ __launch_bounds__(512, 4) void enc1_mfma(Enc1Args p) {
                 const int gy = y0 / 2 + owy + p.oy, gx = owx + p.ox;
                 const uint32_t eo = (uint32_t)((gy * p.Wo + gx) * 32 + 8 * (m & 3));
                 *reinterpret_cast<uint4 *>(ob + (m >> 2) * tstride + eo) = sv;
+                // the ride's results: D rows 4 kg + r = position r of window kg, column m = parity -> float m of the position's four
+                if (ride && m < 4) {
+                    float *const pw = reinterpret_cast<float *>(pb4 + (y0 + 2 * owy) * GW + 2 * owx) + m;
+                    pw[0] = pride[0]; pw[4] = pride[1]; pw[4 * GW] = pride[2]; pw[4 * GW + 4] = pride[3];
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -2308,15 +2314,17 @@ void prep_final(int cin, int cout, const float *k, const float *bias, const floa
         epi[0] = (float)bsum;
     }
 }
-// The skip half of the same fold for the level-1 kernel (enc1_mfma's partial logits): A fragments of v_mfma_f32_16x16x32_f16,
-// A[i][k] in lane 16 * (k / 8) + i; row i < 4 = output parity, one K step = the two taps (a, bb = 0 | 1) x 16 skip channels:
-// k = 16 * bb + (channel), K step s = a.
+// The skip half of the same fold for the level-1 kernel (enc1_mfma's partial logits): fragments of v_mfma_f32_16x16x32_f16 whose
+// row / column index i < 4 is the output parity and whose K index follows enc1_mfma's main convolution: for a position (y, x) K step
+// 0 holds input row y - 1 (a = 1) and K step 1 row y (a = 0); within a step k < 16 is column x - 1 (bb = 1), k >= 16 column x
+// (bb = 0).  A[i][k] and B[k][n] of that instruction share the lane decomposition (lane = 16 * (k / 8) + i), so ONE set serves the
+// tiles of the main convolution (weights as the B operand) and the edge pass (weights as the A operand).
 void prep_tail(int cin, int cout, const float *k, const float *fk, int c0, _Float16 *wfrag) {
     for (int s = 0; s < 2; s++)
         for (int l = 0; l < 64; l++)
             for (int j = 0; j < 8; j++) {
-                const int i = l & 15, kg = l >> 4, bb = kg >> 1, c = c0 + 8 * (kg & 1) + j;
-                wfrag[((size_t)s * 64 + l) * 8 + j] = f2h(i < 4 ? final_fold(cin, cout, k, fk, i, s, bb, c) : 0.f);
+                const int i = l & 15, kg = l >> 4, c = c0 + 8 * (kg & 1) + j;
+                wfrag[((size_t)s * 64 + l) * 8 + j] = f2h(i < 4 ? final_fold(cin, cout, k, fk, i, 1 - s, 1 - (kg >> 1), c) : 0.f);
             }
 }
 
@@ -2717,7 +2725,7 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
                 part_written = m->tail_part && ws.part && m->dec_ci[3] == 32 && m->dec_co[3] == 16 && m->enc_c[1] == 16;
                 a.part = part_written ? ws.part : nullptr;
                 a.wtail = (const half8 *)(prep + pr->tail_w);
-                a.mGW = magic(W + 1);
+                a.mXe = magic(2 * Wp);
                 a.use_ktab = 0;
                 if (by_frames && inp.h_index && batch <= BN_KTAB_STACKS) {
                     a.use_ktab = 1;
