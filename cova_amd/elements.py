@@ -267,7 +267,7 @@ class FilterPipe:
     overlapped on three HIP streams, boxes compacted on the device."""
 
     def __init__(self, net: "BlobNetInfer", max_batch: int, max_frames: int, max_boxes: int = 256, n_slots: int = 3,
-                 want_mask: bool = False, packed: bool = False):
+                 want_mask: bool = False, packed: bool = False, blocking_wait: bool = False):
         self.net, self.max_batch, self.max_frames, self.max_boxes = net, max_batch, max_frames, max_boxes
         self.packed = packed
         self._lib = L.lib()
@@ -277,6 +277,8 @@ class FilterPipe:
         self._h = h
         if packed:      # the slots take two-byte records (pack_frames) instead of the decoder's four bytes per macroblock
             L.check(self._lib.covahip_pipe_set_packed(h, 1), "covahip_pipe_set_packed")
+        if blocking_wait:   # collect() sleeps until the results have landed instead of spinning (covahip_pipe_set_blocking_wait)
+            L.check(self._lib.covahip_pipe_set_blocking_wait(h, 1), "covahip_pipe_set_blocking_wait", net.ctx.handle)
         self._batch = {}
         self._views = {}     # slot -> numpy views of its pinned input buffers (the addresses never change)
         self._held = []      # collected slots whose result views are still handed out

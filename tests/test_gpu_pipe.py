@@ -10,7 +10,8 @@ from cova_amd.elements import BlobNetInfer, FilterPipe
 pytestmark = pytest.mark.gpu
 
 
-def test_pipelined_batches_equal_synchronous_calls(ctx, weights_flat):
+@pytest.mark.parametrize("blocking_wait", [False, True])
+def test_pipelined_batches_equal_synchronous_calls(ctx, weights_flat, blocking_wait):
     h, w, b, streams, n_batches = 45, 80, 48, 4, 7
     net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=64)
     data = [synth.carrier_batch(b, h, w, seed=300 + 10 * k, streams=streams) for k in range(n_batches)]
@@ -18,7 +19,8 @@ def test_pipelined_batches_equal_synchronous_calls(ctx, weights_flat):
     for frames, index in data:
         boxes, counts, mask, _ = net.filter_frames(frames, index, 4, max_boxes=512, want_mask=True)
         ref.append((boxes, counts, mask))
-    pipe = FilterPipe(net, max_batch=64, max_frames=64 + 3 * streams, max_boxes=512, n_slots=3, want_mask=True)
+    # blocking_wait (round 5): the waiting thread sleeps on the completion interrupt instead of spinning -- same results
+    pipe = FilterPipe(net, max_batch=64, max_frames=64 + 3 * streams, max_boxes=512, n_slots=3, want_mask=True, blocking_wait=blocking_wait)
     got, in_flight = {}, []
     for k, (frames, index) in enumerate(data):
         acq = pipe.acquire()
@@ -142,3 +144,28 @@ def test_packed_records_give_identical_results(ctx, weights_flat):
     for a, c in zip(res[0], res[1]):
         np.testing.assert_array_equal(a, c)
     assert res[0][0].sum() > 0
+
+
+def test_blocking_wait_only_with_idle_slots_and_device_pci_address(ctx, weights_flat):
+    """covahip_pipe_set_blocking_wait is refused while a slot is acquired or in flight (the events it replaces may be waited on);
+    covahip_device_pci_bus_id names the device the way sysfs does (what multigpu.pin_to_gpu reads the NUMA node from)."""
+    import ctypes as C
+    import os
+    import re
+    lib = L.lib()
+    net = BlobNetInfer(ctx, weights_flat, 45, 80, max_batch=8)
+    pipe = FilterPipe(net, max_batch=8, max_frames=16, max_boxes=64, n_slots=2)
+    slot, pf, pi = pipe.acquire()
+    assert lib.covahip_pipe_set_blocking_wait(pipe._h, 1) != 0
+    pipe.abort(slot)
+    assert lib.covahip_pipe_set_blocking_wait(pipe._h, 1) == 0
+    assert lib.covahip_pipe_set_blocking_wait(pipe._h, 0) == 0
+    assert lib.covahip_pipe_set_blocking_wait(None, 1) != 0
+    pipe.close()
+    buf = C.create_string_buffer(32)
+    assert lib.covahip_device_pci_bus_id(0, buf, len(buf)) == 0
+    addr = buf.value.decode().lower()
+    assert re.fullmatch(r"[0-9a-f]{4}:[0-9a-f]{2}:[0-9a-f]{2}\.[0-9a-f]", addr), addr
+    assert lib.covahip_device_pci_bus_id(0, buf, 4) != 0 and lib.covahip_device_pci_bus_id(9999, buf, len(buf)) != 0
+    if os.path.isdir("/sys/bus/pci/devices"):
+        assert os.path.exists(os.path.join("/sys/bus/pci/devices", addr))
