@@ -380,6 +380,29 @@ def test_tail_partial_logits_match_the_skip_tensor_form(ctx, weights_flat, hw, m
     assert differ.mean() < 1e-3
 
 
+@pytest.mark.parametrize("b", [1, 7, 33, 191, 192, 193, 255, 257])
+def test_default_chain_across_batch_sizes(ctx, weights_flat, b):
+    """The default kernel chain picks its forms by batch size (levels 2 + 3 as one launch from three quarters of a frame per CU
+    on, the stack table by value up to 256 stacks, band plans by rounds): around every threshold the result is the one the
+    two-launch chain gives, bit for bit, the two entries agree, and frame k of a batch does not depend on the batch around it."""
+    h, w = 68, 120
+    frames, index = synth.carrier_batch(257, h, w, seed=53, streams=3)
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=257)
+    got = net.filter_frames(frames, index[:b], 1, max_boxes=1024, want_mask=True, want_logits=True)
+    net.set_impl("enc23_separate")
+    try:
+        got2 = net.filter_frames(frames, index[:b], 1, max_boxes=1024, want_mask=True, want_logits=True)
+    finally:
+        net.set_impl("mfma")
+    for a, c in zip(got, got2):
+        np.testing.assert_array_equal(a, c)
+    # batch independence: the last frame of this batch, alone
+    one = net.filter_frames(frames, index[b - 1:b], 1, max_boxes=1024, want_mask=True, want_logits=True)
+    np.testing.assert_array_equal(one[3][0], got[3][b - 1])
+    np.testing.assert_array_equal(one[2][0], got[2][b - 1])
+    assert one[1][0] == got[1][b - 1]
+
+
 def test_fused_encoder_levels_2_3_more_frames_than_workgroups(ctx, weights_flat):
     """enc23_mfma is persistent over frames (grid = min(batch, CUs)): 600 frames on 256 CUs take two to three frames per
     workgroup -- the band's borders stay zero, the ring and the store scratch are reused -- and give the bits of the two
