@@ -37,7 +37,14 @@ int covahip_device_count(int *count) {
 
 int covahip_device_pci_bus_id(int device_id, char *out, int out_len) {
     if (!out || out_len < 13) return COVAHIP_ERR_INVALID_ARG;
+    out[0] = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) {
+        (void)hipGetLastError();   // (HIP's last error is sticky per thread: a later hipGetLastError() check must not see this one)
+        return COVAHIP_ERR_NO_DEVICE;
+    }
     if (hipDeviceGetPCIBusId(out, out_len, device_id) != hipSuccess) {
+        (void)hipGetLastError();
         out[0] = 0;
         return COVAHIP_ERR_NO_DEVICE;
     }
