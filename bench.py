@@ -562,6 +562,12 @@ def main():
                                          "this box's CPU share")
                 chain["cova_us_per_frame_upper_bound"] = round(t_cova * 1e6, 1)
             pre["full_filter_chain"] = chain
+            # the same chain through the C-ABI alone (covahip_pipe + per-stream covahip_gopfilter, no GStreamer): the library's own
+            # share of the host cost -- what an element written against include/covahip.h pays before its framework's per-buffer work
+            native = element_rate("native_chain.sh", ("4000", "16", "8"))
+            if "frames_per_s_native_chain" in native:
+                native["host_cores_one_gpu_would_need"] = "filled in below"
+            pre["native_chain_c_abi_only"] = native
         if not args.no_cpu_baseline:
             pre["cpu_tracking"] = cpu_tracking_baseline()
 
@@ -929,7 +935,7 @@ def main():
         })
         line.update(rank0)
         line.update(extras)
-        for k in ("through_gstreamer_elements", "full_filter_chain"):
+        for k in ("through_gstreamer_elements", "full_filter_chain", "native_chain_c_abi_only"):
             if k in pre:
                 line[k] = pre[k]
         if not args.no_cpu_baseline and world == 1:
@@ -943,6 +949,9 @@ def main():
                 fc = pre["full_filter_chain"]
                 fc["vs_cpu_full_chain"] = round(fc["frames_per_s_full_chain"] / cb.get("full_chain_frames_per_s", cb["value"]), 1)
                 fc["host_cores_one_gpu_would_need"] = int(line["value"] / max(1.0, fc["frames_per_s_full_chain"]) * min(16, effective_cores()))
+            nc = pre.get("native_chain_c_abi_only", {})
+            if "cpu_us_per_frame" in nc:   # process CPU time per frame (eight worker threads, OpenMP waits and the HIP runtime's threads included)
+                nc["host_cores_one_gpu_would_need"] = round(line["value"] * nc["cpu_us_per_frame"] * 1e-6, 1)
             line["gpu_over_cpu"] = round(line["value"] / world / line["cpu_baseline"]["value"], 1)
         # the long strings last, so that the numbers survive a truncated log
         line["config"] = {"workload": ("temporal stacking as a GPU gather + BlobNet + bboxcc fused (covahip_filter_forward_frames): carrier "
