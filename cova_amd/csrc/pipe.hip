@@ -21,52 +21,33 @@
 
 namespace {
 
-// counts -> offsets (exclusive scan of min(count, max_boxes)); one 1,024-thread workgroup, batch <= 1,024 * PER
-constexpr int SCAN_THREADS = 1024;
-__global__ __launch_bounds__(SCAN_THREADS) void pack_scan_kernel(const int32_t *__restrict__ counts, int batch, int max_boxes,
-                                                                 int32_t *__restrict__ offsets) {
-    __shared__ int32_t wave_tot[SCAN_THREADS / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int per = (batch + SCAN_THREADS - 1) / SCAN_THREADS;
-    const int i0 = tid * per;
+// Boxes -> packed array, one launch (round 5; rounds 2-4: a one-workgroup scan kernel + this gather = two launches, 4.6 + 4.2 us on the
+// GPU and two launches' worth of host time per batch).  Workgroup b sums min(count, max_boxes) of the frames in front of it itself
+// (at most max_batch values, a wave reduction: 1 KB from L2), writes offsets[b] -- the last one also offsets[batch] -- and moves its
+// frame's boxes.
+__global__ __launch_bounds__(64) void pack_kernel(const covahip_box *__restrict__ boxes, const int32_t *__restrict__ counts, int batch,
+                                                  int max_boxes, int32_t *__restrict__ offsets, covahip_box *__restrict__ packed) {
+    const int b = blockIdx.x, lane = threadIdx.x;
     int32_t sum = 0;
-    for (int k = 0; k < per; k++)
-        if (i0 + k < batch) sum += min(counts[i0 + k], max_boxes);
-    int32_t incl = sum;
+    for (int i = lane; i < b; i += 64) sum += min(counts[i], max_boxes);
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int32_t t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
-    if (lane == 63) wave_tot[wv] = incl;
-    __syncthreads();
-    int32_t base = 0;
-    for (int k = 0; k < wv; k++) base += wave_tot[k];
-    int32_t run = base + incl - sum;
-    for (int k = 0; k < per; k++)
-        if (i0 + k < batch) {
-            offsets[i0 + k] = run;
-            run += min(counts[i0 + k], max_boxes);
-        }
-    if (tid == SCAN_THREADS - 1) offsets[batch] = run;
-}
-
-__global__ __launch_bounds__(64) void pack_gather_kernel(const covahip_box *__restrict__ boxes, const int32_t *__restrict__ counts,
-                                                         const int32_t *__restrict__ offsets, int max_boxes,
-                                                         covahip_box *__restrict__ packed) {
-    const int b = blockIdx.x;
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     const int n = min(counts[b], max_boxes);
+    if (lane == 0) {
+        offsets[b] = sum;
+        if (b == batch - 1) offsets[batch] = sum + n;
+    }
     // 20-byte boxes as 5 dwords: consecutive lanes move consecutive dwords
     const uint32_t *src = reinterpret_cast<const uint32_t *>(boxes + (size_t)b * max_boxes);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(packed + offsets[b]);
-    for (int i = threadIdx.x; i < n * 5; i += 64) dst[i] = src[i];
+    uint32_t *dst = reinterpret_cast<uint32_t *>(packed + sum);
+    for (int i = lane; i < n * 5; i += 64) dst[i] = src[i];
 }
 
 struct Slot {
     uint8_t *h_frames = nullptr;
     int32_t *h_index = nullptr;
-    int32_t *h_meta = nullptr;       // counts [B] | offsets [B + 1]
-    covahip_box *h_packed = nullptr;
+    int32_t *h_meta = nullptr;       // counts [B] | offsets [B + 1] | pad to 64 B | packed boxes: ONE pinned allocation (and one
+    covahip_box *h_packed = nullptr; // device allocation of the same shape), so that one copy brings all of it back
     uint8_t *h_mask = nullptr;
     uint8_t *d_frames = nullptr;
     covahip_box *d_boxes = nullptr, *d_packed = nullptr;
@@ -82,6 +63,7 @@ struct Slot {
 
 struct covahip_pipe {
     covahip_ctx *ctx = nullptr;
+    size_t meta_bytes = 0;           // bytes of a slot's meta words in front of its packed boxes
     int max_batch = 0, max_frames = 0, max_boxes = 0, n_slots = 0, want_mask = 0, packed = 0;
     size_t frame_bytes = 0, hw = 0;
     int spec = 0;                    // packed boxes copied back by the pipelined D2H; grows to what the stream produces
@@ -103,12 +85,10 @@ void covahip_pipe_destroy(covahip_pipe *p) {
     for (Slot &s : p->slots) {
         if (s.h_frames) hipHostFree(s.h_frames);
         if (s.h_index) hipHostFree(s.h_index);
-        if (s.h_meta) hipHostFree(s.h_meta);
-        if (s.h_packed) hipHostFree(s.h_packed);
+        if (s.h_meta) hipHostFree(s.h_meta);   // (h_packed / d_packed point into the meta allocations)
         if (s.h_mask) hipHostFree(s.h_mask);
         if (s.d_frames) hipFree(s.d_frames);
         if (s.d_boxes) hipFree(s.d_boxes);
-        if (s.d_packed) hipFree(s.d_packed);
         if (s.d_meta) hipFree(s.d_meta);
         if (s.d_mask) hipFree(s.d_mask);
         if (s.ev_in) hipEventDestroy(s.ev_in);
@@ -127,7 +107,7 @@ int covahip_pipe_create(covahip_ctx *ctx, int max_batch, int max_frames, int max
     *out = nullptr;
     covahip_blobnet *m = ctx->blobnet;
     if (!m) return COVAHIP_ERR_NOT_LOADED;
-    if (max_batch > m->max_batch || max_frames > BN_T * m->max_batch || max_batch > SCAN_THREADS * 64) return COVAHIP_ERR_INVALID_ARG;
+    if (max_batch > m->max_batch || max_frames > BN_T * m->max_batch || max_batch > 65536) return COVAHIP_ERR_INVALID_ARG;
     COVAHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     covahip_pipe *p = new covahip_pipe();
     p->ctx = ctx;
@@ -142,18 +122,22 @@ int covahip_pipe_create(covahip_ctx *ctx, int max_batch, int max_frames, int max
         hipStreamCreateWithFlags(&p->s_d2h, hipStreamNonBlocking) != hipSuccess)
         return fail(COVAHIP_ERR_HIP);
     const size_t meta_ints = (size_t)2 * max_batch + 1;
+    const size_t meta_bytes = (meta_ints * sizeof(int32_t) + 63) & ~(size_t)63;   // the packed boxes start 64-byte aligned behind it
+    p->meta_bytes = meta_bytes;
     for (Slot &s : p->slots) {
         bool ok = hipHostMalloc((void **)&s.h_frames, (size_t)max_frames * p->frame_bytes, hipHostMallocDefault) == hipSuccess &&
                   hipHostMalloc((void **)&s.h_index, (size_t)max_batch * BN_T * sizeof(int32_t), hipHostMallocDefault) == hipSuccess &&
-                  hipHostMalloc((void **)&s.h_meta, meta_ints * sizeof(int32_t), hipHostMallocDefault) == hipSuccess &&
-                  hipHostMalloc((void **)&s.h_packed, (size_t)max_batch * max_boxes * sizeof(covahip_box), hipHostMallocDefault) == hipSuccess &&
+                  hipHostMalloc((void **)&s.h_meta, meta_bytes + (size_t)max_batch * max_boxes * sizeof(covahip_box), hipHostMallocDefault) == hipSuccess &&
                   hipMalloc((void **)&s.d_frames, (size_t)max_frames * p->frame_bytes) == hipSuccess &&
                   hipMalloc((void **)&s.d_boxes, (size_t)max_batch * max_boxes * sizeof(covahip_box)) == hipSuccess &&
-                  hipMalloc((void **)&s.d_packed, (size_t)max_batch * max_boxes * sizeof(covahip_box)) == hipSuccess &&
-                  hipMalloc((void **)&s.d_meta, meta_ints * sizeof(int32_t)) == hipSuccess &&
+                  hipMalloc((void **)&s.d_meta, meta_bytes + (size_t)max_batch * max_boxes * sizeof(covahip_box)) == hipSuccess &&
                   hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming) == hipSuccess;
+        if (ok) {
+            s.h_packed = reinterpret_cast<covahip_box *>(reinterpret_cast<uint8_t *>(s.h_meta) + meta_bytes);
+            s.d_packed = reinterpret_cast<covahip_box *>(reinterpret_cast<uint8_t *>(s.d_meta) + meta_bytes);
+        }
         if (ok && p->want_mask)
             ok = hipHostMalloc((void **)&s.h_mask, (size_t)max_batch * p->hw, hipHostMallocDefault) == hipSuccess &&
                  hipMalloc((void **)&s.d_mask, (size_t)max_batch * p->hw) == hipSuccess;
@@ -230,17 +214,16 @@ int covahip_pipe_submit(covahip_pipe *p, int slot, int n_frames, int batch, int 
     if (rc) return rc;
     {
         ProfScope ps(ctx, "pack_boxes");
-        hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, (const int32_t *)d_counts, batch, p->max_boxes, d_offsets);
-        hipLaunchKernelGGL(pack_gather_kernel, dim3(batch), dim3(64), 0, ctx->stream, (const covahip_box *)s.d_boxes, (const int32_t *)d_counts,
-                           (const int32_t *)d_offsets, p->max_boxes, s.d_packed);
+        hipLaunchKernelGGL(pack_kernel, dim3(batch), dim3(64), 0, ctx->stream, (const covahip_box *)s.d_boxes, (const int32_t *)d_counts, batch,
+                           p->max_boxes, d_offsets, s.d_packed);
     }
     PIPE_CHECK(hipGetLastError());
     PIPE_CHECK(hipEventRecord(s.ev_done, ctx->stream));
     PIPE_CHECK(hipStreamWaitEvent(p->s_d2h, s.ev_done, 0));
-    // counts [batch] and offsets [batch + 1] sit max_batch apart: one copy covers both
-    PIPE_CHECK(hipMemcpyAsync(s.h_meta, s.d_meta, ((size_t)p->max_batch + batch + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, p->s_d2h));
+    // counts [batch], offsets [batch + 1] (max_batch apart) and the packed boxes behind them are one allocation: ONE copy brings the
+    // meta words and the speculative part of the boxes
     s.spec = std::min(p->spec, batch * p->max_boxes);
-    PIPE_CHECK(hipMemcpyAsync(s.h_packed, s.d_packed, (size_t)s.spec * sizeof(covahip_box), hipMemcpyDeviceToHost, p->s_d2h));
+    PIPE_CHECK(hipMemcpyAsync(s.h_meta, s.d_meta, p->meta_bytes + (size_t)s.spec * sizeof(covahip_box), hipMemcpyDeviceToHost, p->s_d2h));
     if (p->want_mask)
         PIPE_CHECK(hipMemcpyAsync(s.h_mask, s.d_mask, (size_t)batch * p->hw, hipMemcpyDeviceToHost, p->s_d2h));
     PIPE_CHECK(hipEventRecord(s.ev_out, p->s_d2h));
