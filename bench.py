@@ -517,6 +517,9 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="developer rehearsal of the multi-rank path on a box with fewer GPUs than ranks: rank r uses GPU r %% (GPUs present); "
                          "the line then says so and its value is NOT a scaling result")
+    ap.add_argument("--control-plane-only", action="store_true",
+                    help="rehearsal of the N-rank CONTROL path alone, without a GPU: rendezvous, stream partition, NUMA / core split, "
+                         "barrier, MAX over ranks, gather, the aggregate line's shape -- no kernel runs and the line carries no rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="only the timed workload (profiling runs)")
     args = ap.parse_args()
@@ -566,7 +569,7 @@ def main():
             # share of the host cost -- what an element written against include/covahip.h pays before its framework's per-buffer work
             native = element_rate("native_chain.sh", ("4000", "16", "8"))
             if "frames_per_s_native_chain" in native:
-                native["host_cores_one_gpu_would_need"] = "filled in below"
+                native["host_cores_one_gpu_would_need"] = None   # filled in once `value` is known (below)
             pre["native_chain_c_abi_only"] = native
         if not args.no_cpu_baseline:
             pre["cpu_tracking"] = cpu_tracking_baseline()
@@ -582,21 +585,50 @@ def main():
     from cova_amd import synth, weights as W
     from cova_amd.elements import BlobNetInfer, Context
 
-    dev = local_rank
-    if args.rehearse_on_one_gpu:
-        import ctypes as C
-        from cova_amd import _lib as L
-        n_dev = C.c_int(0)
-        L.lib().covahip_device_count(C.byref(n_dev))
-        dev = local_rank % max(1, n_dev.value)
     # rank r = GPU r + the cores of that GPU's NUMA node: the per-stream host work (decoder threads, cova elements) of the
     # streams a rank owns runs next to the GPU it feeds.  Ranks whose GPUs share a node split its cores.
+    # The GPU's PCI address is asked for in a short-lived CHILD (cova_amd.multigpu.gpu_numa_in_child) and every thread this
+    # process has by now (gloo's) is bound as well: the pin is in place BEFORE the HIP runtime starts its threads, and
+    # OMP_NUM_THREADS follows the narrowed mask.
+    dev = local_rank
     pin = {"pinned": False}
-    if world > 1:
-        from cova_amd.multigpu import gpu_numa
-        nodes = grp.gather(gpu_numa(dev)[0])
-        same = [r for r in range(world) if nodes[r] == nodes[rank]]
-        pin = pin_to_gpu(dev, len(same), same.index(rank))
+    if world > 1 or args.rehearse_on_one_gpu:
+        from cova_amd.multigpu import gpu_numa_in_child, gpu_numa_sysfs
+        # sysfs first (KFD topology: no HIP call, no process on the card); the child only where the topology does not say
+        info = gpu_numa_sysfs(local_rank, modulo_present=args.rehearse_on_one_gpu)
+        if info is None and not args.control_plane_only:
+            info = gpu_numa_in_child(local_rank, modulo_present=args.rehearse_on_one_gpu)
+        node, node_cpus, dev = info if info is not None else (-1, [], local_rank)
+        if world > 1:
+            nodes = grp.gather(node)
+            same = [r for r in range(world) if nodes[r] == nodes[rank]]
+            pin = pin_to_gpu(dev, len(same), same.index(rank), node_info=(node, node_cpus), world=world, rank=rank)
+            if pin["pinned"]:
+                os.environ["OMP_NUM_THREADS"] = str(len(pin["cpus"]))
+                if grp.torch is not None:
+                    grp.torch.set_num_threads(len(pin["cpus"]))
+    if args.control_plane_only:
+        # what an 8-GPU node's launch exercises besides the kernels: every rank has joined, owns its streams, has its cores; the
+        # barrier + MAX + gather that bracket the timed region run on made-up clocks
+        grp.barrier()
+        fake_s = 1e-3 * (1 + rank)
+        slowest = grp.max(fake_s)
+        mine = {"rank": rank, "local_rank": local_rank, "device": dev, "streams": streams_of_rank(8 * world, rank, world),
+                "frames_per_step": args.batch, "numa_node": pin.get("numa_node"), "cpus": pin.get("cpus") or sorted(os.sched_getaffinity(0)),
+                "pinned": pin.get("pinned"), "threads_bound": pin.get("threads_bound"), "input_seed": 0xC07A + 1000 * rank,
+                "omp_num_threads": os.environ.get("OMP_NUM_THREADS")}
+        print(json.dumps({"bench_rank": mine}), file=sys.stderr, flush=True)
+        all_ranks = grp.gather(mine)
+        if rank == 0:
+            print(json.dumps({"metric": "compressed-domain frames/sec (BlobNet+bboxcc) at 1080p b=256", "value": None, "unit": "frames/s",
+                              "n_gpus": world, "scaling": "weak", "control_plane_only": True,
+                              "rehearsal": f"control plane of {world} ranks only, no GPU touched: NOT a measurement",
+                              "slowest_rank_region_s": slowest, "ranks": all_ranks,
+                              "control_plane": "gloo on CPU tensors (rendezvous, barrier, MAX over ranks, gather of these objects); "
+                                               "no RCCL communicator exists"}), flush=True)
+        grp.barrier()
+        grp.close()
+        return
     ctx = Context(dev)
     ctx.set_lanes(1)         # the extra legs and the per-kernel pass run one step after the other
     B = args.batch
@@ -852,12 +884,19 @@ def main():
             if k not in macs:
                 continue
             fl, by = 2.0 * macs[k] * B, kbytes[k] * B
+            # frac_hbm is priced on the bytes the fabric counters saw for this launch (the committed FETCH_SIZE x 2 + WRITE_SIZE
+            # summary, b = 256): the structural count below it includes re-reads that L2 absorbs (level 1 gathers every P slice
+            # four times: 109 MB structural, 71 MB on the fabric) and is no HBM figure
+            cnt, cnt_src = committed_traffic(k, args.entry) if B == BATCH else (None, None)
             kernels[k] = {"us_alone": round(us, 2), "alg_flop": fl, "frac_mfma": round(fl / (us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                          "hbm_bytes": by, "frac_hbm": round(by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+                          "hbm_bytes_counter": cnt, "hbm_bytes_counter_source": cnt_src,
+                          "frac_hbm": round(cnt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if cnt else None,
+                          "bytes_structural": by, "frac_hbm_structural": round(by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
         if "dec3_bboxcc_fused" in kernels:
             kernels["dec3_bboxcc_fused"]["executed_flop"] = 2.0 * fold_exec * B
             kernels["dec3_bboxcc_fused"]["note"] = "alg_flop = convT 32->16 + 1x1 as written; executed folded; bboxcc runs in the same launch"
         step_s = elapsed / args.steps
+        other_entry = rank0.get("stacked_entry" if args.entry == "frames" else "carrier_frame_entry", {})
         dom_flop = 2.0 * macs[dominant] * B
         ach_tflops = dom_flop / dom_s / 1e12
         dom_bytes = kbytes[dominant] * B
@@ -868,6 +907,16 @@ def main():
             "metric": "compressed-domain frames/sec (BlobNet+bboxcc) at 1080p b=256",
             "value": round(world * B * args.steps / elapsed, 1),
             "unit": "frames/s",
+            # the literal BASELINE config-3 input (pre-stacked tensors) and a step on its own, right beside `value`
+            "value_stacked_entry": other_entry.get("frames_per_s") if args.entry == "frames" else round(world * B * args.steps / elapsed, 1),
+            "ms_per_step_stacked_entry": other_entry.get("ms_per_step") if args.entry == "frames" else round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step_one_lane": round(serial_ms, 4),
+            "value_one_lane": round(world * B / serial_ms * 1e3, 1),
+            "schema": 6,
+            "schema_note": ("6 (round 6): roofline.alone / roofline.in_situ are both explicit; roofline.achieved / frac / avg_launch_us repeat "
+                            "roofline.alone (the dominant launch alone on the chip, as in round 5; rounds 1-4 printed the in-situ figure "
+                            "under those names); kernels{}.frac_hbm is priced on counter bytes (hbm_bytes_counter), the structural count "
+                            "moved to bytes_structural"),
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -881,8 +930,6 @@ def main():
             **({"rehearsal": f"{world} ranks shared the GPUs present on this box: NOT a scaling result"} if args.rehearse_on_one_gpu else {}),
             **({"ranks": all_ranks, "control_plane": "gloo on CPU tensors (rendezvous, barrier, MAX over ranks, gather of these objects); "
                                                       "no RCCL communicator exists"} if world > 1 else {}),
-            "ms_per_step_one_lane": round(serial_ms, 4),
-            "value_one_lane": round(world * B / serial_ms * 1e3, 1),
             "timed_regions_s": [round(r, 5) for r in regions],
             "timed_region": f"median of {len(regions)} barrier-to-barrier regions of {args.steps} steps each",
             "ms_per_step_one_batch": round(elapsed_cached / args.steps * 1e3, 4),
@@ -913,6 +960,10 @@ def main():
                          "traffic_source": dom_traffic_src,
                          "algorithmic_flop_per_launch": dom_flop, "avg_launch_us": round(serial_dom_s * 1e6, 2),
                          "measured": "HIP events on the launch's own stream, the launch alone on the chip (20 one-lane steps after the timed regions, warm)",
+                         "alone": {"avg_launch_us": round(serial_dom_s * 1e6, 2), "achieved": round(dom_flop / serial_dom_s / 1e12, 2),
+                                   "frac": round(dom_flop / serial_dom_s / 1e12 / MFMA_PEAK_TFLOPS, 4)},
+                         "in_situ": {"lanes": NL, "avg_launch_us": round(dom_s * 1e6, 2), "achieved": round(ach_tflops, 2),
+                                     "frac": round(ach_tflops / MFMA_PEAK_TFLOPS, 4)},
                          f"in_situ_{NL}_lanes": {"avg_launch_us": round(dom_s * 1e6, 2), "launches_timed": dom_n,
                                                  "achieved": round(ach_tflops, 2), "frac": round(ach_tflops / MFMA_PEAK_TFLOPS, 4),
                                                  "measured": (f"HIP events inside the timed region; with {NL} lanes the launch shares the chip with "
@@ -949,11 +1000,13 @@ def main():
             if "frames_per_s_full_chain" in pre.get("full_filter_chain", {}):
                 fc = pre["full_filter_chain"]
                 fc["vs_cpu_full_chain"] = round(fc["frames_per_s_full_chain"] / cb.get("full_chain_frames_per_s", cb["value"]), 1)
-                fc["host_cores_one_gpu_would_need"] = int(line["value"] / max(1.0, fc["frames_per_s_full_chain"]) * min(16, effective_cores()))
-            nc = pre.get("native_chain_c_abi_only", {})
-            if "cpu_us_per_frame" in nc:   # process CPU time per frame (eight worker threads, OpenMP waits and the HIP runtime's threads included)
-                nc["host_cores_one_gpu_would_need"] = round(line["value"] * nc["cpu_us_per_frame"] * 1e-6, 1)
             line["gpu_over_cpu"] = round(line["value"] / world / line["cpu_baseline"]["value"], 1)
+        nc = pre.get("native_chain_c_abi_only", {})
+        if "cpu_us_per_frame" in nc and world == 1:   # process CPU time per frame (eight worker threads, OpenMP waits and the HIP runtime's threads included)
+            nc["host_cores_one_gpu_would_need"] = round(line["value"] * nc["cpu_us_per_frame"] * 1e-6, 1)
+        fc = pre.get("full_filter_chain", {})
+        if "frames_per_s_full_chain" in fc and world == 1:
+            fc["host_cores_one_gpu_would_need"] = int(line["value"] / max(1.0, fc["frames_per_s_full_chain"]) * min(16, effective_cores()))
         # the long strings last, so that the numbers survive a truncated log
         line["config"] = {"workload": ("temporal stacking as a GPU gather + BlobNet + bboxcc fused (covahip_filter_forward_frames): carrier "
                                        "frames of 8 streams + stack table, 256 output frames, 1080p macroblock grid 68x120, T=4, inputs "

@@ -23,19 +23,55 @@ namespace {
 
 // Boxes -> packed array, one launch (round 5; rounds 2-4: a one-workgroup scan kernel + this gather = two launches, 4.6 + 4.2 us on the
 // GPU and two launches' worth of host time per batch).  Workgroup b sums min(count, max_boxes) of the frames in front of it itself
-// (at most max_batch values, a wave reduction: 1 KB from L2), writes offsets[b] -- the last one also offsets[batch] -- and moves its
-// frame's boxes.
+// (a wave reduction: at most PACK_SELF_SCAN values from L2), writes offsets[b] -- the last one also offsets[batch] -- and moves its
+// frame's boxes.  Batches larger than PACK_SELF_SCAN (the pipe admits 65,536 frames) would read batch^2 / 2 counts that way: their
+// offsets come from scan_kernel, one pass over the counts, and `pre` != nullptr.
+// Round 6, measured and NOT kept: this kernel storing counts, offsets and boxes straight into the slot's pinned host buffer (no
+// copy-engine operation on the result path, the slot's event on the lane's stream) -- DESIGN.md round 6, item 4: equal for a few
+// boxes per frame, 10 % slower at 256 boxes per frame (5 MB of the kernel's own stores across the link per batch).
+constexpr int PACK_SELF_SCAN = 1024;
+__global__ __launch_bounds__(1024) void scan_kernel(const int32_t *__restrict__ counts, int batch, int max_boxes, int32_t *__restrict__ pre) {
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < batch; base += 1024) {
+        const int i = base + tid;
+        const int32_t v = i < batch ? min(counts[i], max_boxes) : 0;
+        int32_t x = v;   // inclusive scan within the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int32_t before = carry;
+        for (int w = 0; w < wave; w++) before += wsum[w];
+        if (i < batch) pre[i] = before + x - v;
+        __syncthreads();
+        if (tid == 1023) carry = before + x;
+        __syncthreads();
+    }
+    if (tid == 0) pre[batch] = carry;
+}
 __global__ __launch_bounds__(64) void pack_kernel(const covahip_box *__restrict__ boxes, const int32_t *__restrict__ counts, int batch,
-                                                  int max_boxes, int32_t *__restrict__ offsets, covahip_box *__restrict__ packed) {
+                                                  int max_boxes, const int32_t *__restrict__ pre, int32_t *__restrict__ offsets,
+                                                  covahip_box *__restrict__ packed) {
     const int b = blockIdx.x, lane = threadIdx.x;
     int32_t sum = 0;
-    for (int i = lane; i < b; i += 64) sum += min(counts[i], max_boxes);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     const int n = min(counts[b], max_boxes);
-    if (lane == 0) {
-        offsets[b] = sum;
-        if (b == batch - 1) offsets[batch] = sum + n;
+    if (pre) {
+        sum = pre[b];   // (scan_kernel wrote offsets[] itself, offsets[batch] included: pre == offsets)
+    } else {
+        for (int i = lane; i < b; i += 64) sum += min(counts[i], max_boxes);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (lane == 0) {
+            offsets[b] = sum;
+            if (b == batch - 1) offsets[batch] = sum + n;
+        }
     }
     // 20-byte boxes as 5 dwords: consecutive lanes move consecutive dwords
     const uint32_t *src = reinterpret_cast<const uint32_t *>(boxes + (size_t)b * max_boxes);
@@ -214,8 +250,10 @@ int covahip_pipe_submit(covahip_pipe *p, int slot, int n_frames, int batch, int 
     if (rc) return rc;
     {
         ProfScope ps(ctx, "pack_boxes");
+        const bool self = batch <= PACK_SELF_SCAN;
+        if (!self) hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)d_counts, batch, p->max_boxes, d_offsets);
         hipLaunchKernelGGL(pack_kernel, dim3(batch), dim3(64), 0, ctx->stream, (const covahip_box *)s.d_boxes, (const int32_t *)d_counts, batch,
-                           p->max_boxes, d_offsets, s.d_packed);
+                           p->max_boxes, self ? (const int32_t *)nullptr : (const int32_t *)d_offsets, d_offsets, s.d_packed);
     }
     PIPE_CHECK(hipGetLastError());
     PIPE_CHECK(hipEventRecord(s.ev_done, ctx->stream));

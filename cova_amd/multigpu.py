@@ -40,13 +40,19 @@ def parse_cpulist(text: str) -> list[int]:
     return out
 
 
-def cpus_for_rank(allowed: list[int], node_cpus: list[int], sharers: int, share_index: int) -> list[int]:
+def cpus_for_rank(allowed: list[int], node_cpus: list[int], sharers: int, share_index: int,
+                  world: int = 0, rank: int = 0) -> list[int]:
     """The CPUs a rank pins itself to: the CPUs of its GPU's NUMA node that this process may use (`allowed`: its affinity mask,
     i.e. what the cgroup grants), divided evenly among the `sharers` ranks whose GPUs hang off that node (`share_index` = this
     rank's position among them).  With no usable node information (`node_cpus` empty, or disjoint from `allowed`) the allowed
-    set itself is divided.  Never returns an empty set."""
+    set itself is divided -- among ALL `world` ranks when the caller says how many there are (ranks on different nodes would
+    otherwise take identical slices of it), else among the sharers.  Never returns an empty set."""
     allowed = sorted(set(allowed))
-    pool = sorted(set(node_cpus) & set(allowed)) or allowed
+    pool = sorted(set(node_cpus) & set(allowed))
+    if not pool:
+        pool = allowed
+        if world > 0:
+            sharers, share_index = world, rank
     sharers = max(1, sharers)
     share_index = min(max(0, share_index), sharers - 1)
     if len(pool) < sharers:
@@ -56,16 +62,9 @@ def cpus_for_rank(allowed: list[int], node_cpus: list[int], sharers: int, share_
     return pool[lo:hi]
 
 
-def gpu_numa(device: int):
-    """(numa_node, cpus of that node) of HIP device `device` from sysfs; (-1, []) when unknown.  Calls into libcovahip.so
-    (hipDeviceGetPCIBusId): only from a process that is going to use the GPU anyway."""
-    import ctypes as C
-    from cova_amd import _lib as L
-    buf = C.create_string_buffer(32)
+def _numa_of_bus_id(bus_id: str):
     try:
-        if L.lib().covahip_device_pci_bus_id(device, buf, len(buf)) != 0:
-            return -1, []
-        base = os.path.join("/sys/bus/pci/devices", buf.value.decode().lower())
+        base = os.path.join("/sys/bus/pci/devices", bus_id.lower())
         node = int(open(os.path.join(base, "numa_node")).read().strip())
         cpus = parse_cpulist(open(os.path.join(base, "local_cpulist")).read())
         return node, cpus
@@ -73,17 +72,130 @@ def gpu_numa(device: int):
         return -1, []
 
 
-def pin_to_gpu(device: int, sharers: int = 1, share_index: int = 0) -> dict:
-    """Pins this process (and the threads it starts later) to the cores next to GPU `device` (cpus_for_rank).  Returns what it
-    did: {"numa_node", "cpus", "pinned"}."""
-    node, node_cpus = gpu_numa(device)
+def gpu_numa(device: int):
+    """(numa_node, cpus of that node) of HIP device `device` from sysfs; (-1, []) when unknown.  Calls into libcovahip.so
+    (hipDeviceGetPCIBusId) IN THIS PROCESS: only from a process that has initialised the GPU anyway.  A process that wants to pin
+    itself first uses gpu_numa_in_child."""
+    import ctypes as C
+    from cova_amd import _lib as L
+    buf = C.create_string_buffer(32)
+    try:
+        if L.lib().covahip_device_pci_bus_id(device, buf, len(buf)) != 0:
+            return -1, []
+        return _numa_of_bus_id(buf.value.decode())
+    except OSError:
+        return -1, []
+
+
+def kfd_gpu_bus_ids(root: str = "/sys/class/kfd/kfd/topology/nodes", dev_root: str = "/dev/dri") -> list[str]:
+    """PCI addresses ("dddd:bb:dd.f") of the GPUs this process can open, in HIP device order, from the KFD topology in sysfs -- no
+    HIP call, no GPU context, no child process: topology nodes with SIMDs are GPUs; the runtime enumerates the ones whose render
+    node (/dev/dri/renderD<drm_render_minor>) this process may open, in node order; ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES
+    lists of plain indices select from that order as the runtime does.  [] when the topology is unreadable or a list holds
+    something else than indices (UUIDs): the caller then falls back (gpu_numa_in_child)."""
+    try:
+        nodes = sorted((int(n) for n in os.listdir(root) if n.isdigit()))
+    except OSError:
+        return []
+    gpus = []
+    for n in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(os.path.join(root, str(n), "properties")) if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) == 0:
+                continue
+            minor = int(props.get("drm_render_minor", "-1"))
+            if minor >= 0 and not os.access(os.path.join(dev_root, f"renderD{minor}"), os.R_OK | os.W_OK):
+                continue
+            loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+            gpus.append(f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}")
+        except (OSError, ValueError, KeyError):
+            return []
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        text = os.environ.get(var)
+        if text is None:
+            continue
+        try:
+            idx = [int(x) for x in text.split(",") if x.strip() != ""]
+        except ValueError:
+            return []
+        gpus = [gpus[i] for i in idx if 0 <= i < len(gpus)]
+    return gpus
+
+
+def gpu_numa_sysfs(device: int, modulo_present: bool = False):
+    """(numa_node, cpus of that node, device actually meant) of HIP device `device` from sysfs alone (kfd_gpu_bus_ids); None when
+    the topology does not say.  What a rank asks BEFORE it touches the GPU: nothing here starts a runtime thread or opens the
+    device, so several ranks can ask at once without adding processes to the card."""
+    ids = kfd_gpu_bus_ids()
+    if not ids:
+        return None
+    d = device % len(ids) if modulo_present else device
+    if not 0 <= d < len(ids):
+        return None
+    node, cpus = _numa_of_bus_id(ids[d])
+    return node, cpus, d
+
+
+def gpu_numa_in_child(device: int, modulo_present: bool = False):
+    """gpu_numa, but the HIP call runs in a short-lived child process: the caller has not touched the GPU afterwards, so it can
+    still pin itself BEFORE the HIP runtime, torch and gloo start their threads (sched_setaffinity binds the calling thread and
+    the threads created later, not the ones that exist).  `modulo_present`: device % (GPUs present), the rehearsal's mapping.
+    Returns (numa_node, cpus, device actually asked)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, ctypes as C\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from cova_amd import _lib as L\n"
+        "n = C.c_int(0); L.lib().covahip_device_count(C.byref(n))\n"
+        f"d = {int(device)} % max(1, n.value) if {bool(modulo_present)} else {int(device)}\n"
+        "b = C.create_string_buffer(32)\n"
+        "rc = L.lib().covahip_device_pci_bus_id(d, b, len(b))\n"
+        "print('BUS', d, b.value.decode() if rc == 0 else '-')\n")
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+        for line in r.stdout.splitlines():
+            if line.startswith("BUS "):
+                _, d, bus = line.split()
+                node, cpus = _numa_of_bus_id(bus) if bus != "-" else (-1, [])
+                return node, cpus, int(d)
+    except (OSError, subprocess.SubprocessError, ValueError):
+        pass
+    return -1, [], device
+
+
+def pin_threads(cpus: list[int]) -> int:
+    """Binds EVERY thread this process has right now (and, through the calling thread, the ones it starts later) to `cpus`:
+    sched_setaffinity(0) alone leaves the threads that already exist -- the HIP / HSA runtime's, gloo's, OpenMP's -- where they
+    were.  Returns the number of threads bound."""
+    n = 0
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except OSError:
+        tids = []
+    for tid in tids:
+        try:
+            os.sched_setaffinity(tid, cpus)
+            n += 1
+        except OSError:
+            pass                                      # a thread that has just exited
+    os.sched_setaffinity(0, cpus)
+    return max(n, 1)
+
+
+def pin_to_gpu(device: int, sharers: int = 1, share_index: int = 0, node_info=None, world: int = 0, rank: int = 0) -> dict:
+    """Pins this process -- all of its current threads and the ones it starts later -- to the cores next to GPU `device`
+    (cpus_for_rank).  `node_info` = (numa_node, node_cpus) when the caller already has it (gpu_numa_in_child: no HIP call in
+    this process before the pin).  Returns what it did: {"numa_node", "cpus", "pinned", "threads_bound"}."""
+    node, node_cpus = node_info if node_info is not None else gpu_numa(device)
     try:
         allowed = sorted(os.sched_getaffinity(0))
-        cpus = cpus_for_rank(allowed, node_cpus, sharers, share_index)
-        os.sched_setaffinity(0, cpus)
-        return {"numa_node": node, "cpus": cpus, "pinned": True}
+        cpus = cpus_for_rank(allowed, node_cpus, sharers, share_index, world, rank)
+        n = pin_threads(cpus)
+        return {"numa_node": node, "cpus": cpus, "pinned": True, "threads_bound": n}
     except (AttributeError, OSError):
-        return {"numa_node": node, "cpus": [], "pinned": False}
+        return {"numa_node": node, "cpus": [], "pinned": False, "threads_bound": 0}
 
 
 class Group:

@@ -426,6 +426,12 @@ static gboolean bf_try_reserve(GstBlobNetFilter *s, BfPad *p, GstBuffer *buf, ui
 static gboolean bf_pack_into(GstBuffer *buf, uint16_t *dst, gsize frame_bytes, gboolean records) {
     GstMapInfo mi;
     if (gst_buffer_map(buf, &mi, GST_MAP_READ)) {
+        /* (the chain function checked the buffer it was given; a held history buffer is checked here, where it is read) */
+        if (mi.size < (records ? frame_bytes / 2 : frame_bytes)) {
+            gst_buffer_unmap(buf, &mi);
+            memset(dst, 0, frame_bytes / 2);
+            return FALSE;
+        }
         /* application/x-cova-records (round 5): the producer -- h264entropydec records=true, or any front end that writes
          * covahip_carrier_pack's form -- hands over the two-byte records themselves: a 16 KB copy at 1080p instead of reading a
          * 32 KB carrier region and packing it (the feeders' 6.4 us per frame of the round-4 chain) */
@@ -545,6 +551,7 @@ static gboolean bf_sink_event(GstPad *pad, GstObject *parent, GstEvent *ev) {
         GstVideoInfo vi;
         gboolean ok;
         gint w = 0, h = 0;
+        const gboolean was_records = p->records;
         gst_event_parse_caps(ev, &caps);
         if (gst_structure_has_name(gst_caps_get_structure(caps, 0), "application/x-cova-records")) {
             /* packed records: the grid itself is in the caps */
@@ -559,6 +566,16 @@ static gboolean bf_sink_event(GstPad *pad, GstObject *parent, GstEvent *ev) {
             /* metapreprocess' caps arithmetic (imp.rs:262-268): macroblock grid = picture / 16 */
             w = GST_VIDEO_INFO_WIDTH(&vi) / 16; h = GST_VIDEO_INFO_HEIGHT(&vi) / 16;
             p->records = FALSE;
+        }
+        if (p->records != was_records) {
+            /* the pad changed its buffer form mid-stream (serialized with this pad's chain function): the held history frames are
+             * in the OLD form -- half or twice the bytes the new mode reads -- so the stream starts its stacks over */
+            for (int k = 0; k < BF_TIMESTEP - 1; k++) {
+                if (p->hist[k]) gst_buffer_unref(p->hist[k]);
+                p->hist[k] = NULL;
+                p->hist_pos[k] = -1;
+            }
+            p->n_seen = 0;
         }
         g_mutex_lock(&s->lock);
         {

@@ -34,6 +34,7 @@ typedef struct {
     GArray *held;          /* EdHeld, unsorted; at most max_num_reorder_frames (or num_ref_frames + 1) + 1 entries */
     guint max_threads;
     gboolean records;      /* property: packed two-byte records out instead of the I420 carrier frame */
+    gboolean records_neg;  /* the property's value when the CAPS event arrived: what scratch, the src caps and ed_chain agree on */
     guint8 *scratch;       /* records = TRUE: the four-byte records of the picture being decoded */
     gint fps_n, fps_d;
 } GstEntropyDec;
@@ -77,7 +78,7 @@ static GstFlowReturn ed_chain(GstPad *pad, GstObject *parent, GstBuffer *buf) {
         gst_buffer_unref(buf);
         return GST_FLOW_NOT_NEGOTIATED;
     }
-    GstBuffer *ob = gst_buffer_new_allocate(NULL, s->records ? s->rec_bytes / 2 : s->frame_bytes, NULL);
+    GstBuffer *ob = gst_buffer_new_allocate(NULL, s->records_neg ? s->rec_bytes / 2 : s->frame_bytes, NULL);
     if (!ob || !gst_buffer_map(buf, &in, GST_MAP_READ)) {
         if (ob) gst_buffer_unref(ob);
         gst_buffer_unref(buf);
@@ -91,7 +92,7 @@ static GstFlowReturn ed_chain(GstPad *pad, GstObject *parent, GstBuffer *buf) {
         GST_ELEMENT_ERROR(s, RESOURCE, FAILED, ("cannot map the output frame"), (NULL));
         return GST_FLOW_ERROR;
     }
-    if (s->records) {
+    if (s->records_neg) {
         rc = covahip_h264_decode_au(s->h, in.data, in.size, s->scratch, s->rec_bytes, &hdr, &key);
         if (rc == COVAHIP_OK) covahip_carrier_pack(s->scratch, s->rec_bytes / 4, (uint16_t *)out.data);
     } else {
@@ -156,8 +157,9 @@ static gboolean ed_sink_event(GstPad *pad, GstObject *parent, GstEvent *ev) {
         s->rec_bytes = (gsize)s->info.width_mbs * s->info.height_mbs * 4;
         s->frame_bytes = (gsize)s->info.width_mbs * 16 * s->info.height_mbs * 16 * 3 / 2;
         g_free(s->scratch);
-        s->scratch = s->records ? g_malloc0(s->rec_bytes) : NULL;
-        if (s->records)
+        s->records_neg = s->records;   /* latched: a later g_object_set takes effect with the next CAPS event */
+        s->scratch = s->records_neg ? g_malloc0(s->rec_bytes) : NULL;
+        if (s->records_neg)
             out = gst_caps_new_simple("application/x-cova-records", "width-mbs", G_TYPE_INT, s->info.width_mbs, "height-mbs", G_TYPE_INT,
                                       s->info.height_mbs, "framerate", GST_TYPE_FRACTION, s->fps_n, s->fps_d, NULL);
         else

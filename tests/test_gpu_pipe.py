@@ -72,6 +72,30 @@ def test_more_boxes_than_the_speculative_copy_and_truncation(ctx, weights_flat):
         pipe.close()
 
 
+def test_batches_past_the_self_scan_limit_take_the_scan_kernel(ctx, weights_flat):
+    """The pack kernel's workgroups sum the counts in front of them themselves up to 1,024 frames; larger batches (the pipe admits
+    65,536) get their offsets from a one-pass scan kernel instead of batch^2 / 2 reads.  Same packed result."""
+    h, w, b, streams = 35, 60, 1100, 4
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=b)
+    frames, index = synth.carrier_batch(b, h, w, seed=911, streams=streams)
+    boxes, counts, _, _ = net.filter_frames(frames, index, 2, max_boxes=64)
+    pipe = FilterPipe(net, max_batch=b, max_frames=frames.shape[0], max_boxes=64, n_slots=2)
+    for _ in range(2):
+        slot, pf, pi = pipe.acquire()
+        pf[:frames.shape[0]] = frames
+        pi[:b] = index
+        pipe.submit(slot, frames.shape[0], b, 2)
+        c, o, bx, _m = pipe.collect(slot)
+        np.testing.assert_array_equal(c, counts)
+        np.testing.assert_array_equal(o, np.concatenate([[0], np.cumsum(np.minimum(counts, 64))]))
+        assert int(o[b]) > b                          # more than a box per frame: the offsets are not trivial
+        for i in range(0, b, 37):
+            np.testing.assert_array_equal(bx[o[i]:o[i + 1]], boxes[i, :min(counts[i], 64)])
+        np.testing.assert_array_equal(bx[o[b - 1]:o[b]], boxes[b - 1, :min(counts[b - 1], 64)])
+    pipe.acquire()
+    pipe.close()
+
+
 def test_pipe_argument_checks(ctx, weights_flat):
     lib = L.lib()
     net = BlobNetInfer(ctx, weights_flat, 45, 80, max_batch=8)

@@ -37,6 +37,39 @@ def test_cpulist_and_core_shares():
     assert cpus_for_rank([5], [5], 8, 7) == [5]                   # fewer cores than ranks: shared
     parts = [cpus_for_rank(list(range(10)), [], 3, k) for k in range(3)]
     assert sorted(c for p_ in parts for c in p_) == list(range(10)) and all(parts)
+    # ranks on DIFFERENT nodes whose nodes are all outside the grant: each one is the only sharer of its node, and without the
+    # world / rank arguments every one of them would take the whole grant -- with them the grant is split among all ranks
+    grant = list(range(8))
+    outside = [list(range(100 + 10 * r, 110 + 10 * r)) for r in range(4)]
+    shares = [cpus_for_rank(grant, outside[r], 1, 0, world=4, rank=r) for r in range(4)]
+    assert shares == [[0, 1], [2, 3], [4, 5], [6, 7]]
+    assert cpus_for_rank(grant, outside[0], 1, 0) == grant                      # (the old call: no world given)
+    assert cpus_for_rank(allowed, node, 2, 1, world=8, rank=5) == list(range(24, 32))   # node known: world / rank play no part
+
+
+def test_pin_binds_the_threads_that_already_exist():
+    """sched_setaffinity(0) binds the calling thread only: a process that pins itself after a runtime has started threads must
+    walk /proc/self/task (multigpu.pin_threads).  Run in a child so that the test runner keeps its own mask."""
+    code = (
+        "import os, sys, threading, time\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from cova_amd.multigpu import pin_threads\n"
+        "allowed = sorted(os.sched_getaffinity(0))\n"
+        "ev = threading.Event(); tids = []\n"
+        "def w():\n"
+        "    tids.append(threading.get_native_id()); ev.wait()\n"
+        "ts = [threading.Thread(target=w) for _ in range(3)]\n"
+        "[t.start() for t in ts]\n"
+        "while len(tids) < 3: time.sleep(0.01)\n"
+        "target = allowed[:1]\n"
+        "n = pin_threads(target)\n"
+        "masks = [sorted(os.sched_getaffinity(t)) for t in tids] + [sorted(os.sched_getaffinity(0))]\n"
+        "ev.set(); [t.join() for t in ts]\n"
+        "assert n >= 4, n\n"
+        "assert all(m == target for m in masks), masks\n"
+        "print('PINNED', n)\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "PINNED" in r.stdout, r.stderr[-2000:]
 
 
 def test_group_is_gloo_only():
@@ -71,3 +104,38 @@ def test_two_rank_gloo_job(tmp_path):
     for r_ in ranks:
         for res in r_["results"]:
             assert res["emitted"] == 117 and res["dead_tracks"] == 1
+
+
+def test_eight_rank_control_path_of_bench():
+    """the exact 8-way control path of `bench.py --gpus 8` -- the ranks started as a child before anything
+    touches a GPU, rendezvous on 127.0.0.1, stream partition, NUMA / core split with its documented sharing fallback, barrier,
+    MAX over ranks, gather, ONE aggregate line -- runs once before an 8-GPU node ever sees it.  No kernel runs
+    (--control-plane-only): the pool's process guard admits six processes on a card, so eight GPU ranks are the driver's to
+    launch, not a test's.  Partition to match: gst-plugins/gst-gopsplit/gstgopsplit.cpp:556-603."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--control-plane-only"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE aggregate line on stdout"
+    line = lines[0]
+    assert line["n_gpus"] == 8 and line["value"] is None and line["control_plane_only"] and "NOT a measurement" in line["rehearsal"]
+    assert "no RCCL" in line["control_plane"] and line["scaling"] == "weak"
+    ranks = line["ranks"]
+    assert [x["rank"] for x in ranks] == list(range(8))
+    sets = [set(x["streams"]) for x in ranks]
+    assert all(sets) and set().union(*sets) == set(range(64)) and sum(len(s) for s in sets) == 64   # eight disjoint stream sets
+    for r_, x in enumerate(ranks):
+        assert all(s % 8 == r_ for s in x["streams"])
+    assert len({x["input_seed"] for x in ranks}) == 8
+    assert abs(line["slowest_rank_region_s"] - 8e-3) < 1e-9                                            # MAX over the ranks' clocks
+    allowed = sorted(os.sched_getaffinity(0))
+    cpus = [x["cpus"] for x in ranks]
+    assert all(c and set(c) <= set(allowed) for c in cpus)
+    if len(allowed) >= 8 and all(x["pinned"] for x in ranks):
+        flat = [c for cs in cpus for c in cs]
+        assert len(flat) == len(set(flat)), "eight ranks split the granted cores"                      # eight disjoint core sets
+    else:
+        assert all(c == cpus[0] for c in cpus) or all(x["pinned"] for x in ranks)                      # the documented sharing fallback
+    per_rank = [json.loads(l)["bench_rank"] for l in r.stderr.splitlines() if l.startswith('{"bench_rank"')]
+    assert sorted(x["rank"] for x in per_rank) == list(range(8))
