@@ -241,12 +241,14 @@ __device__ __forceinline__ int frame_wave(const uint8_t *m, uint8_t *sm, const W
 // the row masks of phase B for itself (a few dozen instructions); in phase C wave w takes the runs w, w + NTH / 64, ... of
 // every block row.  Run capacity is the worst case (one run per block): nothing overflows.
 // m: H x W mask bytes (LDS or HBM, 8-byte aligned); sm: g.wave_bytes of LDS; called by all NTH threads.
-template <int NTH>
+// PLANES (round 6, dec3cc_rows_mfma): the parity planes are there already (`planes`, the layout of phase A: [2 BH + 2][E lo, E hi,
+// O lo, O hi], pixel row y at y + 1, complete and behind a workgroup barrier); phase A is skipped and `m` is not read.
+template <int NTH, bool PLANES = false>
 __device__ __forceinline__ void frame_wg(const uint8_t *m, uint8_t *sm, const WvGeom &g, int area_thresh, covahip_box *ob,
-                                         int32_t *count_out, int max_boxes, int tid) {
+                                         int32_t *count_out, int max_boxes, int tid, uint32_t *planes = nullptr) {
     constexpr int NWV = NTH / 64;
     const int lane = tid & 63, wave = tid >> 6;
-    uint32_t *rows = reinterpret_cast<uint32_t *>(sm);
+    uint32_t *rows = PLANES ? planes : reinterpret_cast<uint32_t *>(sm);
     uint32_t *lab = reinterpret_cast<uint32_t *>(sm + g.rows_bytes);
     uint32_t *s_area = lab + g.cap, *s_minx = s_area + g.cap, *s_maxx = s_minx + g.cap, *s_miny = s_maxx + g.cap,
              *s_maxy = s_miny + g.cap;
@@ -256,6 +258,7 @@ __device__ __forceinline__ void frame_wg(const uint8_t *m, uint8_t *sm, const Wv
 #endif
 
     // ---- A
+    if constexpr (!PLANES) {
     for (int i = tid; i < g.rows_bytes / 4; i += NTH) rows[i] = 0;
     __syncthreads();
     const int npieces = g.H * g.NXB;
@@ -272,6 +275,7 @@ __device__ __forceinline__ void frame_wg(const uint8_t *m, uint8_t *sm, const Wv
         if (o) atomicOr(rw + 2, o << sh);
     }
     __syncthreads();
+    }
     CCWG_MARK(0);   // A: bit planes
     // ---- B (every wave for itself)
     uint64_t a = 0, b = 0, c = 0, d = 0, ue = 0, uo = 0;

@@ -51,6 +51,7 @@ struct covahip_blobnet {
     int fuse_tail = 1;  // MFMA path, with bboxcc requested: last decoder block + bboxcc in one launch
     int fuse_dec = 1;  // MFMA path: decoder blocks 0..2 as one launch (a frame's three input tiles side by side in LDS) when they fit
     int enc1_tile16 = 1;  // MFMA path: level 1 on 16-position tiles (enc1_mfma) where the row fits its fixed LDS stride
+    int tail_rows = 1;    // MFMA path: the fused tail on row tiles with ballots straight into bboxcc's planes (dec3cc_rows_mfma, round 6)
     int tail_part = 1;    // MFMA path: the last decoder block's skip half computed by the level-1 kernel as partial logits (enc1_mfma only)
     int fuse_enc23 = 1;   // MFMA path: encoder levels 2 + 3 in one launch (enc23_mfma: level 2's output stays in LDS as level 3's band) when they fit
                           // and the batch / geometry make it pay; 0: never, 2: whenever they fit

@@ -279,12 +279,13 @@ int covahip_blobnet_set_enc_plan(covahip_ctx *ctx, int level, int nbands, int nb
 
 int covahip_blobnet_set_impl(covahip_ctx *ctx, int impl) {
     if (!ctx || !ctx->blobnet) return COVAHIP_ERR_NOT_LOADED;
-    if (impl != 1 && (impl < 4 || impl > 9)) return COVAHIP_ERR_INVALID_ARG;
+    if (impl != 1 && (impl < 4 || impl > 10)) return COVAHIP_ERR_INVALID_ARG;
     ctx->blobnet->fuse_dec = impl != 4;
     ctx->blobnet->enc1_tile16 = impl != 5;
     ctx->blobnet->enc_rowtiles = impl != 6;
     ctx->blobnet->fuse_enc23 = impl == 7 ? 0 : impl == 8 ? 2 : 1;
     ctx->blobnet->tail_part = impl != 9;
+    ctx->blobnet->tail_rows = impl != 10;
     return COVAHIP_OK;
 }
 

@@ -1979,11 +1979,15 @@ __global__ __launch_bounds__(512, 2) void dec012_mfma(Dec012Args p) {
 #ifdef PHASE_TIMING
     unsigned long long ph_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memrealtime();
 #endif
+    // border pieces only: disjoint from what the tile requests fill, and ordered in front of the first tile reads by the barrier
+    // behind the landing
     dec012_zero_border<128>(t0, p.lv[0], tid);
     dec012_zero_border<128>(t1, p.lv[1], tid);
     dec012_zero_border<64>(t2, p.lv[2], tid);
     for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
-        lds_barrier();   // the previous frame's last block has left its tile (first frame: the borders are written)
+        // the previous frame's last block has left its tiles.  The FIRST frame of a workgroup (at b <= CUs the only one) has nothing
+        // to wait for: its weights and tile requests go out at once (round 6)
+        if (b != (int)blockIdx.x) lds_barrier();
         PHASE_MARK(0);
         {
             Dec012W<128, 64> w0;
@@ -2099,7 +2103,7 @@ __global__ __launch_bounds__(ccbody::CC_THREADS) void dec3cc_mfma(Dec3ccArgs q) 
                 }
             }
         };
-        lds_barrier();   // the previous frame's bboxcc is done with the band buffers it reuses
+        if (b != (int)blockIdx.x) lds_barrier();   // the previous frame's bboxcc is done with the band buffers it reuses (the first frame has none)
         PHASE_MARK(0);
         if constexpr (PART) {   // the frame's partial logits: one 16-byte piece per grid position
             const uint8_t *ps = reinterpret_cast<const uint8_t *>(p.part) + (size_t)b * GH * GW * 16;
@@ -2176,6 +2180,157 @@ __global__ __launch_bounds__(ccbody::CC_THREADS) void dec3cc_mfma(Dec3ccArgs q) 
         else
             ccbody::bboxcc_frame(mfull, smem + q.cc_off, q.g, q.area_thresh, q.boxes + (size_t)b * q.max_boxes, q.counts + b,
                                  q.max_boxes, tid);
+        PHASE_MARK(7);   // bboxcc
+    }
+#ifdef PHASE_TIMING
+    if (tid == 0)
+        for (int i = 0; i < 9; i++) atomicAdd(&g_phase[64 + i], ph_[i]);
+#endif
+    WGSPAN_END(4);
+}
+
+// ------------------------------------------------------------------ last decoder block + bboxcc fused, ROW tiles (round 6)
+// dec3cc_mfma<true, true> spent most of its vector instructions around four products per tile: positions of a band wrap around grid rows
+// at tile-dependent places (a division, four tap addresses with their swizzles per tile), every lane tests the bounds of its four
+// output pixels and stores them as BYTES into the frame's mask in LDS (bank-conflicted ds_write_b8), the staging loop decomposes
+// every 16-byte piece, and bboxcc then reads those bytes back and packs them into its parity planes.  Here
+//   * a tile is 32 consecutive grid positions of ONE grid row (two tiles per row for rows of up to 64 positions): the row is
+//     wave-uniform, a tap's fragment address is [lane constant of the tile half] + [row offset], the swizzle depends on the pixel
+//     column alone ((xx >> 3) & 1: the 16 lanes of a ds_read_b128 group that fall on one bank group are 8 or 24 pixels apart);
+//   * the four logits of a position are compared and BALLOTED: bit v of a ballot is output pixel (2u + py - cy, 2v + px - cx), i.e.
+//     a ballot IS a piece of a parity plane of bboxcc (E = even x, O = odd x, bboxcc_wave.h) -- shifted by the crop offset and ORed
+//     into the plane words by one lane; no mask bytes exist in LDS, bboxcc starts at its phase B;
+//   * the mask bytes the caller asked for are expanded from the planes, 4 bytes per thread and store;
+//   * the tile's skip-less input ("up" half, 16 channels) is requested row by row (a wave takes whole rows, two requests per row),
+//     its border is written as zeros.
+// Same products in the same order, same logit expression: logits, mask, boxes and their order are bit-identical to dec3cc_mfma<true,
+// true> (tests/test_gpu_blobnet.py).  Taken when the partial-logit form runs, the frame's tile fits one buffer, a grid row has at
+// most 64 positions and the run-based bboxcc body takes the shape.
+__global__ __launch_bounds__(ccbody::CC_THREADS) void dec3cc_rows_mfma(Dec3ccArgs q) {
+    constexpr int NW = ccbody::CC_THREADS / 64, PS = 32;   // 16 channels per pixel
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const DecArgs &p = q.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int TC = p.Wi + 2, GW = p.Wi + 1, GH = p.Hi + 1;
+    const int kh = lane >> 5, pos = lane & 31;
+    const float fbias = p.epi[0];
+    uint32_t *const planes = reinterpret_cast<uint32_t *>(smem + q.mfull_off);   // [2 BH + 2][E lo, E hi, O lo, O hi], pixel row y at y + 1
+    const f32x4 *const part = reinterpret_cast<const f32x4 *>(smem + q.part_off);
+    WGSPAN_BEGIN();
+#ifdef PHASE_TIMING
+    unsigned long long ph_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memrealtime();
+#endif
+    // lane constants of the two tile halves x two tap columns: pixel column xx = 32 h + pos + 1 - bb (clamped to the grid's last
+    // position: lanes past the row's end compute on that pixel and are masked out of the ballots)
+    uint32_t lc[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int bb = 0; bb < 2; bb++) {
+            const int xx = min(32 * h + pos, GW - 1) + 1 - bb;
+            lc[h][bb] = (uint32_t)(xx * PS + ((kh ^ ((xx >> 3) & 1)) << 4));
+        }
+    const int row_b = TC * PS;
+    for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+        half8 wf[4];   // (re)loaded per frame: their registers are free again while bboxcc runs
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) wf[ks] = p.wfrag[ks * 64 + lane];
+        if (b != (int)blockIdx.x) lds_barrier();   // the previous frame's bboxcc is done with the tile buffer it reuses
+        PHASE_MARK(0);
+        {   // the frame's partial logits: one 16-byte piece per grid position
+            const uint8_t *ps = reinterpret_cast<const uint8_t *>(p.part) + (size_t)b * GH * GW * 16;
+            const int nch = GH * GW;
+            for (int s0 = wave * 64; s0 < nch; s0 += NW * 64)
+                if (s0 + lane < nch) glds16(ps + (size_t)(s0 + lane) * 16, smem + q.part_off + s0 * 16);
+        }
+        {   // the tile: rows 1 .. Hi by request (a wave takes whole rows), the border as zeros (bboxcc's arrays overwrite it every frame)
+            const __half *su = p.up + (size_t)b * p.Hi * p.Wi * 16;
+            const int NI = 2 * p.Wi;   // interior 16-byte pieces of a row
+            for (int y = wave; y < p.Hi; y += NW) {
+                const __half *rowp = su + (size_t)y * p.Wi * 16;
+                uint8_t *rowl = smem + ((y + 1) * TC + 1) * PS;
+                for (int q0 = 0; q0 < NI; q0 += 64) {
+                    const int qq = q0 + lane, px = qq >> 1;
+                    const int cb = ((qq & 1) ^ (((px + 1) >> 3) & 1)) * 8;
+                    if (qq < NI) glds16(rowp + px * 16 + cb, rowl + q0 * 16);
+                }
+            }
+            const int n_rows = 4 * TC, n_cols = 4 * p.Hi;   // top + bottom row; left + right pixel of the rows between (2 pieces per pixel)
+            for (int i = tid; i < n_rows + n_cols; i += NW * 64) {
+                int piece;
+                if (i < n_rows) {
+                    piece = i < 2 * TC ? i : (p.Hi + 1) * 2 * TC + (i - 2 * TC);
+                } else {
+                    const int j = i - n_rows, y = j >> 2, k = j & 3;
+                    piece = (y + 1) * 2 * TC + (k < 2 ? k : (p.Wi + 1) * 2 + (k - 2));
+                }
+                *reinterpret_cast<uint4 *>(smem + piece * 16) = uint4{0, 0, 0, 0};
+            }
+            for (int i = tid; i < q.wg.rows_bytes / 4; i += NW * 64) planes[i] = 0;
+        }
+        PHASE_MARK(1);   // requesting the tile (+ weights)
+        wait_vmem();
+        lds_barrier();
+        PHASE_MARK(2);   // tile landing
+        for (int t = wave; t < 2 * GH; t += NW) {
+            const int u = t >> 1, h = t & 1;
+            if (32 * h >= GW) continue;   // rows of at most 32 positions have one tile
+            const uint32_t rb = (uint32_t)(u * row_b);   // tile row u holds input row u - 1 (tap a = 1); tap a = 0 one row further
+            const uint32_t a00 = rb + row_b + (h ? lc[1][0] : lc[0][0]), a01 = rb + row_b + (h ? lc[1][1] : lc[0][1]);
+            const uint32_t a10 = rb + (h ? lc[1][0] : lc[0][0]), a11 = rb + (h ? lc[1][1] : lc[0][1]);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0], *reinterpret_cast<const half8 *>(smem + a00), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1], *reinterpret_cast<const half8 *>(smem + a01), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[2], *reinterpret_cast<const half8 *>(smem + a10), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[3], *reinterpret_cast<const half8 *>(smem + a11), acc, 0, 0, 0);
+            const int v = 32 * h + pos;
+            const bool live = kh == 0 && v < GW;
+            const f32x4 pl = part[u * GW + min(v, GW - 1)];
+            float l[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) l[r] = (acc[r] + fbias) + pl[r];
+            if (p.logits && live) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int Y = 2 * u + (r >> 1) - p.cy, X = 2 * v + (r & 1) - p.cx;
+                    if (Y >= 0 && Y < p.Hd && X >= 0 && X < p.Wd) p.logits[((size_t)b * p.Hd + Y) * p.Wd + X] = l[r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                // bit v - 32 h of the ballot = output pixel (Y, 2 v + X0): plane X0 & 1, plane bit v + (X0 >> 1)
+                const uint64_t bits = (uint64_t)(uint32_t)__ballot(live && l[r] > 0.f) << (32 * h);
+                const int Y = 2 * u + (r >> 1) - p.cy, X0 = (r & 1) - p.cx;
+                const int pln = X0 & 1, sh = X0 >> 1;                         // (arithmetic shift: floor)
+                const int nb = (p.Wd - pln + 1) >> 1;                          // pixels of this plane in a row
+                uint64_t w = sh >= 0 ? bits << sh : bits >> (-sh);
+                w &= nb >= 64 ? ~0ull : ((1ull << nb) - 1);
+                if (Y >= 0 && Y < p.Hd && lane == 0) {
+                    uint32_t *rw = planes + (Y + 1) * 4 + 2 * pln;
+                    if ((uint32_t)w) atomicOr(rw, (uint32_t)w);
+                    if ((uint32_t)(w >> 32)) atomicOr(rw + 1, (uint32_t)(w >> 32));
+                }
+            }
+        }
+        PHASE_MARK(4);   // tiles
+        lds_barrier();   // the frame's planes are complete; the tile buffer is free
+        PHASE_MARK(5);   // barrier
+        if (p.mask) {    // four mask bytes per thread and store, out of the planes (W is a multiple of 8: ccwave::wv_plan)
+            uint32_t *dst = reinterpret_cast<uint32_t *>(p.mask + (size_t)b * p.Hd * p.Wd);
+            const int wq = p.Wd >> 2, nq = p.Hd * wq;
+            for (int i = tid; i < nq; i += NW * 64) {
+                const int y = fdiv(i, p.mRC), xq = i - y * wq;   // (mRC = magic(Wd / 4) for this kernel)
+                const int bx = 2 * xq;
+                const uint32_t *rw = planes + (y + 1) * 4 + (bx >> 5);
+                const uint32_t e2 = (rw[0] >> (bx & 31)) & 3u, o2 = (rw[2] >> (bx & 31)) & 3u;
+                dst[i] = (e2 & 1u) | ((o2 & 1u) << 8) | ((e2 >> 1) << 16) | ((o2 >> 1) << 24);
+            }
+        }
+        PHASE_MARK(6);   // mask out
+        ccwave::frame_wg<ccbody::CC_THREADS, true>(nullptr, smem + q.cc_off, q.wg, q.area_thresh, q.boxes + (size_t)b * q.max_boxes,
+                                                   q.counts + b, q.max_boxes, tid, planes);
         PHASE_MARK(7);   // bboxcc
     }
 #ifdef PHASE_TIMING
@@ -2971,6 +3126,16 @@ int blobnet_forward_mfma(covahip_ctx *ctx, covahip_blobnet *m, BnWorkspace &ws, 
                        t.part_off = (int)((size_t)t.mfull_off + mfull);
                        const size_t tl = (size_t)t.part_off + partb;
                        const dim3 grid3(std::min(batch, 2 * num_cu)), wg3(ccbody::CC_THREADS);
+                       // row tiles + ballots straight into bboxcc's planes (dec3cc_rows_mfma) when the shape allows it
+                       if (half && t.use_wv && best_nb == 1 && in.W + 1 <= 64 && m->tail_rows && (out.W & 7) == 0 &&
+                           (size_t)t.wg.rows_bytes <= mfull && (!d_mask || (reinterpret_cast<uintptr_t>(d_mask) & 3) == 0)) {
+                           t.d.swz = Swz{3, 1, 0, 0, 0};            // s = (xx >> 3) & 1 (what the staging of both forms evaluates)
+                           t.d.mRC = magic(out.W / 4);               // the mask expansion's division
+                           if (set_lds(ctx, dec3cc_rows_mfma, tl)) return false;
+                           ProfScope ps(ctx, "dec3_bboxcc_fused");
+                           LAUNCH(dec3cc_rows_mfma, grid3, wg3, tl, ctx->stream, t);
+                           return true;
+                       }
                        if (half) {
                            if (t.use_wv ? set_lds(ctx, dec3cc_mfma<true, true>, tl) : set_lds(ctx, dec3cc_mfma<false, true>, tl)) return false;
                            ProfScope ps(ctx, "dec3_bboxcc_fused");

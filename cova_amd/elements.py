@@ -184,7 +184,7 @@ class BlobNetInfer:
         fits (the default takes the single launch when the batch fills the chip and the rows fill their tile columns);
         "tail_skip_tensor": the last decoder block reads the level-0 skip tensor (rounds 1-4) instead of the partial logits the
         level-1 kernel computes from it (round 5 default; another summation order, not another value)."""
-        L.check(self._lib.covahip_blobnet_set_impl(self.ctx.handle, {"mfma": 1, "dec_separate": 4, "enc1_legacy": 5, "enc_general_tiles": 6, "enc23_separate": 7, "enc23_force": 8, "tail_skip_tensor": 9}[impl]), "set_impl")
+        L.check(self._lib.covahip_blobnet_set_impl(self.ctx.handle, {"mfma": 1, "dec_separate": 4, "enc1_legacy": 5, "enc_general_tiles": 6, "enc23_separate": 7, "enc23_force": 8, "tail_skip_tensor": 9, "tail_band_tiles": 10}[impl]), "set_impl")
 
     @property
     def macs_per_frame(self) -> int:

@@ -380,6 +380,56 @@ def test_tail_partial_logits_match_the_skip_tensor_form(ctx, weights_flat, hw, m
     assert differ.mean() < 1e-3
 
 
+@pytest.mark.parametrize("hw", [(68, 120), (67, 120), (45, 80), (35, 60), (61, 104), (24, 32), (128, 120)])
+@pytest.mark.parametrize("mixed_gamma", [False, True])
+def test_tail_row_tiles_and_ballot_planes_match_the_band_tiles(ctx, weights_flat, hw, mixed_gamma):
+    """Round 6: the fused tail on ROW tiles (dec3cc_rows_mfma): a tile = 32 positions of one grid row, the four logits of a position
+    are balloted straight into bboxcc's parity planes (no mask bytes in LDS, bboxcc starts at its phase B), the mask the caller asked
+    for is expanded from the planes.  Against the band-tile form (developer switch "tail_band_tiles", round 5's dec3cc_mfma): the
+    same products in the same order -> logits, masks, counts, boxes AND their order are bit-identical; odd / even grids (crop
+    offsets, rows of one and two tiles, a partial second tile), both gamma sign classes, with and without the logits / mask outputs,
+    more frames than workgroups (600 frames: the tile's border and the planes are rewritten per frame)."""
+    h, w = hw
+    b = 12
+    flat = _mixed_gamma_weights(57) if mixed_gamma else weights_flat
+    frames, index = synth.carrier_batch(b, h, w, seed=43, streams=2)
+    net = BlobNetInfer(ctx, flat, h, w, max_batch=b)
+    got = net.filter_frames(frames, index, 1, max_boxes=2048, want_mask=True, want_logits=True)
+    lean = net.filter_frames(frames, index, 3, max_boxes=64)            # no mask, no logits, another threshold, truncation
+    net.set_impl("tail_band_tiles")
+    try:
+        got2 = net.filter_frames(frames, index, 1, max_boxes=2048, want_mask=True, want_logits=True)
+        lean2 = net.filter_frames(frames, index, 3, max_boxes=64)
+    finally:
+        net.set_impl("mfma")
+    for a, c in zip(got[1:], got2[1:]):
+        np.testing.assert_array_equal(a, c)
+    np.testing.assert_array_equal(lean[1], lean2[1])
+    for i in range(b):
+        n = min(int(got[1][i]), 2048)                                   # (entries behind a frame's count are unspecified)
+        np.testing.assert_array_equal(got[0][i, :n], got2[0][i, :n])
+        n = min(int(lean[1][i]), 64)
+        np.testing.assert_array_equal(lean[0][i, :n], lean2[0][i, :n])
+    assert got[1].sum() > 0 and (got[2] == (got[3] > 0)).all()
+
+
+def test_tail_row_tiles_more_frames_than_workgroups(ctx, weights_flat):
+    h, w, b = 68, 120, 600
+    frames, index = synth.carrier_batch(b, h, w, seed=47, streams=5)
+    net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=b)
+    got = net.filter_frames(frames, index, 1, max_boxes=1024, want_mask=True)
+    net.set_impl("tail_band_tiles")
+    try:
+        got2 = net.filter_frames(frames, index, 1, max_boxes=1024, want_mask=True)
+    finally:
+        net.set_impl("mfma")
+    np.testing.assert_array_equal(got[1], got2[1])
+    np.testing.assert_array_equal(got[2], got2[2])
+    for i in range(b):
+        n = min(int(got[1][i]), 1024)
+        np.testing.assert_array_equal(got[0][i, :n], got2[0][i, :n])
+
+
 @pytest.mark.parametrize("b", [1, 7, 33, 191, 192, 193, 255, 257])
 def test_default_chain_across_batch_sizes(ctx, weights_flat, b):
     """The default kernel chain picks its forms by batch size (levels 2 + 3 as one launch from three quarters of a frame per CU
