@@ -106,7 +106,7 @@ def kernel_bytes_per_frame():
 
 PMC_KERNEL_KEYS = {"enc0p_mfma": "enc0p_mfma", "enc1_mfma": "enc1_mfma<", "enc2_mfma": "enc_mfma<32, 64",
                    "enc3_mfma": "enc_mfma<64, 128", "enc23_mfma": "enc23_mfma", "dec0_mfma": "dec_mfma<0, 128", "dec1_mfma": "dec_mfma<64, 64",
-                   "dec2_mfma": "dec_mfma<32, 32", "dec012_mfma": "dec012_mfma", "dec3_final_mfma": "dec_mfma<16, 16", "dec3_bboxcc_fused": "dec3cc_mfma",
+                   "dec2_mfma": "dec_mfma<32, 32", "dec012_mfma": "dec012_mfma", "dec3_final_mfma": "dec_mfma<16, 16", "dec3_bboxcc_fused": "dec3cc_",
                    "bboxcc_kernel": "bboxcc_kernel"}
 
 
@@ -503,6 +503,13 @@ def element_rate(script="element_bench.sh", args=("20000", "8", str(CC_THRESHOLD
         return {"error": repr(e)[:200]}
 
 
+def rank_line(mine):
+    """One rank's object on stderr as ONE write (line + newline together: eight ranks share the pipe, and print() sends the newline
+    separately -- two ranks' lines then run into each other)."""
+    sys.stderr.write(json.dumps({"bench_rank": mine}) + "\n")
+    sys.stderr.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -571,6 +578,10 @@ def main():
             if "frames_per_s_native_chain" in native:
                 native["host_cores_one_gpu_would_need"] = None   # filled in once `value` is known (below)
             pre["native_chain_c_abi_only"] = native
+            # the pinned pipeline driven from C (no interpreter in the loop), three lanes x six slots (what `blobnetfilter` runs), on a
+            # seeded random batch, beside the SAME batch resident in HBM through covahip_filter_forward_frames_packed: the PCIe-inclusive
+            # share of the resident rate on one input (round 6)
+            pre["pcie_inclusive_c_driver"] = element_rate("pipe_host_cost.sh", ("--bench",))
         if not args.no_cpu_baseline:
             pre["cpu_tracking"] = cpu_tracking_baseline()
 
@@ -596,7 +607,9 @@ def main():
         from cova_amd.multigpu import gpu_numa_in_child, gpu_numa_sysfs
         # sysfs first (KFD topology: no HIP call, no process on the card); the child only where the topology does not say
         info = gpu_numa_sysfs(local_rank, modulo_present=args.rehearse_on_one_gpu)
-        if info is None and not args.control_plane_only:
+        # (the child opens the device for a moment: in a rehearsal of more than three ranks on one card that would double the processes
+        # on it -- the pool admits six --, so there the node simply stays unknown and the granted cores are split among the ranks)
+        if info is None and not args.control_plane_only and not (args.rehearse_on_one_gpu and world > 3):
             info = gpu_numa_in_child(local_rank, modulo_present=args.rehearse_on_one_gpu)
         node, node_cpus, dev = info if info is not None else (-1, [], local_rank)
         if world > 1:
@@ -617,7 +630,7 @@ def main():
                 "frames_per_step": args.batch, "numa_node": pin.get("numa_node"), "cpus": pin.get("cpus") or sorted(os.sched_getaffinity(0)),
                 "pinned": pin.get("pinned"), "threads_bound": pin.get("threads_bound"), "input_seed": 0xC07A + 1000 * rank,
                 "omp_num_threads": os.environ.get("OMP_NUM_THREADS")}
-        print(json.dumps({"bench_rank": mine}), file=sys.stderr, flush=True)
+        rank_line(mine)
         all_ranks = grp.gather(mine)
         if rank == 0:
             print(json.dumps({"metric": "compressed-domain frames/sec (BlobNet+bboxcc) at 1080p b=256", "value": None, "unit": "frames/s",
@@ -849,7 +862,7 @@ def main():
             "ms_per_step_one_lane": round(serial_ms, 4), "numa_node": pin.get("numa_node"), "cpus": pin.get("cpus"),
             "pinned": pin.get("pinned"), "input_seed": seed}
     if world > 1:
-        print(json.dumps({"bench_rank": mine}), file=sys.stderr, flush=True)
+        rank_line(mine)
     all_ranks = grp.gather(mine)
 
     if rank == 0:
@@ -987,7 +1000,7 @@ def main():
         })
         line.update(rank0)
         line.update(extras)
-        for k in ("through_gstreamer_elements", "full_filter_chain", "native_chain_c_abi_only"):
+        for k in ("through_gstreamer_elements", "full_filter_chain", "native_chain_c_abi_only", "pcie_inclusive_c_driver"):
             if k in pre:
                 line[k] = pre[k]
         if not args.no_cpu_baseline and world == 1:

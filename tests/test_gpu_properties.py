@@ -162,5 +162,27 @@ def test_bench_two_ranks_rehearsed_on_this_gpu():
         assert not (set(ranks[0]["cpus"]) & set(ranks[1]["cpus"])), "two ranks on one NUMA node split its cores"
     # the aggregate is both ranks' frames over the slowest rank's region
     assert abs(line["value"] - 2 * line["config"]["batch_per_gpu"] * line["steps"] / (line["ms_per_step"] * 1e-3 * line["steps"])) / line["value"] < 1e-3
-    per_rank = [json.loads(l)["bench_rank"] for l in r.stderr.splitlines() if l.startswith('{"bench_rank"')]
+    per_rank = [json.loads(l)["bench_rank"] for l in r.stderr.splitlines() if l.startswith('{"bench_rank"')]   # (one write per line: bench.rank_line)
     assert sorted(x["rank"] for x in per_rank) == [0, 1]
+
+
+@pytest.mark.gpu
+def test_sysfs_gpu_enumeration_agrees_with_the_runtime(ctx):
+    """A rank pins itself to its GPU's NUMA node BEFORE it touches the GPU: the PCI address comes from the KFD
+    topology in sysfs (cova_amd.multigpu.kfd_gpu_bus_ids), not from a HIP call.  Where the topology is readable its device order
+    must be the runtime's: device d of the list = hipDeviceGetPCIBusId(d), for every device the runtime shows."""
+    import ctypes as C
+    from cova_amd import _lib as L
+    from cova_amd.multigpu import gpu_numa, gpu_numa_sysfs, kfd_gpu_bus_ids
+    ids = kfd_gpu_bus_ids()
+    n = C.c_int(0)
+    assert L.lib().covahip_device_count(C.byref(n)) == 0 and n.value >= 1
+    if not ids:
+        pytest.skip("KFD topology not readable on this box: bench.py falls back to asking a child process")
+    assert len(ids) == n.value, (ids, n.value)
+    for d in range(n.value):
+        buf = C.create_string_buffer(32)
+        assert L.lib().covahip_device_pci_bus_id(d, buf, len(buf)) == 0
+        assert buf.value.decode().lower() == ids[d], (d, buf.value, ids)
+        node, cpus, dev = gpu_numa_sysfs(d)
+        assert dev == d and (node, cpus) == gpu_numa(d)

@@ -137,5 +137,5 @@ def test_eight_rank_control_path_of_bench():
         assert len(flat) == len(set(flat)), "eight ranks split the granted cores"                      # eight disjoint core sets
     else:
         assert all(c == cpus[0] for c in cpus) or all(x["pinned"] for x in ranks)                      # the documented sharing fallback
-    per_rank = [json.loads(l)["bench_rank"] for l in r.stderr.splitlines() if l.startswith('{"bench_rank"')]
+    per_rank = [json.loads(l)["bench_rank"] for l in r.stderr.splitlines() if l.startswith('{"bench_rank"')]   # (one write per line: bench.rank_line)
     assert sorted(x["rank"] for x in per_rank) == list(range(8))

@@ -25,5 +25,11 @@ for SPEC in "frames 3" "frames 1" "stack 1"; do
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/${ENTRY}_pmc_sq -- python3 $R/bench.py --steps 20 --warmup 5 $ARGS > /dev/null 2> $OUT/${ENTRY}_pmc_sq.err
   python3 $R/tools/pmc_summary.py $OUT/${ENTRY}_pmc_sq > $OUT/${ENTRY}_pmc_sq.txt
 done
-find $OUT -name "*kernel_trace.csv" -delete   # large; the stats summary is what is kept
+# round 6: bboxcc over objects per frame at B = 65,536, the LDS bank-conflict share per kernel, the pinned
+# pipeline's host cost over lanes x slots and its kernel + memory-copy time line (C driver)
+SWEEP_KINDS=blobs,obj6,obj20,obj50,obj100 SWEEP_BATCHES=65536 SWEEP_OUT=$OUT/bboxcc_objects_B65536.json python3 $R/tools/bboxcc_sweep.py > $OUT/bboxcc_objects_B65536.txt 2>&1
+PHC_CFGS="3 3;3 6" bash $R/tools/pipe_host_cost.sh cur > $OUT/pipe_host_cost.txt 2>&1
+bash $R/tools/pipe_trace2.sh $OUT/pipe_trace c_driver_3x6_blob blob 3 6 > $OUT/pipe_trace.log 2>&1
+python3 $R/tools/pipe_timeline.py $OUT/pipe_trace c_driver_3x6_blob 600 > $OUT/pipe_timeline_c_driver_3x6_blob.txt 2>&1
+find $OUT -name "*kernel_trace.csv" -not -path "*pipe_trace*" -delete   # large; the stats summary is what is kept
 ls $OUT | head -40
