@@ -455,13 +455,14 @@ def pipelined_host_rate(net, frames, index, steps):
     the decoder's four bytes per macroblock."""
     from cova_amd.elements import FilterPipe, pack_frames
     B, nf = index.shape[0], frames.shape[0]
-    res = {}
+    NSLOT = 4      # one more slot than lanes (round 6; rounds 2-5: three)
+    res = {"slots": NSLOT}
     for packed, fill in ((True, False), (True, True), (False, False)):
-      pipe = FilterPipe(net, max_batch=B, max_frames=nf, max_boxes=MAX_BOXES, n_slots=3, packed=packed)
+      pipe = FilterPipe(net, max_batch=B, max_frames=nf, max_boxes=MAX_BOXES, n_slots=NSLOT, packed=packed)
       src = pack_frames(frames) if packed else frames
       for fill in (fill,):
         slots = []
-        for _ in range(3):                     # every slot holds the batch once; warms the plan and the speculative copy size
+        for _ in range(NSLOT):                 # every slot holds the batch once; warms the plan and the speculative copy size
             slot, pf, pi = pipe.acquire()
             pf[:nf] = src; pi[:B] = index
             pipe.submit(slot, nf, B, CC_THRESHOLD)

@@ -178,6 +178,7 @@ DEV_PROTOTYPES = {
     "covahip_dev_graph_probe": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int, C.POINTER(C.c_float),
                                           C.POINTER(C.c_float)]),
     "covahip_dev_bboxcc_overflow": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "covahip_dev_pipe_queue_plan": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 
 _lib = None

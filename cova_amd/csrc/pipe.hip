@@ -7,6 +7,9 @@
 //   * H2D of batch k+1, the kernels of batch k (a lane of the ctx: its own stream and activation workspace, so the
 //     kernels of consecutive batches overlap as well), D2H of batch k-1, chained by events -- PCIe traffic in both
 //     directions hides behind the kernels;
+//   * (round 6) WHERE the copy streams land among the runtime's hardware queues is measured at creation, not left to the order
+//     in which the process happened to create its streams: the upload stream takes a queue no active lane uses, and a batch's
+//     results leave on the lane that ran it (streams_share_queue below; 2.2 M frames/s PCIe-inclusive instead of 1.4 - 1.9 M);
 //   * boxes are compacted on the device (exclusive scan of the per-frame counts -> one packed array + offsets), so
 //     the D2H copy carries what exists, not batch x max_boxes slots.
 //
@@ -14,6 +17,7 @@
 // (pipeline/cova/pipeline.py:139-261), with metapreprocess' stacking (imp.rs:288-332) as the GPU-side gather of
 // covahip_filter_forward_frames.
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "blobnet.h"
@@ -79,6 +83,34 @@ __global__ __launch_bounds__(64) void pack_kernel(const covahip_box *__restrict_
     for (int i = lane; i < n * 5; i += 64) dst[i] = src[i];
 }
 
+// ---- which hardware queue does a stream share?  (round 6; DESIGN.md "The copy streams' hardware queues")
+// HIP multiplexes its streams onto a few hardware queues (four by default).  Packets of different streams that share one are
+// processed in order, so a copy stream's marker that waits for an 88 us upload -- or for a lane's kernels -- holds up every kernel a
+// lane has queued behind it: with the ctx's five streams (primary + four lanes) every queue is taken, and where the pipe's two copy
+// streams land decided between 116 and 182 us per batch on one box (creation order alone).  The pipe therefore MEASURES where a
+// candidate stream lands: a kernel that spins for PROBE_US on stream A, an empty kernel on stream B right behind it -- B's kernel
+// finishes early unless the two share a hardware queue.
+constexpr int PROBE_US = 120;
+__global__ __launch_bounds__(64) void spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+__global__ __launch_bounds__(64) void empty_kernel() {}
+// true: work on `b` waits for work enqueued earlier on `a` (they share a hardware queue)
+static bool streams_share_queue_once(hipStream_t a, hipStream_t b) {
+    hipStreamSynchronize(a);
+    hipStreamSynchronize(b);
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, (unsigned long long)PROBE_US * 100);
+    hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, b);
+    hipStreamSynchronize(b);
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    hipStreamSynchronize(a);
+    return us > 0.6 * PROBE_US;
+}
+// (a host thread that loses its core between the two launches and the wait reads as "shared": a positive is confirmed once)
+static bool streams_share_queue(hipStream_t a, hipStream_t b) { return streams_share_queue_once(a, b) && streams_share_queue_once(a, b); }
+
 struct Slot {
     uint8_t *h_frames = nullptr;
     int32_t *h_index = nullptr;
@@ -106,6 +138,8 @@ struct covahip_pipe {
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     std::vector<Slot> slots;
     int next = 0;
+    bool results_on_lane = false;    // the copy-out of a batch is enqueued on the lane that ran its kernels (see covahip_pipe_submit)
+    int queue_plan[2] = {0, 0};      // active lanes that share a hardware queue with the upload / the result stream (covahip_dev_pipe_queue_plan)
 };
 
 #define PIPE_CHECK(expr) COVAHIP_CHECK_HIP(p->ctx, expr)
@@ -154,9 +188,44 @@ int covahip_pipe_create(covahip_ctx *ctx, int max_batch, int max_frames, int max
     p->spec = std::min(max_batch * max_boxes, std::max(1024, max_batch * 16));
     p->slots.resize(n_slots);
     auto fail = [&](int rc) { covahip_pipe_destroy(p); return rc; };
-    if (hipStreamCreateWithFlags(&p->s_h2d, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&p->s_d2h, hipStreamNonBlocking) != hipSuccess)
-        return fail(COVAHIP_ERR_HIP);
+    {
+        // the copy streams: among a few candidates, the upload stream is one that shares its hardware queue with as few ACTIVE lanes
+        // as possible (none, while the ctx runs at most three of its four lanes: the primary stream's queue is idle while a pipe is
+        // fed), the result stream one that does not share the upload stream's queue, again with as few active lanes as possible
+        constexpr int NC = 8;
+        hipStream_t cand[NC] = {};
+        int busy[NC];              // active lanes on the candidate's queue
+        int nc = 0;
+        covahip_sync_all(ctx);
+        for (; nc < NC; nc++) {
+            if (hipStreamCreateWithFlags(&cand[nc], hipStreamNonBlocking) != hipSuccess) break;
+            busy[nc] = 0;
+            if (ctx->n_lanes > 1)
+                for (int l = 0; l < ctx->n_lanes; l++) busy[nc] += streams_share_queue(ctx->lanes[l].stream, cand[nc]);
+            else
+                busy[nc] = streams_share_queue(ctx->primary, cand[nc]);   // one lane: the kernels run on the primary stream
+        }
+        if (nc < 2) {
+            for (int i = 0; i < nc; i++) hipStreamDestroy(cand[i]);
+            return fail(COVAHIP_ERR_HIP);
+        }
+        int up = 0;
+        for (int i = 1; i < nc; i++)
+            if (busy[i] < busy[up]) up = i;
+        int down = -1;
+        for (int i = 0; i < nc; i++) {
+            if (i == up || streams_share_queue(cand[up], cand[i])) continue;
+            if (down < 0 || busy[i] < busy[down]) down = i;
+        }
+        if (down < 0) down = up == 0 ? 1 : 0;   // (one hardware queue for everything: nothing to choose)
+        p->s_h2d = cand[up];
+        p->s_d2h = cand[down];
+        p->queue_plan[0] = busy[up]; p->queue_plan[1] = busy[down];
+        p->results_on_lane = busy[up] == 0 && ctx->n_lanes > 1 && ctx->n_lanes <= 3;
+        for (int i = 0; i < nc; i++)
+            if (i != up && i != down) hipStreamDestroy(cand[i]);
+        (void)hipGetLastError();
+    }
     const size_t meta_ints = (size_t)2 * max_batch + 1;
     const size_t meta_bytes = (meta_ints * sizeof(int32_t) + 63) & ~(size_t)63;   // the packed boxes start 64-byte aligned behind it
     p->meta_bytes = meta_bytes;
@@ -183,6 +252,14 @@ int covahip_pipe_create(covahip_ctx *ctx, int max_batch, int max_frames, int max
         }
     }
     *out = p;
+    return COVAHIP_OK;
+}
+
+// developer / test view of what the probe at creation found (include/covahip_dev.h)
+int covahip_dev_pipe_queue_plan(covahip_pipe *p, int *lanes_on_upload_queue, int *lanes_on_result_queue) {
+    if (!p) return COVAHIP_ERR_INVALID_ARG;
+    if (lanes_on_upload_queue) *lanes_on_upload_queue = p->queue_plan[0];
+    if (lanes_on_result_queue) *lanes_on_result_queue = p->queue_plan[1];
     return COVAHIP_OK;
 }
 
@@ -256,15 +333,22 @@ int covahip_pipe_submit(covahip_pipe *p, int slot, int n_frames, int batch, int 
                            p->max_boxes, self ? (const int32_t *)nullptr : (const int32_t *)d_offsets, d_offsets, s.d_packed);
     }
     PIPE_CHECK(hipGetLastError());
-    PIPE_CHECK(hipEventRecord(s.ev_done, ctx->stream));
-    PIPE_CHECK(hipStreamWaitEvent(p->s_d2h, s.ev_done, 0));
+    // the results leave on the LANE's own stream when the upload stream has a hardware queue without a lane (up to three lanes): a
+    // separate result stream shares its queue with some lane, and its wait for THIS lane's kernels then holds that other lane's next
+    // batch up (3 lanes x 3 slots: 122 vs 147 us per batch); with every queue taken by a lane (four lanes) the separate stream is
+    // the better of two evils (120 vs 130)
+    hipStream_t s_out = p->results_on_lane ? ctx->stream : p->s_d2h;
+    if (!p->results_on_lane) {
+        PIPE_CHECK(hipEventRecord(s.ev_done, ctx->stream));
+        PIPE_CHECK(hipStreamWaitEvent(p->s_d2h, s.ev_done, 0));
+    }
     // counts [batch], offsets [batch + 1] (max_batch apart) and the packed boxes behind them are one allocation: ONE copy brings the
     // meta words and the speculative part of the boxes
     s.spec = std::min(p->spec, batch * p->max_boxes);
-    PIPE_CHECK(hipMemcpyAsync(s.h_meta, s.d_meta, p->meta_bytes + (size_t)s.spec * sizeof(covahip_box), hipMemcpyDeviceToHost, p->s_d2h));
+    PIPE_CHECK(hipMemcpyAsync(s.h_meta, s.d_meta, p->meta_bytes + (size_t)s.spec * sizeof(covahip_box), hipMemcpyDeviceToHost, s_out));
     if (p->want_mask)
-        PIPE_CHECK(hipMemcpyAsync(s.h_mask, s.d_mask, (size_t)batch * p->hw, hipMemcpyDeviceToHost, p->s_d2h));
-    PIPE_CHECK(hipEventRecord(s.ev_out, p->s_d2h));
+        PIPE_CHECK(hipMemcpyAsync(s.h_mask, s.d_mask, (size_t)batch * p->hw, hipMemcpyDeviceToHost, s_out));
+    PIPE_CHECK(hipEventRecord(s.ev_out, s_out));
     s.batch = batch;
     s.n_frames = n_frames;
     s.state = 2;

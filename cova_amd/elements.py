@@ -290,6 +290,13 @@ class FilterPipe:
 
     __del__ = close
 
+    def queue_plan(self):
+        """(active lanes on the upload stream's hardware queue, active lanes on the result stream's): what the probe at creation
+        found (include/covahip_dev.h)."""
+        a, b = C.c_int(-1), C.c_int(-1)
+        L.check(self._lib.covahip_dev_pipe_queue_plan(self._h, C.byref(a), C.byref(b)), "covahip_dev_pipe_queue_plan")
+        return a.value, b.value
+
     def acquire(self):
         """-> (slot, frames u8 [max_frames][h][w][4] -- u16 [max_frames][h][w] records when packed --, index i32 [max_batch][4]):
         numpy views of the slot's pinned buffers, or None when every slot is in flight.  Result views of earlier collect() calls

@@ -182,7 +182,10 @@ int covahip_filter_forward_frames(covahip_ctx *ctx, const uint8_t *frames, int n
 /* Pipelined host-buffer form of the carrier-frame hot path, for a caller that batches frames continuously (the
  * batching element gst/gstcova.c `blobnetfilter`; stands where nvstreammux -> nvinfer -> nvstreamdemux -> maskcopy
  * -> bboxcc stand in pipeline/cova/pipeline.py:139-261).  A pipe owns n_slots batches in flight: H2D of batch k+1,
- * the kernels of batch k and D2H of batch k-1 run on three HIP streams.  Per batch:
+ * the kernels of batch k and D2H of batch k-1 overlap.  (Round 6: the runtime multiplexes its streams onto a few hardware queues and a
+ * copy stream that shares one with a lane stalls that lane; covahip_pipe_create therefore measures -- a few milliseconds, the ctx
+ * idle -- where candidate streams land for the lane count the ctx has AT THAT MOMENT, uploads on a queue without a lane and sends a
+ * batch's results out on the lane that ran it: set the lanes before creating the pipe.)  Per batch:
  *   acquire: a free slot and its PINNED host buffers -- frames u8 [max_frames][h_mb][w_mb][4] and stack_index
  *            i32 [max_batch][4] (see covahip_filter_forward_frames) -- which the caller fills in place;
  *            COVAHIP_ERR_OVERFLOW when every slot is taken (collect one first);

@@ -47,6 +47,11 @@ int covahip_dev_graph_probe(covahip_ctx *ctx, const uint8_t *d_frames, int n_fra
                             int area_thresh, covahip_box *d_boxes, int32_t *d_counts, int max_boxes, uint8_t *d_mask, int iters,
                             float *ms_direct, float *ms_graph);
 
+/* What covahip_pipe_create's hardware-queue probe decided (pipe.hip, round 6): how many of the ctx's ACTIVE lanes share a hardware
+ * queue with the pipe's upload stream / with its result stream.  0 / <= 1 with up to three lanes on the default four queues. */
+struct covahip_pipe;
+int covahip_dev_pipe_queue_plan(struct covahip_pipe *pipe, int *lanes_on_upload_queue, int *lanes_on_result_queue);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,44 @@ def test_batches_past_the_self_scan_limit_take_the_scan_kernel(ctx, weights_flat
     pipe.close()
 
 
+@pytest.mark.parametrize("lanes", [1, 2, 3, 4])
+def test_copy_streams_keep_off_the_lanes_hardware_queues(ctx, weights_flat, lanes):
+    """Round 6: HIP multiplexes its streams onto a few hardware queues; a copy stream that shares one with a lane holds that lane's
+    kernels up behind its markers (113 - 182 us per batch depending on where the streams land -- creation order alone).  The pipe
+    MEASURES where candidate streams land (pipe.hip, streams_share_queue) and takes an upload stream that shares its queue with no
+    active lane; the results of a batch then leave on the lane that ran it (up to three lanes).  Results unchanged, whatever the
+    lane count."""
+    h, w, b = 45, 80, 24
+    ctx.set_lanes(lanes)
+    pipe = None
+    try:
+        net = BlobNetInfer(ctx, weights_flat, h, w, max_batch=b)
+        frames, index = synth.carrier_batch(b, h, w, seed=5, streams=2)
+        boxes, counts, _, _ = net.filter_frames(frames, index, 2, max_boxes=128)
+        pipe = FilterPipe(net, max_batch=b, max_frames=frames.shape[0], max_boxes=128, n_slots=4, want_mask=(lanes == 2))
+        up, down = pipe.queue_plan()
+        assert up == 0 if lanes <= 3 else up <= 1, (lanes, up, down)
+        assert 0 <= down <= 1
+        for rnd in range(3):
+            slots = []
+            for _ in range(4):
+                slot, pf, pi = pipe.acquire()
+                pf[:frames.shape[0]] = frames
+                pi[:b] = index
+                pipe.submit(slot, frames.shape[0], b, 2)
+                slots.append(slot)
+            for slot in slots:
+                c, o, bx, _m = pipe.collect(slot)
+                np.testing.assert_array_equal(c, counts)
+                for i in range(b):
+                    np.testing.assert_array_equal(bx[o[i]:o[i + 1]], boxes[i, :min(counts[i], 128)])
+        pipe.acquire()
+    finally:
+        if pipe is not None:
+            pipe.close()
+        ctx.set_lanes(1)
+
+
 def test_pipe_argument_checks(ctx, weights_flat):
     lib = L.lib()
     net = BlobNetInfer(ctx, weights_flat, 45, 80, max_batch=8)
