@@ -34,6 +34,7 @@ GST_DEBUG_CATEGORY_EXTERN(cova_debug);
 
 #define BF_TIMESTEP 4
 #define BF_SLOTS 6
+#define BF_LANES 3   /* batches in flight on the GPU (round 6: three; the pipe plans its copy streams for this count, pipe.hip) */
 
 /* ===================================================================== blobnetfilter */
 typedef struct {
@@ -134,7 +135,7 @@ static gboolean bf_ensure_model(GstBlobNetFilter *s) {   /* lock held */
         return FALSE;
     }
     /* two batches in flight: every pipe slot owns its output buffers (the ctx default is one lane, include/covahip.h) */
-    rc = covahip_ctx_set_lanes(s->ctx, 2);
+    rc = covahip_ctx_set_lanes(s->ctx, BF_LANES);
     if (rc == COVAHIP_OK) rc = covahip_blobnet_load(s->ctx, blob, len, s->h_mb, s->w_mb, BF_TIMESTEP, (int)s->batch_size);
     g_free(blob);
     if (rc == COVAHIP_OK) rc = covahip_pipe_create(s->ctx, (int)s->batch_size, BF_TIMESTEP * (int)s->batch_size, (int)s->max_boxes, BF_SLOTS, 0, &s->pipe);
