@@ -558,8 +558,8 @@ def main():
             # experiment's tracker parameters, blob-like weights (a few boxes per frame, as a trained BlobNet gives)
             # (round 5: the streams hand `blobnetfilter` packed two-byte records -- caps application/x-cova-records, what
             # `h264entropydec records=true` emits -- instead of I420-sized carrier frames; the I420 form is measured beside it)
-            chain = element_rate("chain_bench.sh", ("60000", "16"), env={"CHAINBENCH_RECORDS": "1"})
-            chain_i420 = element_rate("chain_bench.sh", ("60000", "16"), env={"CHAINBENCH_RECORDS": "0"})
+            chain = element_rate("chain_bench.sh", ("150000", "16"), env={"CHAINBENCH_RECORDS": "1"})   # (round 6: 150,000 frames per stream; 60,000 moved +- 20 % from run to run)
+            chain_i420 = element_rate("chain_bench.sh", ("150000", "16"), env={"CHAINBENCH_RECORDS": "0"})
             if "frames_per_s_full_chain" in chain:
                 chain["input"] = "application/x-cova-records (packed two-byte records per macroblock)"
                 chain["frames_per_s_full_chain_i420_carrier_frames"] = chain_i420.get("frames_per_s_full_chain")
