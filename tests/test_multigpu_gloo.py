@@ -139,3 +139,37 @@ def test_eight_rank_control_path_of_bench():
         assert all(c == cpus[0] for c in cpus) or all(x["pinned"] for x in ranks)                      # the documented sharing fallback
     per_rank = [json.loads(l)["bench_rank"] for l in r.stderr.splitlines() if l.startswith('{"bench_rank"')]   # (one write per line: bench.rank_line)
     assert sorted(x["rank"] for x in per_rank) == list(range(8))
+
+
+def test_kfd_topology_enumeration(tmp_path, monkeypatch):
+    """multigpu.kfd_gpu_bus_ids on a made-up KFD topology: CPU nodes (no SIMDs) are skipped, GPUs whose render node the process
+    cannot open are skipped (what the runtime does in a container that is granted one GPU of eight), location_id / domain become a
+    PCI address, and a *_VISIBLE_DEVICES list of indices selects from that order; anything else than indices gives up ([])."""
+    from cova_amd.multigpu import kfd_gpu_bus_ids
+    nodes, dri = tmp_path / "nodes", tmp_path / "dri"
+    dri.mkdir()
+    spec = [  # (simd_count, drm_render_minor, location_id, domain, render node present)
+        (0, -1, 0, 0, False),                 # the CPU
+        (1024, 128, 0x0500, 0, True),         # 0000:05:00.0
+        (1024, 129, 0x1508, 0, False),        # not granted to this process
+        (1024, 130, 0x2600, 1, True),         # 0001:26:00.0
+        (1024, 131, (0x65 << 8) | (0x1f << 3) | 0x7, 0, True),   # 0000:65:1f.7
+    ]
+    for n, (simd, minor, loc, dom, present) in enumerate(spec):
+        d = nodes / str(n)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count 0\nsimd_count {simd}\ndrm_render_minor {minor}\nlocation_id {loc}\ndomain {dom}\n")
+        if present:
+            (dri / f"renderD{minor}").write_text("")
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    ids = kfd_gpu_bus_ids(str(nodes), str(dri))
+    assert ids == ["0000:05:00.0", "0001:26:00.0", "0000:65:1f.7"]
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,0")
+    assert kfd_gpu_bus_ids(str(nodes), str(dri)) == ["0000:65:1f.7", "0000:05:00.0"]
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1,2")           # applied first: the runtime below HIP sees two GPUs
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1")
+    assert kfd_gpu_bus_ids(str(nodes), str(dri)) == ["0000:65:1f.7"]
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "GPU-0123456789abcdef")
+    assert kfd_gpu_bus_ids(str(nodes), str(dri)) == []
+    assert kfd_gpu_bus_ids(str(tmp_path / "absent"), str(dri)) == []
