@@ -165,37 +165,57 @@ __device__ __forceinline__ int frame_wave(const uint8_t *m, uint8_t *sm, const W
     for (int i = lane; i < n; i += 64) lab[i] = (uint32_t)i;
     wave_fence();
 
-    // ---- C: runs of my block row
-    uint64_t Sr = S;
-    int idx = base;
-    while (__any(Sr != 0)) {
-        uint64_t Tu = 0;
-        if (Sr) {
-            const int s = ctz64(Sr);
-            Sr &= Sr - 1;
-            const uint64_t jr = (J >> s) >> 1;                       // bit k: block s+1+k is joined to its left neighbour
-            const int e = s + (~jr ? ctz64(~jr) : 0);                // jr has zeros above BW, so ~jr != 0
-            const uint64_t mk = mask_upto(e) & ~((1ull << s) - 1);   // the run's blocks
-            const uint64_t ra = a & mk, rb = b & mk, rc = c & mk, rd = d & mk;
-            s_area[idx] = (uint32_t)(__popcll((unsigned long long)ra) + __popcll((unsigned long long)rb) +
-                                     __popcll((unsigned long long)rc) + __popcll((unsigned long long)rd));
-            s_minx[idx] = (uint32_t)(2 * s + (((a | c) >> s) & 1 ? 0 : 1));
-            s_maxx[idx] = (uint32_t)(2 * e + (((b | d) >> e) & 1 ? 1 : 0));
-            s_miny[idx] = (uint32_t)(2 * lane + ((ra | rb) ? 0 : 1));
-            s_maxy[idx] = (uint32_t)(2 * lane + ((rc | rd) ? 1 : 0));
-            Tu = (cU & mk) | ((cUL & mk) >> 1) | ((cUR & mk) << 1);   // blocks of the row above this run touches
-        }
-        while (__any(Tu != 0)) {
-            if (Tu) {
-                const int p = ctz64(Tu);
-                const int rank = __popcll((unsigned long long)(S_up << (63 - p))) - 1;   // run of the row above that holds block p
-                const uint64_t jr = (J_up >> p) >> 1;
-                const int e_up = p + (~jr ? ctz64(~jr) : 0);
-                Tu &= ~mask_upto(e_up);
-                ccbody::uf_union(lab, (uint32_t)idx, (uint32_t)(base_up + rank));
+    // ---- C: runs of a block row.  Round 6: the lanes behind the last block row HELP -- lane BH + r takes the odd-ranked runs of block
+    // row r (r < 64 - BH; at 68 rows of pixels 30 of the 34 block rows get a helper), so a frame with many objects walks half as many
+    // runs per lane (the longest row sets the pace of the wave).  A helper fetches its row's planes with wave shuffles and derives the
+    // masks itself; run ids -- and with them the order of the boxes -- are what they were.
+    {
+        const int nhelp = min(64 - g.BH, g.BH);
+        const bool helper = lane >= g.BH && lane - g.BH < nhelp;
+        const int row = helper ? lane - g.BH : lane;
+        const bool split = row < nhelp;   // this row's runs are shared between its lane and a helper
+        const uint64_t ha = (uint64_t)__shfl((unsigned long long)a, row, 64), hb = (uint64_t)__shfl((unsigned long long)b, row, 64);
+        const uint64_t hc = (uint64_t)__shfl((unsigned long long)c, row, 64), hd = (uint64_t)__shfl((unsigned long long)d, row, 64);
+        const uint64_t hue = (uint64_t)__shfl((unsigned long long)ue, row, 64), huo = (uint64_t)__shfl((unsigned long long)uo, row, 64);
+        const uint64_t hSu = (uint64_t)__shfl((unsigned long long)S_up, row, 64), hJu = (uint64_t)__shfl((unsigned long long)J_up, row, 64);
+        const int hbase = __shfl(base, row, 64), hbase_up = __shfl(base_up, row, 64);
+        const uint64_t hJ = (ha | hc) & ((hb | hd) << 1);
+        const uint64_t hS = (ha | hb | hc | hd) & ~hJ;
+        const uint64_t hcU = (ha | hb) & (hue | huo), hcUL = ha & (huo << 1), hcUR = hb & (hue >> 1);
+        // P: bit i = parity of the number of run starts at or below block i -> hS & P = runs of even rank, hS & ~P = odd rank
+        uint64_t P = hS;
+        P ^= P << 1; P ^= P << 2; P ^= P << 4; P ^= P << 8; P ^= P << 16; P ^= P << 32;
+        uint64_t Sr = lane >= g.BH && !helper ? 0 : !split ? hS : helper ? hS & ~P : hS & P;
+        while (__any(Sr != 0)) {
+            uint64_t Tu = 0;
+            int idx = 0;
+            if (Sr) {
+                const int s = ctz64(Sr);
+                Sr &= Sr - 1;
+                idx = hbase + __popcll((unsigned long long)(hS & ((1ull << s) - 1)));
+                const uint64_t jr = (hJ >> s) >> 1;                      // bit k: block s+1+k is joined to its left neighbour
+                const int e = s + (~jr ? ctz64(~jr) : 0);                // jr has zeros above BW, so ~jr != 0
+                const uint64_t mk = mask_upto(e) & ~((1ull << s) - 1);   // the run's blocks
+                const uint64_t ra = ha & mk, rb = hb & mk, rc = hc & mk, rd = hd & mk;
+                s_area[idx] = (uint32_t)(__popcll((unsigned long long)ra) + __popcll((unsigned long long)rb) +
+                                         __popcll((unsigned long long)rc) + __popcll((unsigned long long)rd));
+                s_minx[idx] = (uint32_t)(2 * s + (((ha | hc) >> s) & 1 ? 0 : 1));
+                s_maxx[idx] = (uint32_t)(2 * e + (((hb | hd) >> e) & 1 ? 1 : 0));
+                s_miny[idx] = (uint32_t)(2 * row + ((ra | rb) ? 0 : 1));
+                s_maxy[idx] = (uint32_t)(2 * row + ((rc | rd) ? 1 : 0));
+                Tu = (hcU & mk) | ((hcUL & mk) >> 1) | ((hcUR & mk) << 1);   // blocks of the row above this run touches
+            }
+            while (__any(Tu != 0)) {
+                if (Tu) {
+                    const int p = ctz64(Tu);
+                    const int rank = __popcll((unsigned long long)(hSu << (63 - p))) - 1;   // run of the row above that holds block p
+                    const uint64_t jr = (hJu >> p) >> 1;
+                    const int e_up = p + (~jr ? ctz64(~jr) : 0);
+                    Tu &= ~mask_upto(e_up);
+                    ccbody::uf_union(lab, (uint32_t)idx, (uint32_t)(hbase_up + rank));
+                }
             }
         }
-        idx++;
     }
 
     wave_fence();
