@@ -147,7 +147,6 @@ __device__ __forceinline__ int frame_wave(const uint8_t *m, uint8_t *sm, const W
     const uint64_t F = a | b | c | d;
     const uint64_t J = (a | c) & ((b | d) << 1);
     const uint64_t S = F & ~J;
-    const uint64_t cU = (a | b) & (ue | uo), cUL = a & (uo << 1), cUR = b & (ue >> 1);
     const int nr = __popcll((unsigned long long)S);
     int incl = nr;
 #pragma unroll
