@@ -75,7 +75,7 @@ int covahip_ctx_sync(covahip_ctx *ctx);
  *     (inputs may be shared) or call covahip_ctx_sync between them.
  * n_lanes in [1, 4]; DEFAULT 1 = strictly in call order on one stream, no hidden concurrency (the boundary the reference's
  * own FFI has, cova-rs/nvdsbbox/nvdsbbox.h:7-14).  A caller that owns one set of output buffers per batch in flight opts in
- * with covahip_ctx_set_lanes(ctx, 2): the blobnetfilter element, tools/pipe_bench and bench.py do (covahip_pipe_* slots own
+ * with covahip_ctx_set_lanes(ctx, n), n = 2 or 3: the blobnetfilter element, tools/pipe_bench and bench.py do (covahip_pipe_* slots own
  * their buffers).  Workspace per lane at 68x120, max_batch 256: about 150 MB.  Drains the ctx first. */
 int covahip_ctx_set_lanes(covahip_ctx *ctx, int n_lanes);
 int covahip_ctx_get_lanes(covahip_ctx *ctx, int *n_lanes);
