@@ -18,6 +18,7 @@
 // covahip_filter_forward_frames.
 #include <algorithm>
 #include <chrono>
+#include <ctime>
 #include <vector>
 
 #include "blobnet.h"
@@ -138,6 +139,7 @@ struct covahip_pipe {
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     std::vector<Slot> slots;
     int next = 0;
+    bool sleeping_wait = false;      // covahip_pipe_set_blocking_wait: wait / collect poll + sleep instead of hipEventSynchronize
     bool results_on_lane = false;    // the copy-out of a batch is enqueued on the lane that ran its kernels (see covahip_pipe_submit)
     int queue_plan[2] = {0, 0};      // active lanes that share a hardware queue with the upload / the result stream (covahip_dev_pipe_queue_plan)
 };
@@ -276,11 +278,27 @@ int covahip_pipe_set_packed(covahip_pipe *p, int on) {
 // then burns a whole core doing so (13 - 16 % of the chain's CPU samples sat in the HSA runtime, tools/prof_resolve.py).  With
 // blocking waits the slot's "results are in host memory" event is created with hipEventBlockingSync and the waiting thread
 // sleeps until the completion interrupt; several slots are in flight, so the wake-up latency is not on the critical path.
+// Round 6: the call-chain profile of the plugin chain (profiles/r6/chain_call_chains_before.txt) put 12.5 % of the process's CPU
+// samples inside hipEventSynchronize under covahip_pipe_wait -- WITH hipEventBlockingSync: the runtime spins on the signal for a
+// while before it parks, and with a batch every 110 - 200 us it never gets to park.  A sleeping wait is therefore a poll:
+// hipEventQuery, then a nanosleep of 20 us (the kernel's timer slack makes that ~70 us), a handful of wake-ups per batch.
+static int wait_event_sleeping(hipEvent_t ev) {
+    while (true) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return COVAHIP_OK;
+        if (q != hipErrorNotReady) return COVAHIP_ERR_HIP;
+        (void)hipGetLastError();
+        struct timespec ts = {0, 20000};
+        nanosleep(&ts, nullptr);
+    }
+}
+
 int covahip_pipe_set_blocking_wait(covahip_pipe *p, int on) {
     if (!p) return COVAHIP_ERR_INVALID_ARG;
     for (const Slot &s : p->slots)
         if (s.state != 0) return COVAHIP_ERR_INVALID_ARG;   // not with slots acquired or in flight
     if (hipSetDevice(p->ctx->device) != hipSuccess) return COVAHIP_ERR_HIP;
+    p->sleeping_wait = on != 0;
     for (Slot &s : p->slots) {
         hipEvent_t ev = nullptr;
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming | (on ? hipEventBlockingSync : 0)) != hipSuccess) return COVAHIP_ERR_HIP;
@@ -357,6 +375,7 @@ int covahip_pipe_submit(covahip_pipe *p, int slot, int n_frames, int batch, int 
 
 int covahip_pipe_wait(covahip_pipe *p, int slot) {
     if (!p || slot < 0 || slot >= p->n_slots || p->slots[slot].state != 2) return COVAHIP_ERR_INVALID_ARG;
+    if (p->sleeping_wait) return wait_event_sleeping(p->slots[slot].ev_out);
     if (hipEventSynchronize(p->slots[slot].ev_out) != hipSuccess) return COVAHIP_ERR_HIP;
     return COVAHIP_OK;
 }
@@ -382,7 +401,11 @@ int covahip_pipe_collect(covahip_pipe *p, int slot, const int32_t **counts, cons
     if (!p || slot < 0 || slot >= p->n_slots || p->slots[slot].state != 2) return COVAHIP_ERR_INVALID_ARG;
     Slot &s = p->slots[slot];
     PIPE_CHECK(hipSetDevice(p->ctx->device));
-    PIPE_CHECK(hipEventSynchronize(s.ev_out));
+    if (p->sleeping_wait) {
+        if (wait_event_sleeping(s.ev_out) != COVAHIP_OK) { p->ctx->last_hip_error = "covahip_pipe_collect: hipEventQuery failed"; return COVAHIP_ERR_HIP; }
+    } else {
+        PIPE_CHECK(hipEventSynchronize(s.ev_out));
+    }
     const int32_t *off = s.h_meta + p->max_batch;
     const int total = off[s.batch];
     if (total > s.spec) {   // more boxes than the pipelined copy carried: fetch the rest now, and copy more from the next batch on

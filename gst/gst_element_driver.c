@@ -376,15 +376,25 @@ static int run_muxbench(const char *desc, int n_pads, int w_px, int h_px, int fr
 static void *prof_pc[_PROF_MAX];
 static int prof_tid[_PROF_MAX];
 static volatile gint prof_n;
+#include <execinfo.h>
 #include <sys/syscall.h>
+/* CHAINBENCH_PROF_STACKS=1 (round 6): up to PROF_DEPTH return addresses per sample (glibc backtrace: primed once before the timer
+ * starts so that the unwinder is loaded; the raw file then carries the whole chain, innermost first) */
+#define PROF_DEPTH 12
+#define PROF_STACK_MAX 20000
+static void *prof_stack[PROF_STACK_MAX][PROF_DEPTH];
+static int prof_stack_n[PROF_STACK_MAX];
+static int prof_stacks_on;
 static void prof_handler(int sig, siginfo_t *si, void *uc_) {
     ucontext_t *uc = uc_;
     const gint k = g_atomic_int_add(&prof_n, 1);
     if (k < _PROF_MAX) { prof_pc[k] = (void *)uc->uc_mcontext.gregs[REG_RIP]; prof_tid[k] = (int)syscall(SYS_gettid); }
+    if (prof_stacks_on && k < PROF_STACK_MAX) prof_stack_n[k] = backtrace(prof_stack[k], PROF_DEPTH);
 }
 static void prof_start(void) {
     struct sigaction sa;
     struct itimerval it = {{0, 500}, {0, 500}};   /* 2 kHz of CPU time */
+    if (getenv("CHAINBENCH_PROF_STACKS")) { void *prime[4]; backtrace(prime, 4); prof_stacks_on = 1; }
     memset(&sa, 0, sizeof sa);
     sa.sa_sigaction = prof_handler;
     sa.sa_flags = SA_SIGINFO | SA_RESTART;
@@ -414,8 +424,15 @@ static void prof_report(void) {
             snprintf(path, sizeof path, "/proc/self/task/%d/comm", prof_tid[i]);   /* (a thread that has exited by now stays "?") */
             if ((cf = fopen(path, "r"))) { if (fgets(comm, sizeof comm, cf)) comm[strcspn(comm, "\n")] = 0; fclose(cf); }
             for (char *c = comm; *c; c++) if (*c == ' ') *c = '_';
-            if (dladdr(prof_pc[i], &di) && di.dli_fname) fprintf(f, "%s %lx %s\n", di.dli_fname, (unsigned long)((char *)prof_pc[i] - (char *)di.dli_fbase), comm);
-            else fprintf(f, "? %lx %s\n", (unsigned long)prof_pc[i], comm);
+            if (dladdr(prof_pc[i], &di) && di.dli_fname) fprintf(f, "%s %lx %s", di.dli_fname, (unsigned long)((char *)prof_pc[i] - (char *)di.dli_fbase), comm);
+            else fprintf(f, "? %lx %s", (unsigned long)prof_pc[i], comm);
+            if (prof_stacks_on && i < PROF_STACK_MAX)
+                for (int d = 0; d < prof_stack_n[i]; d++) {   /* " | lib offset" per frame */
+                    Dl_info dj;
+                    if (dladdr(prof_stack[i][d], &dj) && dj.dli_fname)
+                        fprintf(f, " | %s %lx %s", dj.dli_fname, (unsigned long)((char *)prof_stack[i][d] - (char *)dj.dli_fbase), dj.dli_sname ? dj.dli_sname : "-");
+                }
+            fprintf(f, "\n");
         }
         if (f) fclose(f);
     }

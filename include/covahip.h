@@ -203,8 +203,9 @@ int covahip_pipe_create(covahip_ctx *ctx, int max_batch, int max_frames, int max
 void covahip_pipe_destroy(covahip_pipe *pipe);
 /* Before the first acquire: the slots' frame area holds packed records (covahip_carrier_pack), hw * 2 bytes per carrier frame. */
 int covahip_pipe_set_packed(covahip_pipe *p, int on);
-/* Before the first acquire: covahip_pipe_wait / covahip_pipe_collect SLEEP until a slot's results have landed (completion
- * interrupt) instead of spinning on the completion signal (the default).  For callers whose host cores are the scarce resource
+/* Before the first acquire: covahip_pipe_wait / covahip_pipe_collect SLEEP until a slot's results have landed instead of spinning
+ * on the completion signal (the default).  Round 6: as a poll -- hipEventQuery + a 20 us nanosleep -- because the runtime's own
+ * blocking wait spins before it parks and, at a batch every 110 - 200 us, never parks (12.5 % of the plugin chain's CPU).  For callers whose host cores are the scarce resource
  * (`blobnetfilter`: its collector thread waits for the GPU most of the time). */
 int covahip_pipe_set_blocking_wait(covahip_pipe *p, int on);
 int covahip_pipe_acquire(covahip_pipe *pipe, int *slot, uint8_t **frames, int32_t **stack_index);
