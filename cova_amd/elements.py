@@ -281,6 +281,7 @@ class FilterPipe:
             L.check(self._lib.covahip_pipe_set_blocking_wait(h, 1), "covahip_pipe_set_blocking_wait", net.ctx.handle)
         self._batch = {}
         self._views = {}     # slot -> numpy views of its pinned input buffers (the addresses never change)
+        self._rviews = {}    # slot -> full-size numpy views of its result buffers
         self._held = []      # collected slots whose result views are still handed out
 
     def close(self):
@@ -335,15 +336,23 @@ class FilterPipe:
                 "covahip_pipe_collect", self.net.ctx.handle)
         b = self._batch.pop(slot)
         self._held.append(slot)
-        counts = np.ctypeslib.as_array(C.cast(cp.value, C.POINTER(C.c_int32)), shape=(b,))
-        offsets = np.ctypeslib.as_array(C.cast(op.value, C.POINTER(C.c_int32)), shape=(b + 1,))
-        total = int(offsets[b])
-        raw = np.ctypeslib.as_array(C.cast(bp.value, C.POINTER(C.c_int32)), shape=(max(total, 1) * 5,))[:total * 5]
-        boxes = raw.view(L.BOX_DTYPE)
-        mask = None
-        if mp.value:
-            mask = np.ctypeslib.as_array(C.cast(mp.value, C.POINTER(C.c_uint8)), shape=(b * self.net.h * self.net.w,)).reshape(b, self.net.h, self.net.w)
-        return counts, offsets, boxes, mask
+        # the result buffers of a slot never move: wrap them ONCE at their full size and slice per batch (np.ctypeslib.as_array costs
+        # 10 - 20 us a call; three or four of them per batch made a Python caller host-bound at ~130 us per batch on a slow box)
+        key = (slot, cp.value, op.value, bp.value, mp.value)
+        full = self._rviews.get(slot)
+        if full is None or full[0] != key:
+            counts_f = np.ctypeslib.as_array(C.cast(cp.value, C.POINTER(C.c_int32)), shape=(self.max_batch,))
+            offsets_f = np.ctypeslib.as_array(C.cast(op.value, C.POINTER(C.c_int32)), shape=(self.max_batch + 1,))
+            boxes_f = np.ctypeslib.as_array(C.cast(bp.value, C.POINTER(C.c_int32)), shape=(self.max_batch * self.max_boxes * 5,)).view(L.BOX_DTYPE)
+            mask_f = None
+            if mp.value:
+                mask_f = np.ctypeslib.as_array(C.cast(mp.value, C.POINTER(C.c_uint8)),
+                                               shape=(self.max_batch * self.net.h * self.net.w,)).reshape(self.max_batch, self.net.h, self.net.w)
+            full = (key, counts_f, offsets_f, boxes_f, mask_f)
+            self._rviews[slot] = full
+        _, counts_f, offsets_f, boxes_f, mask_f = full
+        offsets = offsets_f[:b + 1]
+        return counts_f[:b], offsets, boxes_f[:int(offsets[b])], (mask_f[:b] if mask_f is not None else None)
 
 
 # -------------------------------------------------------------------------------- bbox
